@@ -1,0 +1,375 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for the plain-C restatement of the reference's CPU algorithm
+(oracle/nvbio_oracle.c) and, when it has been built in the development container,
+for the reference's own host code (oracle/_ref/libnvbio_ref.so, built by oracle/Makefile
+from the sources under /root/reference).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; the product (nvbio-gpl_amd) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
+SCORE_MIN = -(1 << 30)
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _c8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _c32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def build(force=False):
+    """compile liboracle.so (and _ref/libnvbio_ref.so when /root/reference exists)"""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("nvbio_oracle.c", "nvbio_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libnvbio_ref.so")
+    ref_src = os.path.join(_HERE, "ref", "nvbio_ref.cpp")
+    if os.path.isdir("/root/reference/nvbio") and (
+            force or not os.path.exists(ref_so) or os.path.getmtime(ref_so) < os.path.getmtime(ref_src)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class Scheme(ctypes.Structure):
+    """orc_gotoh_scheme"""
+    _fields_ = [("match", ctypes.c_int32), ("mm_min", ctypes.c_int32), ("mm_max", ctypes.c_int32),
+                ("pat_gap_open", ctypes.c_int32), ("pat_gap_ext", ctypes.c_int32),
+                ("txt_gap_open", ctypes.c_int32), ("txt_gap_ext", ctypes.c_int32)]
+
+    @staticmethod
+    def simple(match, mismatch, gap_open, gap_ext):
+        """aln::SimpleGotohScheme(match, mismatch, gap_open, gap_ext) (nvbio/alignment/utils.h:103-123)"""
+        return Scheme(match, -mismatch, -mismatch, gap_open, gap_ext, gap_open, gap_ext)
+
+    def as_array(self):
+        return np.array([self.match, self.mm_min, self.mm_max, self.pat_gap_open, self.pat_gap_ext,
+                         self.txt_gap_open, self.txt_gap_ext], dtype=np.int32)
+
+
+class FMView(ctypes.Structure):
+    """orc_fm_index"""
+    _fields_ = [("length", ctypes.c_uint32), ("primary", ctypes.c_uint32), ("L2", ctypes.c_uint32 * 5),
+                ("bwt_occ", _u32p), ("ssa", _u32p)]
+
+
+class HostIndex:
+    """an FM-index held in numpy arrays (production layout)"""
+
+    def __init__(self, n, primary, L2, bwt_occ, ssa, sa=None, text=None):
+        self.n, self.primary = int(n), int(primary)
+        self.L2 = np.asarray(L2, dtype=np.uint32)
+        self.bwt_occ = np.ascontiguousarray(bwt_occ, dtype=np.uint32)
+        self.ssa = np.ascontiguousarray(ssa, dtype=np.uint32)
+        self.sa, self.text = sa, text
+        self.handle = None
+
+    def view(self):
+        v = FMView()
+        v.length, v.primary = self.n, self.primary
+        for i in range(5):
+            v.L2[i] = int(self.L2[i])
+        v.bwt_occ = self.bwt_occ.ctypes.data_as(_u32p)
+        v.ssa = self.ssa.ctypes.data_as(_u32p)
+        return v
+
+
+class Oracle:
+    """the C restatement"""
+
+    def __init__(self):
+        build()
+        self.lib = L = ctypes.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.orc_bwt_words.restype = ctypes.c_uint32
+        L.orc_fm_build.restype = ctypes.c_uint32
+        L.orc_rank.restype = ctypes.c_uint32
+        L.orc_dict_rank.restype = ctypes.c_uint32
+        L.orc_locate.restype = ctypes.c_uint32
+        L.orc_filter_rank.restype = ctypes.c_uint64
+        L.orc_mismatch.restype = ctypes.c_int32
+        L.orc_popc_2bit.restype = ctypes.c_uint32
+        L.orc_popc_2bit_hi.restype = ctypes.c_uint32
+        L.orc_get2.restype = ctypes.c_uint8
+        L.orc_get4.restype = ctypes.c_uint8
+
+    def num_threads(self):
+        return int(self.lib.orc_num_threads())
+
+    # ---- packing -------------------------------------------------------------------------
+    def pack2(self, syms):
+        syms = _c8(syms)
+        words = np.zeros((len(syms) + 15) // 16 + 4, dtype=np.uint32)
+        self.lib.orc_pack2(_p(syms, _u8p), ctypes.c_uint64(len(syms)), _p(words, _u32p))
+        return words
+
+    def pack4(self, syms):
+        syms = _c8(syms)
+        words = np.zeros((len(syms) + 7) // 8 + 4, dtype=np.uint32)
+        self.lib.orc_pack4(_p(syms, _u8p), ctypes.c_uint64(len(syms)), _p(words, _u32p))
+        return words
+
+    def get2(self, words, i):
+        return int(self.lib.orc_get2(_p(words, _u32p), ctypes.c_uint64(i)))
+
+    def get4(self, words, i):
+        return int(self.lib.orc_get4(_p(words, _u32p), ctypes.c_uint64(i)))
+
+    # ---- index ---------------------------------------------------------------------------
+    def suffix_sort(self, text):
+        text = _c8(text)
+        sa = np.zeros(len(text) + 1, dtype=np.uint32)
+        self.lib.orc_suffix_sort(_p(text, _u8p), ctypes.c_uint32(len(text)), _p(sa, _u32p))
+        return sa
+
+    def build_index(self, text, sa=None):
+        text = _c8(text)
+        n = len(text)
+        if sa is None:
+            sa = self.suffix_sort(text)
+        sa = _c32(sa)
+        words = int(self.lib.orc_bwt_words(ctypes.c_uint32(n)))
+        bwt_occ = np.zeros(2 * words, dtype=np.uint32)
+        ssa = np.zeros((n + 16) // 16, dtype=np.uint32)
+        L2 = np.zeros(5, dtype=np.uint32)
+        primary = self.lib.orc_fm_build(_p(text, _u8p), ctypes.c_uint32(n), _p(sa, _u32p), _p(bwt_occ, _u32p),
+                                        _p(ssa, _u32p), _p(L2, _u32p))
+        return HostIndex(n, primary, L2, bwt_occ, ssa, sa=sa, text=text)
+
+    # ---- queries -------------------------------------------------------------------------
+    def rank(self, idx, k, c):
+        v = idx.view()
+        return int(self.lib.orc_rank(ctypes.byref(v), ctypes.c_uint32(k & 0xFFFFFFFF), ctypes.c_uint32(c)))
+
+    def rank2(self, idx, l, r, c):
+        v = idx.view()
+        out = np.zeros(2, dtype=np.uint32)
+        self.lib.orc_rank2(ctypes.byref(v), ctypes.c_uint32(l & 0xFFFFFFFF), ctypes.c_uint32(r & 0xFFFFFFFF),
+                           ctypes.c_uint32(c), _p(out, _u32p))
+        return out
+
+    def rank4(self, idx, k):
+        v = idx.view()
+        out = np.zeros(4, dtype=np.uint32)
+        self.lib.orc_rank4(ctypes.byref(v), ctypes.c_uint32(k & 0xFFFFFFFF), _p(out, _u32p))
+        return out
+
+    def match_batch(self, idx, syms, offsets, reverse=False, want_blocks=False):
+        v = idx.view()
+        syms, offsets = _c8(syms), _c32(offsets)
+        n = len(offsets) - 1
+        ranges = np.zeros((n, 2), dtype=np.uint32)
+        blocks = np.zeros(n, dtype=np.uint32) if want_blocks else None
+        self.lib.orc_match_batch(ctypes.byref(v), _p(syms, _u8p), _p(offsets, _u32p), ctypes.c_uint32(n),
+                                 ctypes.c_int(1 if reverse else 0), _p(ranges, _u32p), _p(blocks, _u32p))
+        return (ranges, blocks) if want_blocks else ranges
+
+    def locate_batch(self, idx, rows):
+        v = idx.view()
+        rows = _c32(rows)
+        pos = np.zeros(len(rows), dtype=np.uint32)
+        self.lib.orc_locate_batch(ctypes.byref(v), _p(rows, _u32p), ctypes.c_uint32(len(rows)), _p(pos, _u32p))
+        return pos
+
+    def locate_ssa_batch(self, idx, rows):
+        v = idx.view()
+        out = np.zeros((len(rows), 2), dtype=np.uint32)
+        tmp = np.zeros(2, dtype=np.uint32)
+        for i, r in enumerate(rows):
+            self.lib.orc_locate_ssa(ctypes.byref(v), ctypes.c_uint32(int(r)), _p(tmp, _u32p))
+            out[i] = tmp
+        return out
+
+    def filter_rank(self, idx, syms, offsets):
+        v = idx.view()
+        syms, offsets = _c8(syms), _c32(offsets)
+        n = len(offsets) - 1
+        ranges = np.zeros((n, 2), dtype=np.uint32)
+        slots = np.zeros(n, dtype=np.uint64)
+        total = self.lib.orc_filter_rank(ctypes.byref(v), _p(syms, _u8p), _p(offsets, _u32p), ctypes.c_uint32(n),
+                                         _p(ranges, _u32p), _p(slots, _u64p))
+        return int(total), ranges, slots
+
+    def filter_locate(self, idx, ranges, slots, begin, end):
+        v = idx.view()
+        hits = np.zeros((end - begin, 2), dtype=np.uint32)
+        self.lib.orc_filter_locate(ctypes.byref(v), _p(ranges, _u32p), _p(slots, _u64p),
+                                   ctypes.c_uint32(len(slots)), ctypes.c_uint64(begin), ctypes.c_uint64(end),
+                                   _p(hits, _u32p))
+        return hits
+
+    # ---- DP ------------------------------------------------------------------------------
+    def mismatch(self, scheme, q):
+        return int(self.lib.orc_mismatch(ctypes.byref(scheme), ctypes.c_uint32(q)))
+
+    def banded_gotoh(self, band, typ, scheme, pat, txt, quals=None):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_banded_gotoh(ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(pat, _u8p),
+                                       _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                       ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def full_gotoh(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_full_gotoh(ctypes.c_int(typ), ctypes.c_int(blocking), ctypes.byref(scheme), _p(pat, _u8p),
+                                     _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                     ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc),
+                                     _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_gotoh_batch(self, band, typ, scheme, pats, pat_off, txts, txt_off, quals=None):
+        pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)
+        pat_off, txt_off = _c32(pat_off), _c32(txt_off)
+        n = len(pat_off) - 1
+        scores = np.zeros(n, dtype=np.int32)
+        sinks = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.orc_banded_gotoh_batch(ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme),
+                                        _p(pats, _u8p), _p(quals, _u8p), _p(pat_off, _u32p), _p(txts, _u8p),
+                                        _p(txt_off, _u32p), ctypes.c_uint32(n), _p(scores, _i32p), _p(sinks, _u32p))
+        return scores, sinks
+
+    def full_gotoh_batch(self, typ, blocking, scheme, pats, pat_off, txts, txt_off, quals=None, min_score=SCORE_MIN):
+        pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)
+        pat_off, txt_off = _c32(pat_off), _c32(txt_off)
+        n = len(pat_off) - 1
+        scores = np.zeros(n, dtype=np.int32)
+        sinks = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.orc_full_gotoh_batch(ctypes.c_int(typ), ctypes.c_int(blocking), ctypes.byref(scheme),
+                                      _p(pats, _u8p), _p(quals, _u8p), _p(pat_off, _u32p), _p(txts, _u8p),
+                                      _p(txt_off, _u32p), ctypes.c_uint32(n), ctypes.c_int32(min_score),
+                                      _p(scores, _i32p), _p(sinks, _u32p))
+        return scores, sinks
+
+    def banded_gotoh_packed_batch(self, band, typ, scheme, reads4, read_offsets, genome2, win_begin, win_end,
+                                  read_id=None, flags=None, quals=None):
+        reads4, read_offsets, genome2 = _c32(reads4), _c32(read_offsets), _c32(genome2)
+        win_begin, win_end, read_id = _c32(win_begin), _c32(win_end), _c32(read_id)
+        flags, quals = _c8(flags), _c8(quals)
+        n = len(win_begin)
+        scores = np.zeros(n, dtype=np.int32)
+        sinks = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.orc_banded_gotoh_packed_batch(
+            ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(reads4, _u32p),
+            _p(read_offsets, _u32p), _p(quals, _u8p), _p(read_id, _u32p), _p(flags, _u8p), _p(genome2, _u32p),
+            _p(win_begin, _u32p), _p(win_end, _u32p), ctypes.c_uint32(n), _p(scores, _i32p), _p(sinks, _u32p))
+        return scores, sinks
+
+
+class Reference:
+    """the reference's own host code (development container only)"""
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libnvbio_ref.so"))
+
+    def __init__(self):
+        self.lib = L = ctypes.CDLL(os.path.join(_HERE, "_ref", "libnvbio_ref.so"))
+        L.ref_fm_create.restype = ctypes.c_void_p
+        L.ref_fm_primary.restype = ctypes.c_uint32
+        L.ref_fm_words.restype = ctypes.c_uint32
+        L.ref_fm_ssa_words.restype = ctypes.c_uint32
+        L.ref_fm_rank.restype = ctypes.c_uint32
+
+    def build_index(self, text):
+        text = _c8(text)
+        n = len(text)
+        h = ctypes.c_void_p(self.lib.ref_fm_create(_p(text, _u8p), ctypes.c_uint32(n)))
+        words = int(self.lib.ref_fm_words(h))
+        bwt_occ = np.zeros(2 * words, dtype=np.uint32)
+        sa = np.zeros(n + 1, dtype=np.int32)
+        ssa = np.zeros(int(self.lib.ref_fm_ssa_words(h)), dtype=np.uint32)
+        L2 = np.zeros(5, dtype=np.uint32)
+        self.lib.ref_fm_export(h, None, None, _p(bwt_occ, _u32p), _p(sa, _i32p), _p(ssa, _u32p))
+        self.lib.ref_fm_L2(h, _p(L2, _u32p))
+        idx = HostIndex(n, self.lib.ref_fm_primary(h), L2, bwt_occ, ssa, sa=sa.view(np.uint32), text=text)
+        idx.handle = h
+        return idx
+
+    def destroy(self, idx):
+        self.lib.ref_fm_destroy(idx.handle)
+        idx.handle = None
+
+    def rank(self, idx, k, c):
+        return int(self.lib.ref_fm_rank(idx.handle, ctypes.c_uint32(k & 0xFFFFFFFF), ctypes.c_uint32(c)))
+
+    def rank2(self, idx, l, r, c):
+        out = np.zeros(2, dtype=np.uint32)
+        self.lib.ref_fm_rank_range(idx.handle, ctypes.c_uint32(l & 0xFFFFFFFF), ctypes.c_uint32(r & 0xFFFFFFFF),
+                                   ctypes.c_uint32(c), _p(out, _u32p))
+        return out
+
+    def rank4(self, idx, k):
+        out = np.zeros(4, dtype=np.uint32)
+        self.lib.ref_fm_rank4(idx.handle, ctypes.c_uint32(k & 0xFFFFFFFF), _p(out, _u32p))
+        return out
+
+    def match_batch(self, idx, syms, offsets, reverse=False):
+        syms, offsets = _c8(syms), _c32(offsets)
+        n = len(offsets) - 1
+        ranges = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.ref_fm_match(idx.handle, _p(syms, _u8p), _p(offsets, _u32p), ctypes.c_uint32(n), _p(ranges, _u32p),
+                              ctypes.c_int(1 if reverse else 0))
+        return ranges
+
+    def locate_batch(self, idx, rows):
+        rows = _c32(rows)
+        pos = np.zeros(len(rows), dtype=np.uint32)
+        self.lib.ref_fm_locate(idx.handle, _p(rows, _u32p), ctypes.c_uint32(len(rows)), _p(pos, _u32p))
+        return pos
+
+    def locate_ssa_batch(self, idx, rows):
+        rows = _c32(rows)
+        out = np.zeros((len(rows), 2), dtype=np.uint32)
+        self.lib.ref_fm_locate_ssa(idx.handle, _p(rows, _u32p), ctypes.c_uint32(len(rows)), _p(out, _u32p))
+        return out
+
+    def banded_gotoh(self, band, typ, scheme, pat, txt, quals=None, simple=False):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        if simple:
+            ok = self.lib.ref_banded_gotoh(ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.c_int(scheme.match),
+                                           ctypes.c_int(-scheme.mm_min), ctypes.c_int(scheme.pat_gap_open),
+                                           ctypes.c_int(scheme.pat_gap_ext), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                           _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(SCORE_MIN),
+                                           ctypes.byref(sc), _p(sk, _u32p))
+        else:
+            arr = scheme.as_array()
+            ok = self.lib.ref_banded_gotoh_ex(ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p),
+                                              _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                              ctypes.c_uint32(len(txt)), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc),
+                                              _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def full_gotoh(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        arr = scheme.as_array()
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_full_gotoh_ex(ctypes.c_int(typ), ctypes.c_int(blocking), _p(arr, _i32p), _p(pat, _u8p),
+                                        _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                        ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc),
+                                        _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))

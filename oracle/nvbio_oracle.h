@@ -1,0 +1,163 @@
+/* oracle/nvbio_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's CPU algorithm for the seed-and-extend hot
+ * path (FM-index rank / match / locate, banded and full-matrix Gotoh scoring).
+ * It is the checker for the HIP path: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product library (libnvbio_amd.so)
+ * never links, loads or calls anything in this directory.
+ *
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_*.py)
+ *   (a) against the committed golden vectors in tests/golden/, which were produced by the
+ *       reference's own host code (oracle/ref/nvbio_ref.cpp -> oracle/_ref/libnvbio_ref.so,
+ *       generator tests/golden/make_golden.py), and which include the known answers of
+ *       nvbio-test/alignment_test.cu:709-828 and nvbio-test/packedstream_test.cpp:143-172;
+ *   (b) live against oracle/_ref/libnvbio_ref.so whenever that library is present
+ *       (development container only).
+ *
+ * File:line citations are relative to the reference tree (/root/reference).
+ */
+#ifndef NVBIO_ORACLE_H
+#define NVBIO_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* --- packed streams (nvbio/basic/packedstream_inl.h:33-75; big-endian within the word) --- */
+uint8_t orc_get2(const uint32_t* words, uint64_t i);            /* 2-bit symbol i  */
+uint8_t orc_get4(const uint32_t* words, uint64_t i);            /* 4-bit symbol i  */
+void    orc_pack2(const uint8_t* syms, uint64_t n, uint32_t* words);   /* words must be zeroed/own  */
+void    orc_pack4(const uint8_t* syms, uint64_t n, uint32_t* words);
+
+/* --- 2-bit popcounts (nvbio/basic/popcount_inl.h:230-236,318-341) --- */
+uint32_t orc_popc_2bit(uint32_t x, uint32_t c);
+uint32_t orc_popc_2bit_hi(uint32_t x, uint32_t c, uint32_t i);  /* all but the first (low) i symbols */
+
+/* --- FM-index view (nvbio/fmindex/fmindex.h:320-361; production layout nvbio/io/fmindex/fmindex.h:75-177) --- */
+typedef struct
+{
+    uint32_t        length;     /* n: symbols in the text (BWT has n symbols, no '$')          */
+    uint32_t        primary;    /* row of '$'                                                    */
+    uint32_t        L2[5];      /* L2[c] = # symbols < c                                         */
+    const uint32_t* bwt_occ;    /* 32-byte records: 4 words BWT (64 symbols) + 4 words occ{A,C,G,T} */
+    const uint32_t* ssa;        /* ssa[j] = SA[16 j]; ssa[0] = 0xFFFFFFFF; (n+16)/16 entries      */
+} orc_fm_index;
+
+/* number of uint32 words of the packed BWT, padded to a multiple of 4 (fmindex_test.cu:436-438) */
+uint32_t orc_bwt_words(uint32_t n);
+
+/* suffix array of text[0,n) (one symbol per byte, values 0..3) in the reference's convention:
+ * sa[0] = n (the empty suffix), sa[1..n] = suffixes in lexicographic order, a proper prefix
+ * sorting before its extensions (nvbio/fmindex/bwt.h:28-37).  Any correct SA gives the same
+ * index, so this is a plain radix+comparison sort, not SA-IS.  sa must hold n+1 entries. */
+void orc_suffix_sort(const uint8_t* text, uint32_t n, uint32_t* sa);
+
+/* build the production index from text + SA:
+ *   bwt/primary   nvbio/fmindex/bwt.h:41-53
+ *   occ (K=64)    nvbio/fmindex/rank_dictionary_inl.h:33-66
+ *   interleave    nvbio/io/fmindex/fmindex_impl.cu:300-313
+ *   ssa (K=16)    nvbio/fmindex/ssa_inl.h:254-301 (entry 0 = -1)
+ * bwt_occ must hold 2*orc_bwt_words(n) words, ssa (n+16)/16 words.  Returns primary. */
+uint32_t orc_fm_build(const uint8_t* text, uint32_t n, const uint32_t* sa,
+                      uint32_t* bwt_occ, uint32_t* ssa, uint32_t L2[5]);
+
+/* rank_dictionary level (nvbio/fmindex/rank_dictionary_inl.h:338-479): k indexes the BWT text */
+uint32_t orc_dict_rank(const orc_fm_index* f, uint32_t k, uint32_t c);
+void     orc_dict_rank2(const orc_fm_index* f, uint32_t l, uint32_t r, uint32_t c, uint32_t out[2]);
+void     orc_dict_rank4(const orc_fm_index* f, uint32_t k, uint32_t out[4]);
+
+/* fm_index level (nvbio/fmindex/fmindex_inl.h:27-173): k indexes BWT-matrix rows */
+uint32_t orc_rank(const orc_fm_index* f, uint32_t k, uint32_t c);
+void     orc_rank2(const orc_fm_index* f, uint32_t l, uint32_t r, uint32_t c, uint32_t out[2]);
+void     orc_rank4(const orc_fm_index* f, uint32_t k, uint32_t out[4]);
+
+/* match / match_reverse (fmindex_inl.h:181-278).  pattern: one symbol per byte, >3 = N.
+ * If blocks != NULL, *blocks receives the number of distinct 32-byte bwt_occ records the
+ * search touched (the algorithmic-bytes unit of the seed pass). */
+void     orc_match(const orc_fm_index* f, const uint8_t* pattern, uint32_t len, int reverse,
+                   uint32_t out[2], uint32_t* blocks);
+
+/* locate family (fmindex_inl.h:286-460) */
+uint32_t orc_basic_inv_psi(const orc_fm_index* f, uint32_t i);
+void     orc_locate_ssa(const orc_fm_index* f, uint32_t i, uint32_t out[2]);   /* (row j, steps t) */
+uint32_t orc_lookup_ssa(const orc_fm_index* f, const uint32_t jt[2]);
+uint32_t orc_locate(const orc_fm_index* f, uint32_t i);
+
+/* batched forms: OpenMP parallel for over work items, the shape of the reference's host
+ * path (nvbio-test/fmindex_test.cu:375-407,879-890; nvbio/fmindex/filter_inl.h:193-252) */
+void orc_match_batch(const orc_fm_index* f, const uint8_t* syms, const uint32_t* offsets, uint32_t n,
+                     int reverse, uint32_t* ranges, uint32_t* blocks);
+void orc_locate_batch(const orc_fm_index* f, const uint32_t* rows, uint32_t n, uint32_t* pos);
+
+/* FMIndexFilter<host_tag> (nvbio/fmindex/filter_inl.h:193-252): ranges + inclusive scan of sizes,
+ * then hits (text_pos, query_id) for global hit indices [begin,end) */
+uint64_t orc_filter_rank(const orc_fm_index* f, const uint8_t* syms, const uint32_t* offsets, uint32_t n,
+                         uint32_t* ranges, uint64_t* slots);
+void     orc_filter_locate(const orc_fm_index* f, const uint32_t* ranges, const uint64_t* slots, uint32_t n,
+                           uint64_t begin, uint64_t end, uint32_t* hits /* 2 per hit */);
+
+/* --- Gotoh scoring --- */
+enum { ORC_GLOBAL = 0, ORC_LOCAL = 1, ORC_SEMI_GLOBAL = 2 };     /* aln::AlignmentType, alignment.h:242 */
+
+/* scoring scheme: the Gotoh scheme concept (alignment.h:437-449) with either a constant
+ * mismatch (SimpleGotohScheme, nvbio/alignment/utils.h:103-123: mm_min == mm_max == -mismatch,
+ * all four gap costs from gap_open/gap_ext) or nvBowtie's quality ramp
+ * (nvBowtie/bowtie2/cuda/scoring.h:73-92,278-285):
+ *     mismatch(q) = -( mm_min + int( float(min(q,40))/40.0f * (mm_max - mm_min) ) ). */
+typedef struct
+{
+    int32_t match;          /* score of a match (constant)                       */
+    int32_t mm_min, mm_max; /* mismatch PENALTIES (positive) at quality 0 / >=40 */
+    int32_t pat_gap_open, pat_gap_ext;  /* signed scores (negative)              */
+    int32_t txt_gap_open, txt_gap_ext;
+} orc_gotoh_scheme;
+
+int32_t orc_mismatch(const orc_gotoh_scheme* s, uint32_t q);
+
+/* Field_traits<int32>::min() = -(1<<30), the BestSink initial score (nvbio/basic/numbers.h:738-742) */
+#define ORC_SCORE_MIN (-(1 << 30))
+
+/* banded Gotoh, any odd band (gotoh_banded_inl.h:397-646, entry :668-688).
+ * pattern/text one symbol per byte; quals may be NULL (trivial_quality_string -> 0).
+ * Returns 0 if text_len < pattern_len (nothing reported), else 1.
+ * score/sink follow BestSink<int32> (sink_inl.h:31-49): init (ORC_SCORE_MIN, (-1,-1)). */
+int orc_banded_gotoh(uint32_t band, int type, const orc_gotoh_scheme* s,
+                     const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                     const uint8_t* txt, uint32_t N,
+                     int32_t* score, uint32_t sink[2]);
+
+/* full-matrix Gotoh, 8-column stripes with an int16 (short2) boundary column
+ * (gotoh_inl.h:444-841 pattern blocking, :847-1256 text blocking; alignment_score_dispatch :1283-1330).
+ * blocking: 0 = PatternBlockingTag (alignment_score default), 1 = TextBlockingTag (sw-benchmark).
+ * Returns 0 when the stripe early-exit fires (max_score + missing*match < min_score), else 1. */
+int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* s,
+                   const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                   const uint8_t* txt, uint32_t N, int32_t min_score,
+                   int32_t* score, uint32_t sink[2]);
+
+/* batched forms (OpenMP over work items: batched_banded_inl.h:113-121, batched_inl.h:283-306) */
+void orc_banded_gotoh_batch(uint32_t band, int type, const orc_gotoh_scheme* s,
+                            const uint8_t* pats, const uint8_t* quals, const uint32_t* pat_off,
+                            const uint8_t* txts, const uint32_t* txt_off, uint32_t n,
+                            int32_t* scores, uint32_t* sinks);
+void orc_full_gotoh_batch(int type, int blocking, const orc_gotoh_scheme* s,
+                          const uint8_t* pats, const uint8_t* quals, const uint32_t* pat_off,
+                          const uint8_t* txts, const uint32_t* txt_off, uint32_t n,
+                          int32_t min_score, int32_t* scores, uint32_t* sinks);
+
+/* nvBowtie-shaped batched extension over packed inputs (the CPU baseline of the extend pass):
+ * work item i aligns read reads[read_id[i]] (4-bit packed, offsets in symbols; flags bit0 = reverse
+ * the read, bit1 = complement it: alignment_utils.h:277-302) against genome[win_begin[i], win_end[i])
+ * (2-bit packed) with band `band`. */
+void orc_banded_gotoh_packed_batch(uint32_t band, int type, const orc_gotoh_scheme* s,
+                                   const uint32_t* reads4, const uint32_t* read_offsets, const uint8_t* quals,
+                                   const uint32_t* read_id, const uint8_t* flags,
+                                   const uint32_t* genome2, const uint32_t* win_begin, const uint32_t* win_end,
+                                   uint32_t n, int32_t* scores, uint32_t* sinks);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

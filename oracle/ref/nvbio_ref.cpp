@@ -1,0 +1,399 @@
+// oracle/ref/nvbio_ref.cpp -- TEST INFRASTRUCTURE, not product code.
+//
+// A thin extern "C" driver around the *reference's own* host-callable template
+// code (headers under /root/reference, compiled where they lie; nothing is
+// copied).  It is built only in the development container by oracle/Makefile
+// into oracle/_ref/libnvbio_ref.so and is used to
+//   (1) pin the C restatement in oracle/nvbio_oracle.c, and
+//   (2) generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py).
+//
+// Reference entry points exercised (file:line relative to /root/reference):
+//   gen_sa / gen_bwt_from_sa / gen_bwt_count_table    nvbio/fmindex/bwt.h:28-89
+//   build_occurrence_table<64>                        nvbio/fmindex/rank_dictionary_inl.h:33-66
+//   rank / rank4 / match / match_reverse / locate /
+//   locate_ssa_iterator / lookup_ssa_iterator         nvbio/fmindex/fmindex_inl.h:27-460
+//   dispatch_rank<2,64,...,uint4,uint4>               nvbio/fmindex/rank_dictionary_inl.h:338-479
+//   (production interleaved bwt_occ layout)           nvbio/io/fmindex/fmindex.h:151-176
+//   aln::banded_alignment_score<BAND>                 nvbio/alignment/gotoh/gotoh_banded_inl.h:397-688
+//   aln::alignment_score (text / pattern blocking)    nvbio/alignment/gotoh/gotoh_inl.h:444-1256
+//   aln::BestSink<int32>                              nvbio/alignment/sink_inl.h:31-49
+//
+// The sampled suffix array type is a template parameter of nvbio::fm_index
+// (interface: nvbio/fmindex/ssa.h:67-74).  nvbio/fmindex/ssa.h itself pulls in
+// thrust::device_vector and does not compile host-only, so the driver passes a
+// user-defined context with the same fetch()/has() semantics as
+// SSA_index_multiple_context<16> (nvbio/fmindex/ssa_inl.h:477-495) backed by the
+// SA the reference's own gen_sa() produced, with entry 0 = uint32(-1)
+// (nvbio/fmindex/ssa_inl.h:299).
+#include <nvbio/basic/types.h>
+#include <nvbio/basic/packedstream.h>
+#include <nvbio/basic/vector_view.h>
+#include <nvbio/basic/deinterleaved_iterator.h>
+#include <nvbio/fmindex/bwt.h>
+#include <nvbio/fmindex/rank_dictionary.h>
+#include <nvbio/fmindex/fmindex.h>
+#include <nvbio/alignment/alignment.h>
+#include <vector>
+#include <cstring>
+#include <cstdint>
+
+using namespace nvbio;
+
+namespace {
+
+struct SampledSA16
+{
+    typedef SampledSA16 context_type;
+    const uint32* ssa;      // ssa[j] = SA[16*j], ssa[0] = uint32(-1)
+    NVBIO_FORCEINLINE bool fetch(const uint32 i, uint32& r) const { if (i & 15u) return false; r = ssa[i >> 4]; return true; }
+    NVBIO_FORCEINLINE bool has(const uint32 i) const { return (i & 15u) == 0; }
+};
+
+struct RefIndex
+{
+    uint32                n;
+    uint32                primary;
+    uint32                L2[5];
+    std::vector<uint32>   text;        // packed 2-bit big-endian
+    std::vector<uint32>   bwt;         // packed 2-bit big-endian
+    std::vector<uint32>   occ;         // 4 counters per 64 symbols
+    std::vector<uint32>   bwt_occ;     // interleaved production layout
+    std::vector<int32>    sa;          // sa[0] = n (then -1), sa[1..n]
+    std::vector<uint32>   ssa;         // every 16-th row
+    std::vector<uint32>   count_table; // 256 entries
+
+    typedef const uint4*                                         bwt_occ_type;
+    typedef deinterleaved_iterator<2,0,bwt_occ_type>             bwt_type;
+    typedef deinterleaved_iterator<2,1,bwt_occ_type>             occ_type;
+    typedef PackedStream<bwt_type,uint8,2u,true>                 bwt_stream_type;
+    typedef rank_dictionary<2u,64u,bwt_stream_type,occ_type,const uint32*> rank_dict_type;
+    typedef fm_index<rank_dict_type,SampledSA16>                 fm_index_type;
+
+    fm_index_type fmi() const
+    {
+        const bwt_occ_type base = (bwt_occ_type)&bwt_occ[0];
+        SampledSA16 s; s.ssa = &ssa[0];
+        return fm_index_type(
+            n, primary, &L2[0],
+            rank_dict_type( bwt_stream_type( bwt_type( base ) ), occ_type( base ), &count_table[0] ),
+            s );
+    }
+};
+
+// A user-side model of the reference's Gotoh scoring-scheme concept (the aligners are
+// templated on it, nvbio/alignment/alignment.h:437-449) with the quality-ramp mismatch
+// cost and the separate read/reference gap costs of nvBowtie's
+// SmithWatermanScoringScheme<QualCost,ConstantCost> (nvBowtie/bowtie2/cuda/scoring.h:73-92,278-285).
+// nvBowtie's own header cannot be compiled host-only (it includes thrust::device_vector
+// through defs.h -> nvbio/basic/cuda/arch.h), so the float->int formula is restated here;
+// what this pins is the DP's use of quals[i] and of the four gap costs.
+struct QualRampScheme
+{
+    int32 m_match, m_mm_min, m_mm_max, m_pat_go, m_pat_ge, m_txt_go, m_txt_ge;
+
+    NVBIO_FORCEINLINE int32 mmp(const int q) const
+    {
+        const float frac = (float)(nvbio::min( q, 40 ) / 40.0f);
+        return m_mm_min + int( frac * (m_mm_max - m_mm_min) );
+    }
+    NVBIO_FORCEINLINE int32 match(const uint8 q = 0)      const { return m_match; }
+    NVBIO_FORCEINLINE int32 mismatch(const uint8 q = 0)   const { return -mmp(q); }
+    NVBIO_FORCEINLINE int32 mismatch(const uint8 a, const uint8 b, const uint8 q = 0) const { return -mmp(q); }
+    NVBIO_FORCEINLINE int32 pattern_gap_open()            const { return m_pat_go; }
+    NVBIO_FORCEINLINE int32 pattern_gap_extension()       const { return m_pat_ge; }
+    NVBIO_FORCEINLINE int32 text_gap_open()               const { return m_txt_go; }
+    NVBIO_FORCEINLINE int32 text_gap_extension()          const { return m_txt_ge; }
+};
+
+template <uint32 BAND, aln::AlignmentType TYPE, typename scheme_type, typename qual_type>
+int banded_run(const scheme_type& scheme,
+               const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+               int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::BestSink<int32> best;
+    const bool ok = aln::banded_alignment_score<BAND>(
+        aln::make_gotoh_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        quals,
+        string_type( N, txt ),
+        min_score,
+        best );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+
+template <uint32 BAND, typename scheme_type, typename qual_type>
+int banded_type(int type, const scheme_type& scheme,
+                const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return banded_run<BAND,aln::GLOBAL>     ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 1: return banded_run<BAND,aln::LOCAL>      ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 2: return banded_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
+template <typename scheme_type, typename qual_type>
+int banded_band(uint32 band, int type, const scheme_type& scheme,
+                const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                int32* score, uint32* sink)
+{
+    switch (band)
+    {
+    case 3:  return banded_type<3> ( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 7:  return banded_type<7> ( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 15: return banded_type<15>( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 31: return banded_type<31>( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
+template <aln::AlignmentType TYPE, typename algorithm_tag, typename scheme_type, typename qual_type>
+int full_run(const scheme_type& scheme,
+             const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+             int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    typedef aln::GotohAligner<TYPE,scheme_type,algorithm_tag>       aligner_type;
+    typedef typename aln::column_storage_type<aligner_type>::type   cell_type;
+
+    // the column must be as large as the text (pattern blocking) or the pattern (text blocking)
+    std::vector<cell_type> column( (M > N ? M : N) + 16u );
+
+    aln::BestSink<int32> best;
+    const bool ok = aln::alignment_score(
+        aligner_type( scheme ),
+        string_type( M, pat ),
+        quals,
+        string_type( N, txt ),
+        min_score,
+        best,
+        &column[0] );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+
+template <typename algorithm_tag, typename scheme_type, typename qual_type>
+int full_type(int type, const scheme_type& scheme,
+              const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+              int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return full_run<aln::GLOBAL,algorithm_tag>     ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 1: return full_run<aln::LOCAL,algorithm_tag>      ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 2: return full_run<aln::SEMI_GLOBAL,algorithm_tag>( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
+} // anonymous namespace
+
+extern "C" {
+
+// Build an FM-index over text[0,n) (one 2-bit symbol per byte) exactly as
+// nvbio-test/fmindex_test.cu:441-534 does.
+void* ref_fm_create(const uint8_t* text_bytes, uint32_t n)
+{
+    RefIndex* idx = new RefIndex;
+    idx->n = n;
+    const uint32 words = ((n + 15u) / 16u + 3u) & ~3u;
+    // +4 words of slack: gen_bwt_from_sa writes the (n+1)-th symbol before squeezing '$' out
+    idx->text.assign( words + 4u, 0u );
+    idx->bwt.assign(  words + 4u, 0u );
+    idx->occ.assign(  words, 0u );     // occ words == bwt words (4 per 64 symbols)
+    idx->count_table.resize( 256 );
+
+    typedef PackedStream<uint32*,uint8,2,true,uint32> stream_type;
+    stream_type text( &idx->text[0] );
+    for (uint32 i = 0; i < n; ++i)
+        text[i] = text_bytes[i] & 3u;
+
+    idx->sa.assign( n + 1u, 0 );
+    gen_sa( n, text, &idx->sa[0] );
+
+    stream_type bwt( &idx->bwt[0] );
+    idx->primary = gen_bwt_from_sa( n, text, &idx->sa[0], bwt );
+    idx->sa[0] = -1;
+
+    build_occurrence_table<64u>( bwt, bwt + n, &idx->occ[0], &idx->L2[1] );
+    idx->L2[0] = 0;
+    for (uint32 c = 0; c < 4; ++c)
+        idx->L2[c+1] += idx->L2[c];
+
+    gen_bwt_count_table( &idx->count_table[0] );
+
+    // interleave as nvbio/io/fmindex/fmindex_impl.cu:300-313 / fmindex_test.cu:512-524
+    idx->bwt_occ.assign( size_t(words) * 2u, 0u );
+    for (uint32 w = 0; w < words; w += 4)
+    {
+        for (uint32 k = 0; k < 4; ++k)
+        {
+            idx->bwt_occ[ w*2 + k     ] = idx->bwt[ w + k ];
+            idx->bwt_occ[ w*2 + 4 + k ] = idx->occ[ w + k ];
+        }
+    }
+
+    idx->ssa.assign( (n + 16u) / 16u, 0u );
+    for (uint32 i = 0; i <= n; i += 16)
+        idx->ssa[i >> 4] = uint32( idx->sa[i] );
+    return idx;
+}
+
+void ref_fm_destroy(void* h) { delete (RefIndex*)h; }
+
+uint32_t ref_fm_primary(void* h) { return ((RefIndex*)h)->primary; }
+void     ref_fm_L2(void* h, uint32_t* out) { memcpy( out, ((RefIndex*)h)->L2, 5*sizeof(uint32) ); }
+uint32_t ref_fm_words(void* h) { return uint32( ((RefIndex*)h)->occ.size() ); }
+uint32_t ref_fm_ssa_words(void* h) { return uint32( ((RefIndex*)h)->ssa.size() ); }
+
+void ref_fm_export(void* h, uint32_t* bwt, uint32_t* occ, uint32_t* bwt_occ, int32_t* sa, uint32_t* ssa)
+{
+    RefIndex* idx = (RefIndex*)h;
+    if (bwt)     memcpy( bwt,     &idx->bwt[0],     idx->occ.size()*4 );
+    if (occ)     memcpy( occ,     &idx->occ[0],     idx->occ.size()*4 );
+    if (bwt_occ) memcpy( bwt_occ, &idx->bwt_occ[0], idx->bwt_occ.size()*4 );
+    if (sa)      memcpy( sa,      &idx->sa[0],      idx->sa.size()*4 );
+    if (ssa)     memcpy( ssa,     &idx->ssa[0],     idx->ssa.size()*4 );
+}
+
+uint32_t ref_fm_rank(void* h, uint32_t k, uint32_t c)
+{
+    return rank( ((RefIndex*)h)->fmi(), k, uint8(c) );
+}
+void ref_fm_rank_range(void* h, uint32_t l, uint32_t r, uint32_t c, uint32_t* out)
+{
+    const uint2 res = rank( ((RefIndex*)h)->fmi(), make_uint2( l, r ), uint8(c) );
+    out[0] = res.x; out[1] = res.y;
+}
+void ref_fm_rank4(void* h, uint32_t k, uint32_t* out)
+{
+    const uint4 r = rank4( ((RefIndex*)h)->fmi(), k );
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// queries: one symbol per byte (values > 3 are 'N'), offsets[n_q+1]
+void ref_fm_match(void* h, const uint8_t* syms, const uint32_t* offsets, uint32_t n_q, uint32_t* ranges, int reverse)
+{
+    const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();
+    #pragma omp parallel for
+    for (int64 q = 0; q < int64(n_q); ++q)
+    {
+        const uint8* p   = syms + offsets[q];
+        const uint32 len = offsets[q+1] - offsets[q];
+        const uint2 r = reverse ? match_reverse( fmi, p, len ) : match( fmi, p, len );
+        ranges[2*q] = r.x; ranges[2*q+1] = r.y;
+    }
+}
+
+void ref_fm_locate(void* h, const uint32_t* rows, uint32_t n, uint32_t* pos)
+{
+    const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();
+    #pragma omp parallel for
+    for (int64 i = 0; i < int64(n); ++i)
+        pos[i] = locate( fmi, rows[i] );
+}
+
+void ref_fm_locate_ssa(void* h, const uint32_t* rows, uint32_t n, uint32_t* jt)
+{
+    const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();
+    #pragma omp parallel for
+    for (int64 i = 0; i < int64(n); ++i)
+    {
+        const uint2 r = locate_ssa_iterator( fmi, rows[i] );
+        jt[2*i] = r.x; jt[2*i+1] = r.y;
+    }
+}
+
+void ref_fm_lookup_ssa(void* h, const uint32_t* jt, uint32_t n, uint32_t* pos)
+{
+    const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();
+    for (uint32 i = 0; i < n; ++i)
+        pos[i] = lookup_ssa_iterator( fmi, make_uint2( jt[2*i], jt[2*i+1] ) );
+}
+
+// type: 0 GLOBAL, 1 LOCAL, 2 SEMI_GLOBAL (aln::AlignmentType, nvbio/alignment/alignment.h:242)
+int ref_banded_gotoh(uint32_t band, int type, int match, int mm, int gap_open, int gap_ext,
+                     const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                     int32_t* score, uint32_t* sink)
+{
+    const aln::SimpleGotohScheme scheme( match, mm, gap_open, gap_ext );
+    return banded_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+// general scheme: sc[7] = { match, mm_min, mm_max, pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext }
+// (mm_min/mm_max are positive penalties as in nvBowtie; gap costs are signed scores); quals may be NULL.
+int ref_banded_gotoh_ex(uint32_t band, int type, const int32_t* sc,
+                        const uint8_t* pat, const uint8_t* quals, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                        int32_t* score, uint32_t* sink)
+{
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    return quals ?
+        banded_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
+        banded_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+int ref_full_gotoh_ex(int type, int blocking, const int32_t* sc,
+                      const uint8_t* pat, const uint8_t* quals, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                      int32_t* score, uint32_t* sink)
+{
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    if (quals)
+        return blocking ?
+            full_type<aln::TextBlockingTag>   ( type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
+            full_type<aln::PatternBlockingTag>( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    return blocking ?
+        full_type<aln::TextBlockingTag>   ( type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink ) :
+        full_type<aln::PatternBlockingTag>( type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+// blocking: 0 = PatternBlockingTag (the alignment_score default), 1 = TextBlockingTag (sw-benchmark)
+int ref_full_gotoh(int type, int blocking, int match, int mm, int gap_open, int gap_ext,
+                   const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                   int32_t* score, uint32_t* sink)
+{
+    const aln::SimpleGotohScheme scheme( match, mm, gap_open, gap_ext );
+    return blocking ?
+        full_type<aln::TextBlockingTag>   ( type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink ) :
+        full_type<aln::PatternBlockingTag>( type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+// batched forms used for timing the reference's host path (OpenMP over work items, as
+// BatchedBandedAlignmentScore<..,HostThreadScheduler>::enact, nvbio/alignment/batched_banded_inl.h:113-121)
+void ref_banded_gotoh_batch(uint32_t band, int type, int match, int mm, int gap_open, int gap_ext,
+                            const uint8_t* pats, const uint32_t* pat_off,
+                            const uint8_t* txts, const uint32_t* txt_off, uint32_t n,
+                            int32_t min_score, int32_t* scores, uint32_t* sinks)
+{
+    #pragma omp parallel for
+    for (int64 i = 0; i < int64(n); ++i)
+    {
+        ref_banded_gotoh( band, type, match, mm, gap_open, gap_ext,
+            pats + pat_off[i], pat_off[i+1] - pat_off[i],
+            txts + txt_off[i], txt_off[i+1] - txt_off[i],
+            min_score, scores + i, sinks + 2*i );
+    }
+}
+
+void ref_full_gotoh_batch(int type, int blocking, int match, int mm, int gap_open, int gap_ext,
+                          const uint8_t* pats, const uint32_t* pat_off,
+                          const uint8_t* txts, const uint32_t* txt_off, uint32_t n,
+                          int32_t min_score, int32_t* scores, uint32_t* sinks)
+{
+    #pragma omp parallel for
+    for (int64 i = 0; i < int64(n); ++i)
+    {
+        ref_full_gotoh( type, blocking, match, mm, gap_open, gap_ext,
+            pats + pat_off[i], pat_off[i+1] - pat_off[i],
+            txts + txt_off[i], txt_off[i+1] - txt_off[i],
+            min_score, scores + i, sinks + 2*i );
+    }
+}
+
+} // extern "C"
