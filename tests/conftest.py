@@ -1,0 +1,52 @@
+"""pytest configuration: markers and shared fixtures.
+
+`-m "not gpu"` : oracle vs golden vectors, host logic, C-ABI symbol checks (CPU only).
+`-m gpu`       : parity of the HIP path (through the C-ABI) against the oracle, on an MI355X.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    return oracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """the reference's own host code; only exists in the development container"""
+    import oracle
+    if not oracle.Reference.available():
+        pytest.skip("oracle/_ref not built (reference sources are not on this machine)")
+    return oracle.Reference()
+
+
+@pytest.fixture(scope="session")
+def fm_golden():
+    return np.load(os.path.join(GOLDEN, "fm_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def dp_golden():
+    return np.load(os.path.join(GOLDEN, "dp_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def amd():
+    """the product package (HIP kernels behind the C-ABI); GPU tests only"""
+    import __graft_entry__ as ge
+    return ge.load_package()

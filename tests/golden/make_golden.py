@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE's own host code.
+
+Runs only in the development container (needs /root/reference and oracle/_ref/libnvbio_ref.so,
+built by `make -C oracle ref`).  The fixtures are data: seeded inputs plus the outputs the
+reference computed for them.  Nothing from the reference's sources is stored.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  fm_golden.npz   a 3,000-symbol seeded text; the index the reference built for it (sais SA, BWT,
+                  occ, interleaved bwt_occ, SSA); rank/rank4 for every row; match ranges for 400
+                  queries (hits, misses, N's; forward and reverse scans); locate for 600 rows.
+  dp_golden.npz   the known-answer pairs of nvbio-test/alignment_test.cu:709-828 and 400 seeded
+                  random pairs (substitutions, indels, N's, qualities, clipped windows, N < M),
+                  each scored by the reference with banded Gotoh (bands 3/7/15/31 x 3 types) and
+                  full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+DNA = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def enc(s):
+    return np.array([DNA[c] for c in s], dtype=np.uint8)
+
+
+# input strings of the reference's own functional tests (nvbio-test/alignment_test.cu:721-722,768-769,801-807)
+KNOWN = [
+    ("ACAACTA", "AAACACCCTAACACACTAAA"),
+    ("TTATGTAGGTGGTCTGGTTTTTGCCTTTTAAGCTTCTGCAAAAAACAACAACAAACTTGTGGTATTACACTGACTCTACAGATCAATTTGGGGACAACTTCCATG"
+     "TGTTCCACCACCAATACTGAATCTTTCAATCGACTGACGTGGTAT",
+     "ATCGGATTCTTTCTTACTTGTAGGTGGTCTGGTTTTTGCCTTTTAAGCTTCTGCAAAAAACAACAACAAACTTGTGGTATTACACTGACTCTACAGATCAATTTG"
+     "GGGACAACTTCCATGTGTTCCACCACCAATACTGAATCTTTCAATCGACTGACGTGGTATCTCTCTCTCCATCTAT"),
+    ("TAGGAGGTAACATGTATGGAGCATTTACCATAGGCCAAGCACTGTTCTAAGAACTTCGGACATGTTATCTCACTTGTATAAGTACTTAGGTGCCTACAACATAAG"
+     "CAGCACCTGGTAAATTAAGTATTGAAAAAATGCAGATCG",
+     "CAGCACTGACCGGTGAGCATAAACCCTGGGGATGCCCAGAGCTGGTACAGCCAGGAGCTCCAGAAGCGTGGGATTCTCAGAGGGAAGTGGAGCTCACTGCTCTAC"
+     "AGGTCCTATTCAAGTTAGAAAGTAAGATACAATGCACACAAAGCCAAATTGTCATCATTCAGCTCCTATTACAGGGGAACTAAGAGCTGCATTGAAAATTATTTG"
+     "CAAAGCTTGTAAGTGGTTCTGCCACTTATTAGCCGTGTGAACCTTAGCAAATTACCTAGCGTCTCTGAGTTTCAACTTCCTCATCTACAAAATAGAAATGATAAT"
+     "AATAACCGCATCGCAAGAGTTGTTGGAAAAATGAAAATGAGGTATCATAGGAGGTAACATGTATGGAGCATTTACCATAGGCCAAGCACTGTTCTAAGAACTTCG"
+     "GACATGTTATCTCACTTGTATAAGTACTTAGGTGCCTACAACATAAACAGCACCTGGTAAATTAAGTATTGAAAAAATGC"),
+]
+
+# scoring schemes: the reference tests' SimpleGotohScheme settings (alignment_test.cu:743-747,771-775),
+# sw-benchmark's (2,-1,-2,-1), nvBowtie's local() and default (e2e) schemes
+# (nvBowtie/bowtie2/cuda/scoring_inl.h:72-114) and one with asymmetric gap costs
+SCHEMES = [
+    (2, 1, 1, -1, -1, -1, -1),
+    (0, 5, 5, -8, -3, -8, -3),
+    (2, 1, 1, -2, -1, -2, -1),
+    (2, 2, 6, -8, -3, -8, -3),
+    (0, 2, 6, -8, -3, -8, -3),
+    (1, 3, 3, -15, -4, -11, -2),
+]
+
+
+def make_fm(R):
+    rng = np.random.default_rng(20240607)
+    n = 3000
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[1000:1400] = np.tile(np.array([0, 1, 0, 2], dtype=np.uint8), 100)      # a repeat: wide SA ranges
+    idx = R.build_index(text)
+
+    ranks = np.zeros((n + 2, 4), dtype=np.uint32)
+    ranks4 = np.zeros((n + 1, 4), dtype=np.uint32)
+    for k in range(-1, n + 1):
+        for c in range(4):
+            ranks[k + 1, c] = R.rank(idx, k, c)
+        if k >= 0:
+            ranks4[k] = R.rank4(idx, k)
+    pairs = np.zeros((500, 3), dtype=np.int64)
+    ranks2 = np.zeros((500, 2), dtype=np.uint32)
+    for i in range(500):
+        l = int(rng.integers(-1, n + 1))
+        r = int(rng.integers(max(l, 0), n + 1))
+        c = int(rng.integers(0, 4))
+        pairs[i] = (l, r, c)
+        ranks2[i] = R.rank2(idx, l, r, c)
+
+    Q = 400
+    lens = rng.integers(1, 33, Q)
+    lens[:40] = 22
+    offs = np.zeros(Q + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum(lens)
+    syms = rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)
+    for q in range(0, Q, 2):
+        p = int(rng.integers(0, n - lens[q] + 1))
+        syms[offs[q]:offs[q + 1]] = text[p:p + lens[q]]
+    syms[rng.integers(0, len(syms), 25)] = 4
+    ranges_bwd = R.match_batch(idx, syms, offs, False)
+    ranges_fwd = R.match_batch(idx, syms, offs, True)
+
+    rows = np.concatenate([np.arange(0, 200), rng.integers(0, n + 1, 398), [idx.primary, n]]).astype(np.uint32)
+    pos = R.locate_batch(idx, rows)
+    jt = R.locate_ssa_batch(idx, rows)
+
+    np.savez_compressed(
+        os.path.join(HERE, "fm_golden.npz"),
+        text=text, sa=idx.sa, primary=np.uint32(idx.primary), L2=idx.L2, bwt_occ=idx.bwt_occ, ssa=idx.ssa,
+        ranks=ranks, ranks4=ranks4, rank2_args=pairs, rank2=ranks2,
+        q_syms=syms, q_offs=offs, ranges_bwd=ranges_bwd, ranges_fwd=ranges_fwd,
+        rows=rows, pos=pos, jt=jt)
+    R.destroy(idx)
+    print("fm_golden.npz: n=%d, %d queries, %d rows" % (n, Q, len(rows)))
+
+
+def make_dp(R):
+    rng = np.random.default_rng(977)
+    pats, txts, quals = [], [], []
+    for p, t in KNOWN:
+        pats.append(enc(p)); txts.append(enc(t)); quals.append(None)
+    for it in range(400):
+        M = int(rng.integers(1, 161)) if it % 10 else 150
+        kind = it % 8
+        if kind == 0:       # window clipped at the text end / shorter than the pattern
+            N = int(rng.integers(max(1, M - 3), M + 12))
+        elif kind == 1:     # long text for full DP
+            N = int(rng.integers(M, M + 350))
+        else:
+            N = M + 31
+        N = max(N, 30)      # the banded reference reads text[0..BAND-2] unconditionally
+        txt = rng.integers(0, 4, N, dtype=np.uint8)
+        st = int(rng.integers(0, max(1, min(31, N - M + 1)))) if N >= M else 0
+        pat = txt[st:st + M].copy()
+        if len(pat) < M:
+            pat = np.concatenate([pat, rng.integers(0, 4, M - len(pat), dtype=np.uint8)])
+        mut = rng.random(M) < 0.05
+        pat[mut] = rng.integers(0, 5, int(mut.sum()))
+        if it % 3 == 0 and M > 12:
+            k = int(rng.integers(2, M - 6)); g = int(rng.integers(1, 4))
+            if it % 2:
+                pat = np.concatenate([pat[:k], pat[k + g:], rng.integers(0, 4, g, dtype=np.uint8)])
+            else:
+                pat = np.concatenate([pat[:k], rng.integers(0, 4, g, dtype=np.uint8), pat[k:M - g]])
+        pats.append(pat); txts.append(txt)
+        quals.append(rng.integers(0, 64, M, dtype=np.uint8) if it % 2 else None)
+
+    n = len(pats)
+    pat_off = np.zeros(n + 1, dtype=np.uint32); pat_off[1:] = np.cumsum([len(p) for p in pats])
+    txt_off = np.zeros(n + 1, dtype=np.uint32); txt_off[1:] = np.cumsum([len(t) for t in txts])
+    has_q = np.array([q is not None for q in quals], dtype=np.uint8)
+    qual_flat = np.concatenate([q if q is not None else np.zeros(len(p), dtype=np.uint8) for q, p in zip(quals, pats)])
+    bands = [3, 7, 15, 31]
+    S = len(SCHEMES)
+    # banded[case, band, type] = (ok, score, sink.x, sink.y); scheme = case % S
+    banded = np.zeros((n, len(bands), 3, 4), dtype=np.int64)
+    # full[case, blocking, type, min_score_variant] = (ok, score, sink.x, sink.y)
+    full = np.zeros((n, 2, 3, 2, 4), dtype=np.int64)
+    min_scores = np.full(n, oracle.SCORE_MIN, dtype=np.int32)
+    for i in range(n):
+        sc = oracle.Scheme(*SCHEMES[i % S])
+        # a finite min_score exercises the stripe early exit (gotoh_inl.h:706-710,1106-1110)
+        min_scores[i] = int(rng.integers(-40, 60)) if i % 3 else sc.match * len(pats[i]) - int(rng.integers(0, 30))
+        for bi, b in enumerate(bands):
+            for typ in range(3):
+                ok, s, sk = R.banded_gotoh(b, typ, sc, pats[i], txts[i], quals[i])
+                banded[i, bi, typ] = (ok, s, sk[0], sk[1])
+        for blk in range(2):
+            for typ in range(3):
+                for v, ms in enumerate((oracle.SCORE_MIN, int(min_scores[i]))):
+                    ok, s, sk = R.full_gotoh(typ, blk, sc, pats[i], txts[i], quals[i], ms)
+                    full[i, blk, typ, v] = (ok, s, sk[0], sk[1])
+    # the reference's functional tests, under the schemes those tests use (alignment_test.cu:743-828):
+    # known[k, variant, type] with variant 0 = banded (band 7 for the 7x20 pair, 31 otherwise),
+    # 1 = full pattern-blocking, 2 = full text-blocking
+    known_scheme = [SCHEMES[0], SCHEMES[1], SCHEMES[1]]
+    known = np.zeros((len(KNOWN), 3, 3, 4), dtype=np.int64)
+    for k in range(len(KNOWN)):
+        sc = oracle.Scheme(*known_scheme[k])
+        for typ in range(3):
+            ok, s_, sk = R.banded_gotoh(7 if k == 0 else 31, typ, sc, pats[k], txts[k], None, simple=True)
+            known[k, 0, typ] = (ok, s_, sk[0], sk[1])
+            for blk in range(2):
+                ok, s_, sk = R.full_gotoh(typ, blk, sc, pats[k], txts[k], None)
+                known[k, 1 + blk, typ] = (ok, s_, sk[0], sk[1])
+
+    np.savez_compressed(
+        os.path.join(HERE, "dp_golden.npz"),
+        known=known, known_schemes=np.array(known_scheme, dtype=np.int32),
+        pats=np.concatenate(pats), pat_off=pat_off, txts=np.concatenate(txts), txt_off=txt_off,
+        quals=qual_flat, has_quals=has_q, schemes=np.array(SCHEMES, dtype=np.int32), bands=np.array(bands),
+        banded=banded, full=full, min_scores=min_scores, n_known=np.int32(len(KNOWN)))
+    print("dp_golden.npz: %d pairs" % n)
+
+
+if __name__ == "__main__":
+    if not oracle.Reference.available():
+        oracle.build()
+    R = oracle.Reference()
+    make_fm(R)
+    make_dp(R)

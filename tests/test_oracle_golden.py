@@ -1,0 +1,221 @@
+"""The oracle (oracle/nvbio_oracle.c) against the golden vectors the REFERENCE produced
+(tests/golden/*.npz, generator tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+import oracle
+
+
+def _mask_stale(bwt_occ, n):
+    """gen_bwt_from_sa leaves a stale (n+1)-th symbol in the padding (nvbio/fmindex/bwt.h:41-53)"""
+    b = bwt_occ.copy()
+    w = (n >> 6) * 8 + ((n & 63) >> 4)
+    if w < len(b):
+        b[w] &= ~np.uint32(3 << (30 - 2 * (n & 15)))
+    return b
+
+
+def test_packed_stream_roundtrip(orc):
+    # nvbio-test/packedstream_test.cpp: pack/unpack round trips, big-endian layout
+    rng = np.random.default_rng(1)
+    s = rng.integers(0, 4, 1003, dtype=np.uint8)
+    w = orc.pack2(s)
+    assert all(orc.get2(w, i) == s[i] for i in range(len(s)))
+    assert (int(w[0]) >> 30) == s[0] and ((int(w[0]) >> 28) & 3) == s[1]
+    s4 = rng.integers(0, 5, 777, dtype=np.uint8)
+    w4 = orc.pack4(s4)
+    assert all(orc.get4(w4, i) == s4[i] for i in range(len(s4)))
+    assert (int(w4[0]) >> 28) == s4[0]
+
+
+def test_sais_sanity_banana(orc):
+    # nvbio-test/packedstream_test.cpp:143-172: SA("banana") == {5,3,1,0,4,2}; over a 2-bit
+    # alphabet the same shape is a=0, b=1, n=2
+    text = np.array([1, 0, 2, 0, 2, 0], dtype=np.uint8)
+    sa = orc.suffix_sort(text)
+    assert list(sa) == [6, 5, 3, 1, 0, 4, 2]
+
+
+def test_suffix_sort_matches_reference_sa(orc, fm_golden):
+    sa = orc.suffix_sort(fm_golden["text"])
+    assert np.array_equal(sa[1:], fm_golden["sa"][1:])
+
+
+def test_index_build_matches_reference(orc, fm_golden):
+    g = fm_golden
+    idx = orc.build_index(g["text"])
+    assert idx.primary == int(g["primary"])
+    assert np.array_equal(idx.L2, g["L2"])
+    assert np.array_equal(idx.bwt_occ, _mask_stale(g["bwt_occ"], len(g["text"])))
+    assert np.array_equal(idx.ssa, g["ssa"])
+    assert idx.ssa[0] == 0xFFFFFFFF
+
+
+def _golden_index(g):
+    return oracle.HostIndex(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"])
+
+
+def test_rank_every_row(orc, fm_golden):
+    # the shape of nvbio-test/rank_test.cu:46-79: every i, every c, rank and rank4
+    g = fm_golden
+    idx = _golden_index(g)
+    n = idx.n
+    for k in range(-1, n + 1):
+        for c in range(4):
+            assert orc.rank(idx, k, c) == g["ranks"][k + 1, c], (k, c)
+        if k >= 0:
+            assert np.array_equal(orc.rank4(idx, k), g["ranks4"][k]), k
+    for (l, r, c), want in zip(g["rank2_args"], g["rank2"]):
+        assert np.array_equal(orc.rank2(idx, int(l), int(r), int(c)), want), (l, r, c)
+
+
+def test_rank_is_a_running_count(orc, fm_golden):
+    # independent of the reference outputs: rank(k,c) = #c in the first k+1 BWT-matrix rows
+    g = fm_golden
+    idx = _golden_index(g)
+    text, sa = g["text"], g["sa"]
+    L = [-1 if sa[i] == 0 else int(text[sa[i] - 1]) for i in range(1, idx.n + 1)]
+    L = [-1 if i == 0 else x for i, x in enumerate([0] + L)]  # row 0 = '$' suffix: preceded by text[n-1]
+    L[0] = int(text[-1])
+    counts = [0, 0, 0, 0]
+    for k in range(idx.n + 1):
+        if L[k] >= 0:
+            counts[L[k]] += 1
+        for c in range(4):
+            assert orc.rank(idx, k, c) == counts[c], (k, c)
+
+
+def test_match_ranges(orc, fm_golden):
+    g = fm_golden
+    idx = _golden_index(g)
+    assert np.array_equal(orc.match_batch(idx, g["q_syms"], g["q_offs"], False), g["ranges_bwd"])
+    assert np.array_equal(orc.match_batch(idx, g["q_syms"], g["q_offs"], True), g["ranges_fwd"])
+
+
+def test_match_against_naive_count(orc, fm_golden):
+    # match() == number of occurrences found by a naive scan (fmindex_test.cu:603-657 self-check)
+    g = fm_golden
+    idx = _golden_index(g)
+    text = g["text"]
+    ranges = orc.match_batch(idx, g["q_syms"], g["q_offs"], False)
+    tb = text.tobytes()
+    for q in range(0, 200):
+        p = g["q_syms"][g["q_offs"][q]:g["q_offs"][q + 1]]
+        if (p > 3).any():
+            continue
+        pb, cnt, st = p.tobytes(), 0, 0
+        while True:
+            st = tb.find(pb, st)
+            if st < 0:
+                break
+            cnt += 1
+            st += 1
+        x, y = int(ranges[q, 0]), int(ranges[q, 1])
+        assert (y + 1 - x if y >= x else 0) == cnt, q
+
+
+def test_locate(orc, fm_golden):
+    g = fm_golden
+    idx = _golden_index(g)
+    assert np.array_equal(orc.locate_batch(idx, g["rows"]), g["pos"])
+    assert np.array_equal(orc.locate_ssa_batch(idx, g["rows"]), g["jt"])
+    # locate(i) == SA[i] for every row but 0 (SSA test of fmindex_test.cu:575-585)
+    rows = g["rows"][g["rows"] > 0]
+    assert np.array_equal(orc.locate_batch(idx, rows), g["sa"][rows])
+
+
+def test_filter_rank_and_locate(orc, fm_golden):
+    g = fm_golden
+    idx = _golden_index(g)
+    total, ranges, slots = orc.filter_rank(idx, g["q_syms"], g["q_offs"])
+    assert np.array_equal(ranges, g["ranges_bwd"])
+    sizes = np.where(ranges[:, 1] >= ranges[:, 0], ranges[:, 1].astype(np.int64) + 1 - ranges[:, 0], 0)
+    assert np.array_equal(slots, np.cumsum(sizes).astype(np.uint64))
+    assert total == int(sizes.sum())
+    hits = orc.filter_locate(idx, ranges, slots, 0, min(total, 2000))
+    # every hit is an occurrence of its query
+    text = g["text"]
+    for pos, q in hits[:500]:
+        p = g["q_syms"][g["q_offs"][q]:g["q_offs"][q + 1]]
+        assert np.array_equal(text[pos:pos + len(p)], p)
+
+
+def _case(g, i):
+    p = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+    t = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+    q = g["quals"][g["pat_off"][i]:g["pat_off"][i + 1]] if g["has_quals"][i] else None
+    return p, t, q
+
+
+def test_banded_gotoh_golden(orc, dp_golden):
+    g = dp_golden
+    S = len(g["schemes"])
+    n = len(g["pat_off"]) - 1
+    for i in range(n):
+        sc = oracle.Scheme(*[int(v) for v in g["schemes"][i % S]])
+        p, t, q = _case(g, i)
+        for bi, b in enumerate(g["bands"]):
+            for typ in range(3):
+                ok, s, sk = orc.banded_gotoh(int(b), typ, sc, p, t, q)
+                want = g["banded"][i, bi, typ]
+                assert (ok, s, sk[0], sk[1]) == tuple(int(v) for v in want), (i, b, typ)
+
+
+def test_full_gotoh_golden(orc, dp_golden):
+    g = dp_golden
+    S = len(g["schemes"])
+    n = len(g["pat_off"]) - 1
+    for i in range(n):
+        sc = oracle.Scheme(*[int(v) for v in g["schemes"][i % S]])
+        p, t, q = _case(g, i)
+        for blk in range(2):
+            for typ in range(3):
+                for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                    ok, s, sk = orc.full_gotoh(typ, blk, sc, p, t, q, ms)
+                    want = g["full"][i, blk, typ, v]
+                    assert (ok, s, sk[0], sk[1]) == tuple(int(x) for x in want), (i, blk, typ, v)
+
+
+def test_known_answers_of_the_reference_tests(orc, dp_golden):
+    """nvbio-test/alignment_test.cu:709-828: '4M1D3M' (banded 7), '147M2D3M' (banded 31), '6I138M'"""
+    g = dp_golden
+    for k in range(int(g["n_known"])):
+        sc = oracle.Scheme(*[int(v) for v in g["known_schemes"][k]])
+        p, t, _ = _case(g, k)
+        for typ in range(3):
+            ok, s, sk = orc.banded_gotoh(7 if k == 0 else 31, typ, sc, p, t)
+            assert (ok, s, sk[0], sk[1]) == tuple(int(v) for v in g["known"][k, 0, typ])
+            for blk in range(2):
+                ok, s, sk = orc.full_gotoh(typ, blk, sc, p, t)
+                assert (ok, s, sk[0], sk[1]) == tuple(int(v) for v in g["known"][k, 1 + blk, typ])
+    # 150 bp read, band 31, Gotoh(0,-5,-8,-3), semi-global -> 147M2D3M: one gap of 2 = -8-3
+    sc = oracle.Scheme.simple(0, -5, -8, -3)
+    p, t, _ = _case(g, 1)
+    assert orc.banded_gotoh(31, oracle.SEMI_GLOBAL, sc, p, t) == (1, -11, (165, 150))
+    # 7x20 pair, Gotoh(2,-1,-1,-1), full semi-global and local -> 4M1D3M: 7 matches and one gap of 1
+    sc = oracle.Scheme.simple(2, -1, -1, -1)
+    p, t, _ = _case(g, 0)
+    for blk in range(2):
+        assert orc.full_gotoh(oracle.SEMI_GLOBAL, blk, sc, p, t)[1] == 13
+        assert orc.full_gotoh(oracle.LOCAL, blk, sc, p, t)[1] == 13
+
+
+def test_mismatch_quality_ramp(orc):
+    # QualCost (nvBowtie/bowtie2/cuda/scoring.h:84-88): min + int(min(q,40)/40 * (max-min))
+    sc = oracle.Scheme(2, 2, 6, -8, -3, -8, -3)
+    assert [orc.mismatch(sc, q) for q in (0, 9, 10, 20, 30, 39, 40, 63, 255)] == [-2, -2, -3, -4, -5, -5, -6, -6, -6]
+
+
+def test_band31_out_of_range_text_reads_as_T(orc):
+    """past the text end the band-31 cache (2-bit packed) turns the 255
+    sentinel into 3 ('T') on later rows; LOCAL scores equal T-padding to 181"""
+    rng = np.random.default_rng(5)
+    sc = oracle.Scheme(2, 6, 6, -8, -3, -8, -3)
+    for _ in range(200):
+        N = int(rng.integers(150, 180))
+        t = rng.integers(0, 4, N, dtype=np.uint8)
+        p = t[:150].copy()
+        p[rng.integers(0, 150, 4)] = rng.integers(0, 4, 4)
+        a = orc.banded_gotoh(31, oracle.LOCAL, sc, p, t)
+        tp = np.concatenate([t, np.full(181 - N, 3, dtype=np.uint8)])
+        b = orc.banded_gotoh(31, oracle.LOCAL, sc, p, tp)
+        assert a[1] == b[1]

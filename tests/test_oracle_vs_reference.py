@@ -1,0 +1,66 @@
+"""Live fuzz of the oracle against the reference's own host code (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Skipped where the reference is not present (GPU box)."""
+import numpy as np
+
+import oracle
+
+SCHEMES = [oracle.Scheme.simple(2, -1, -1, -1), oracle.Scheme.simple(0, -5, -8, -3),
+           oracle.Scheme.simple(2, -1, -2, -1), oracle.Scheme(2, 2, 6, -8, -3, -8, -3),
+           oracle.Scheme(0, 2, 6, -8, -3, -8, -3), oracle.Scheme(1, 3, 3, -15, -4, -11, -2)]
+
+
+def test_fm_index_fuzz(orc, ref):
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 1000, 4097, 50000):
+        text = rng.integers(0, 4, n, dtype=np.uint8)
+        if n == 1000:
+            text[:] = 0
+        if n == 4097:
+            text = np.tile(np.array([0, 1, 2, 3, 3, 2], dtype=np.uint8), 700)[:n]
+        ri, oi = ref.build_index(text), orc.build_index(text)
+        assert np.array_equal(ri.sa[1:], oi.sa[1:])
+        assert ri.primary == oi.primary and np.array_equal(ri.L2, oi.L2) and np.array_equal(ri.ssa, oi.ssa)
+        ks = list(range(-1, min(n, 200) + 1)) + [int(x) for x in rng.integers(0, n + 1, 100)]
+        for k in ks:
+            for c in range(4):
+                assert ref.rank(ri, k, c) == orc.rank(oi, k, c)
+        for _ in range(200):
+            l = int(rng.integers(-1, n + 1)); r = int(rng.integers(max(l, 0), n + 1)); c = int(rng.integers(0, 4))
+            assert np.array_equal(ref.rank2(ri, l, r, c), orc.rank2(oi, l, r, c))
+        Q = 300
+        lens = rng.integers(1, 30, Q)
+        offs = np.zeros(Q + 1, dtype=np.uint32); offs[1:] = np.cumsum(lens)
+        syms = rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)
+        for q in range(0, Q, 2):
+            if lens[q] <= n:
+                p = int(rng.integers(0, n - lens[q] + 1)); syms[offs[q]:offs[q + 1]] = text[p:p + lens[q]]
+        syms[rng.integers(0, len(syms), 10)] = 4
+        for rev in (False, True):
+            assert np.array_equal(ref.match_batch(ri, syms, offs, rev), orc.match_batch(oi, syms, offs, rev))
+        rows = rng.integers(0, n + 1, 200).astype(np.uint32)
+        assert np.array_equal(ref.locate_batch(ri, rows), orc.locate_batch(oi, rows))
+        ref.destroy(ri)
+
+
+def test_gotoh_fuzz(orc, ref):
+    rng = np.random.default_rng(11)
+    for it in range(600):
+        band = [3, 7, 15, 31][it % 4]
+        M = int(rng.integers(1, 160))
+        N = int(rng.integers(max(M, band - 1), M + band + 10))
+        if it % 7 == 0:
+            N = max(band - 1, int(rng.integers(max(1, M - 3), M + 2)))
+        txt = rng.integers(0, 4, N, dtype=np.uint8)
+        st = int(rng.integers(0, max(1, N - M + 1)))
+        pat = txt[st:st + M].copy()
+        if len(pat) < M:
+            pat = np.concatenate([pat, rng.integers(0, 4, M - len(pat), dtype=np.uint8)])
+        mut = rng.random(M) < 0.08
+        pat[mut] = rng.integers(0, 5, int(mut.sum()))
+        quals = rng.integers(0, 60, M, dtype=np.uint8) if it % 2 else None
+        sc = SCHEMES[it % len(SCHEMES)]
+        for typ in range(3):
+            assert ref.banded_gotoh(band, typ, sc, pat, txt, quals) == orc.banded_gotoh(band, typ, sc, pat, txt, quals)
+            ms = oracle.SCORE_MIN if it % 3 else int(rng.integers(-50, 200))
+            for blk in range(2):
+                assert ref.full_gotoh(typ, blk, sc, pat, txt, quals, ms) == orc.full_gotoh(typ, blk, sc, pat, txt, quals, ms)
