@@ -1,0 +1,240 @@
+/* nvbio_amd.h -- C ABI of the MI355X-native seed-and-extend core.
+ *
+ * This is the drop-in boundary for the hot path of NVBIO / nvBowtie: FM-index
+ * rank / match / locate over a 2-bit packed BWT and batched (banded and full-matrix)
+ * Gotoh scoring.  The reference has no C ABI; its operator API for this path is three
+ * template concepts.  Every entry point below names the reference
+ * interface it stands in for (file:line relative to the reference tree); the C++
+ * shim that plugs these calls back under the reference's own class names is in
+ * nvbio-gpl_amd/host/, and INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` / "device pointer" argument is a pointer into the
+ *     HBM of the GPU the handle/stream lives on; the caller owns those buffers.
+ *   - all entry points return an nvbio_status (0 = ok) and never throw; a message for the
+ *     last failure on the calling thread is available from nvbio_amd_last_error().
+ *   - work is enqueued on the caller's stream (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is asynchronous; nvbio_amd_stream_synchronize() (or the caller's
+ *     own hipStreamSynchronize) waits for it.  Calls on one handle from several host
+ *     threads are safe as long as each thread uses its own stream and output buffers.
+ *   - results are bit-identical to the reference's CPU path: SA ranges, SA rows and text
+ *     positions as uint32, scores as int32, sinks as (text, pattern) uint32 pairs.
+ */
+#ifndef NVBIO_AMD_H
+#define NVBIO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVBIO_AMD_VERSION 100   /* 0.1.0 */
+
+typedef enum
+{
+    NVBIO_OK              = 0,
+    NVBIO_ERR_INVALID     = 1,  /* bad argument (null pointer, unsupported band/bits, ...)   */
+    NVBIO_ERR_HIP         = 2,  /* a HIP runtime call failed                                   */
+    NVBIO_ERR_NOMEM       = 3,  /* device or host allocation failed                            */
+    NVBIO_ERR_UNSUPPORTED = 4,  /* valid in the reference but not built here                   */
+    NVBIO_ERR_NO_DEVICE   = 5   /* no usable gfx950 device: the library has NO CPU fallback    */
+} nvbio_status;
+
+int         nvbio_amd_version(void);
+const char* nvbio_amd_last_error(void);
+/* number of visible HIP devices and the gcnArchName of one of them (e.g. "gfx950:sramecc+:xnack-") */
+nvbio_status nvbio_amd_device_count(int* count);
+nvbio_status nvbio_amd_device_arch(int device, char* name, uint32_t name_len);
+nvbio_status nvbio_amd_stream_synchronize(int device, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * pair of uint32, layout-compatible with the reference's uint2 (SA ranges, hits, sinks)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t x, y; } nvbio_uint2;
+
+/* -------------------------------------------------------------------------------------------
+ * FM-index
+ * ------------------------------------------------------------------------------------------- */
+
+/* Storage-free view of an FM-index resident in HBM: the members of nvbio::fm_index
+ * (nvbio/fmindex/fmindex.h:320-361) in the production layout of io::FMIndexDataDevice
+ * (nvbio/io/fmindex/fmindex.h:75-177, :294-295):
+ *   bwt_occ : 32-byte records; record k = 4 words of 2-bit big-endian BWT symbols [64k,64k+64)
+ *             followed by 4 words occ{A,C,G,T} = counts in BWT[0,64k)   (fmindex_impl.cu:300-313)
+ *   ssa     : ssa[j] = SA[16 j], ssa[0] = 0xFFFFFFFF                    (ssa_inl.h:254-301,477-495)
+ *   L2      : L2[c] = number of symbols < c, L2[4] = length             (fmindex.h:335-336)       */
+typedef struct
+{
+    uint32_t        length;          /* n: text symbols (the BWT holds n symbols, '$' is implicit)  */
+    uint32_t        primary;         /* BWT-matrix row of '$'                                       */
+    uint32_t        L2[5];
+    const uint32_t* bwt_occ_dev;     /* device pointer, 32-byte aligned                             */
+    uint64_t        bwt_occ_words;   /* = 2 * ceil4(ceil(n/16))                                     */
+    const uint32_t* ssa_dev;         /* device pointer, may be NULL (match-only index)              */
+    uint64_t        ssa_words;       /* = (n+16)/16                                                 */
+} nvbio_fm_index_view;
+
+typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
+
+/* Wrap an index that is already in HBM (the caller keeps ownership of bwt_occ/ssa, as with the
+ * reference's storage-free views).  kmer_len > 0 additionally builds, on the GPU, a table with
+ * the SA range of every kmer_len-mer (4^kmer_len x 8 bytes, owned by the handle) which match()
+ * uses to replace its first kmer_len backward-search steps with one lookup; results are
+ * identical with and without it.  kmer_len = 0 disables it; values up to 14 are accepted.
+ * Replaces: constructing nvbio::fm_index / io::FMIndexDataDevice (nvbio/io/fmindex/fmindex_impl.cu:740-816). */
+nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len,
+                                   void* stream, nvbio_fm_index_t* out);
+
+/* Build the whole index on the GPU from a 2-bit big-endian packed text in HBM (layout of
+ * io::SequenceData<DNA>, nvbio/io/sequence/sequence_traits.h:32-38): suffix sort, BWT, occ,
+ * interleave, SSA.  All arrays are owned by the handle.  Replaces, for synthetic / benchmark
+ * references, the offline nvBWT + FMIndexDataHost::load path (nvBWT/nvBWT.cu,
+ * nvbio/io/fmindex/fmindex_impl.cu:111-331) and SSA_index_multiple's builder (ssa_inl.h:273-470).
+ * Texts with repeats longer than max_lcp symbols (default 0 -> 4096) are rejected with
+ * NVBIO_ERR_UNSUPPORTED rather than sorted slowly. */
+nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device, uint32_t kmer_len,
+                                  uint32_t max_lcp, void* stream, nvbio_fm_index_t* out);
+
+nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index);
+nvbio_status nvbio_fm_index_get_view(nvbio_fm_index_t index, nvbio_fm_index_view* view);
+/* copy the index arrays into caller buffers in HBM (either may be NULL); sizes from get_view */
+nvbio_status nvbio_fm_index_export(nvbio_fm_index_t index, uint32_t* bwt_occ_out_dev, uint32_t* ssa_out_dev, void* stream);
+/* bytes of HBM owned by the handle (k-mer table, and the index arrays if it was built here) */
+nvbio_status nvbio_fm_index_device_bytes(nvbio_fm_index_t index, uint64_t* bytes);
+
+/* A set of query strings in HBM: the string-set concept FMIndexFilter::rank consumes
+ * (nvbio/fmindex/filter.h:52-231) flattened to arrays.
+ *   symbols      packed big-endian words (symbol_bits 2 or 4: PackedStream<..,true>,
+ *                nvbio/basic/packedstream_inl.h:33-75; 4-bit = io::SequenceData<DNA_N>) or one
+ *                symbol per byte (symbol_bits 8).  Symbols > 3 are 'N'.
+ *   offsets      if offsets_are_ranges: n+1 entries, string i = [offsets[i], offsets[i+1])
+ *                else if non-NULL: n entries, string i = [offsets[i], offsets[i]+fixed_len)
+ *                else: string i = [i*stride, i*stride + fixed_len)                             */
+typedef struct
+{
+    const void*     symbols_dev;
+    uint32_t        symbol_bits;
+    const uint32_t* offsets_dev;
+    uint32_t        offsets_are_ranges;
+    uint32_t        fixed_len;
+    uint32_t        stride;
+    uint32_t        n;
+} nvbio_string_set;
+
+enum
+{
+    NVBIO_FM_SCAN_FORWARD = 1,   /* consume symbols 0..len-1 (match_reverse, fmindex_inl.h:247-278; nvBowtie
+                                    match_range, mapping_inl.h:73-86); default is len-1..0 (match, :181-239) */
+    NVBIO_FM_COMPLEMENT   = 2,   /* search the complement (c < 4 ? 3-c : c), as nvBowtie's rc seeds
+                                    (mapping_inl.h:264-279)                                                   */
+    NVBIO_FM_NO_KMER_TABLE = 4   /* step every symbol through rank() even if the handle has a table         */
+};
+
+/* ranges_dev[i] = SA range (inclusive; empty iff x > y) of query i: nvbio::match / match_reverse
+ * (nvbio/fmindex/fmindex_inl.h:181-278), including the N rule (-> (1,0)) and the reference's
+ * early-exit values for patterns that stop matching.
+ * blocks_dev (optional): number of distinct 32-byte bwt_occ records the reference's algorithm
+ * touches for query i (the algorithmic-traffic unit of SURVEY.md 8d); requires NO_KMER_TABLE. */
+nvbio_status nvbio_fm_match(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                            nvbio_uint2* ranges_dev, uint32_t* blocks_dev, void* stream);
+
+/* rank(fmi, k, c) for n (row, symbol) pairs: nvbio/fmindex/fmindex_inl.h:27-47 */
+nvbio_status nvbio_fm_rank(nvbio_fm_index_t index, const uint32_t* rows_dev, const uint8_t* syms_dev, uint32_t n,
+                           uint32_t* out_dev, void* stream);
+/* rank4(fmi, k): counts of all four symbols, fmindex_inl.h:96-123 (out_dev: 4 words per row) */
+nvbio_status nvbio_fm_rank4(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
+                            uint32_t* out_dev, void* stream);
+
+/* pos_dev[i] = text position of SA row rows_dev[i]: nvbio::locate (fmindex_inl.h:360-394).
+ * rows_dev == pos_dev is allowed (nvBowtie locates in place, locate_inl.h:113-138). */
+nvbio_status nvbio_fm_locate(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
+                             uint32_t* pos_dev, void* stream);
+/* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
+ * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)
+ * pos_dev[i] = lookup_ssa_iterator(jt[i]) = ssa[j/16] + t          (fmindex_inl.h:445-460)      */
+nvbio_status nvbio_fm_locate_init(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
+                                  nvbio_uint2* jt_dev, void* stream);
+nvbio_status nvbio_fm_locate_lookup(nvbio_fm_index_t index, const nvbio_uint2* jt_dev, uint32_t n,
+                                    uint32_t* pos_dev, void* stream);
+
+/* FMIndexFilter<device_tag>::rank (nvbio/fmindex/filter_inl.h:261-293): ranges + inclusive scan of
+ * the range sizes (uint64).  *n_hits receives the total (host value; this call synchronizes). */
+nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                                  nvbio_uint2* ranges_dev, uint64_t* slots_dev, uint64_t* n_hits, void* stream);
+/* FMIndexFilter<device_tag>::locate (filter_inl.h:299-393): hits_dev[h-begin] = (text_pos, query_id)
+ * for the global hit indices h in [begin, end). */
+nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                    uint32_t n_queries, uint64_t begin, uint64_t end,
+                                    nvbio_uint2* hits_dev, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Gotoh scoring
+ * ------------------------------------------------------------------------------------------- */
+typedef enum { NVBIO_GLOBAL = 0, NVBIO_LOCAL = 1, NVBIO_SEMI_GLOBAL = 2 } nvbio_alignment_type;   /* alignment.h:242 */
+
+/* The Gotoh scoring-scheme concept (nvbio/alignment/alignment.h:437-449) as data.
+ * aln::SimpleGotohScheme(match, mismatch, open, ext) (nvbio/alignment/utils.h:103-123) is
+ *   { match, -mismatch, -mismatch, open, ext, open, ext };
+ * nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> (nvBowtie/bowtie2/cuda/scoring.h:206-330) is
+ *   { m_match, mmp_min, mmp_max, -(read_gap_const+read_gap_coeff), -read_gap_coeff,
+ *     -(ref_gap_const+ref_gap_coeff), -ref_gap_coeff }
+ * with mismatch(q) = -( mm_min + int( float(min(q,40))/40.0f * (mm_max-mm_min) ) ) (scoring.h:84-88). */
+typedef struct
+{
+    int32_t match;
+    int32_t mm_min, mm_max;              /* mismatch penalties (positive) at quality 0 / >= 40 */
+    int32_t pat_gap_open, pat_gap_ext;   /* signed scores */
+    int32_t txt_gap_open, txt_gap_ext;
+} nvbio_gotoh_scheme;
+
+#define NVBIO_SCORE_MIN (-(1 << 30))     /* Field_traits<int32>::min(), BestSink's initial score (numbers.h:738-742) */
+
+/* A batch of alignment jobs: the stream concept of aln::Batched[Banded]AlignmentScore
+ * (pattern_length / text_length / load_strings; nvbio/alignment/batched.h:274-298, sw-benchmark.cu:70-209,
+ * nvBowtie score_inl.h:44-136 + alignment_utils.h:194-308) flattened to arrays.
+ *   job i aligns pattern = read[ read_id ? read_id[i] : i ], optionally reversed / complemented
+ *   (flags bit0 / bit1: ReadStream, nvbio/io/utils.h:150-168), against text[ win_begin[i], win_end[i] ).   */
+typedef struct
+{
+    const void*     reads_dev;         /* packed big-endian words (read_bits 2, 4) or bytes (8)            */
+    uint32_t        read_bits;
+    const uint32_t* read_offsets_dev;  /* n_reads+1 symbol offsets (io::SequenceData sequence_index)        */
+    const uint8_t*  quals_dev;         /* one byte per read symbol, or NULL (trivial_quality_string -> 0)   */
+    const uint32_t* read_id_dev;       /* n entries or NULL                                                 */
+    const uint8_t*  flags_dev;         /* n entries or NULL                                                 */
+    const void*     text_dev;          /* packed 2-bit big-endian words (text_bits 2) or bytes (8)          */
+    uint32_t        text_bits;
+    const uint32_t* win_begin_dev;     /* n entries: window begin (symbol index into text)                  */
+    const uint32_t* win_end_dev;       /* n entries: window end (exclusive)                                 */
+    uint32_t        n;
+} nvbio_alignment_batch;
+
+enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };
+
+/* scores_dev[i], sinks_dev[i] = BestSink<int32> (score, (text_end, pattern_end)) after
+ * aln::banded_alignment_score<band>( GotohAligner<type>, pattern, quals, text, min_score, sink )
+ * (nvbio/alignment/gotoh/gotoh_banded_inl.h:397-688; batched form batched_banded_inl.h:34-157).
+ * band must be 3, 7, 15 or 31 (the instantiations nvBowtie dispatches, score_inl.h:468-508).
+ * Jobs with text_len < pattern_len report nothing: score NVBIO_SCORE_MIN, sink (-1,-1).       */
+nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbio_alignment_type type,
+                                      const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                      int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
+
+/* full-matrix Gotoh: aln::alignment_score / BatchedAlignmentScore (nvbio/alignment/gotoh/gotoh_inl.h:444-1256,
+ * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default
+ * PatternBlockingTag; min_scores_dev (optional) enables the reference's stripe early exit.
+ * temp_dev / temp_bytes: optional caller scratch (see nvbio_full_gotoh_temp_bytes); if NULL the
+ * library allocates and frees stream-ordered scratch itself. */
+nvbio_status nvbio_full_gotoh_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t max_pattern_len,
+                                         uint32_t max_text_len, int text_blocking, uint64_t* bytes);
+nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int text_blocking,
+                                    const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                    uint32_t max_pattern_len, uint32_t max_text_len,
+                                    const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                    void* temp_dev, uint64_t temp_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVBIO_AMD_H */

@@ -1,0 +1,434 @@
+"""nvbio-gpl_amd -- MI355X-native seed-and-extend core behind NVBIO's operator API.
+
+The product is the shared library ``lib/libnvbio_amd.so`` (hand-written HIP kernels for gfx950
+behind the C ABI of ``include/nvbio_amd.h``).  This package is the thin host-side mirror of the
+reference's interface for the path, for Python callers (tests, bench): the same names and
+argument meaning as the reference's C++ templates --
+
+    FMIndex                      nvbio::fm_index / io::FMIndexDataDevice   (nvbio/fmindex/fmindex.h:320-557)
+    FMIndexFilter                nvbio::FMIndexFilter<device_tag,...>      (nvbio/fmindex/filter.h:52-231)
+    SimpleGotohScheme, GotohAligner, BestSink semantics                    (nvbio/alignment/utils.h:103-123, alignment.h:437-449)
+    BatchedBandedAlignmentScore, batch_banded_alignment_score              (nvbio/alignment/batched.h:104-298)
+
+PyTorch is used only as plumbing for device memory and streams.  There is NO CPU fallback:
+importing works anywhere (so that symbol checks can run), but every compute entry point raises
+``NvbioError`` when the library or a gfx950 device is missing.  Nothing here imports ``oracle``.
+
+The directory name contains a hyphen, so load it with ``__graft_entry__.load_package()``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnvbio_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
+
+GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
+SCORE_MIN = -(1 << 30)
+FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE = 1, 2, 4
+READ_REVERSE, READ_COMPLEMENT = 1, 2
+
+_STATUS = {0: "OK", 1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "UNSUPPORTED", 5: "NO_DEVICE"}
+
+
+class NvbioError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("nvbio_amd: %s: %s" % (_STATUS.get(status, status), msg))
+        self.status = status
+
+
+# ---- C structs ---------------------------------------------------------------------------------
+class _View(ctypes.Structure):
+    _fields_ = [("length", ctypes.c_uint32), ("primary", ctypes.c_uint32), ("L2", ctypes.c_uint32 * 5),
+                ("bwt_occ_dev", ctypes.c_void_p), ("bwt_occ_words", ctypes.c_uint64),
+                ("ssa_dev", ctypes.c_void_p), ("ssa_words", ctypes.c_uint64)]
+
+
+class _StringSet(ctypes.Structure):
+    _fields_ = [("symbols_dev", ctypes.c_void_p), ("symbol_bits", ctypes.c_uint32),
+                ("offsets_dev", ctypes.c_void_p), ("offsets_are_ranges", ctypes.c_uint32),
+                ("fixed_len", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("n", ctypes.c_uint32)]
+
+
+class _Scheme(ctypes.Structure):
+    _fields_ = [("match", ctypes.c_int32), ("mm_min", ctypes.c_int32), ("mm_max", ctypes.c_int32),
+                ("pat_gap_open", ctypes.c_int32), ("pat_gap_ext", ctypes.c_int32),
+                ("txt_gap_open", ctypes.c_int32), ("txt_gap_ext", ctypes.c_int32)]
+
+
+class _Batch(ctypes.Structure):
+    _fields_ = [("reads_dev", ctypes.c_void_p), ("read_bits", ctypes.c_uint32),
+                ("read_offsets_dev", ctypes.c_void_p), ("quals_dev", ctypes.c_void_p),
+                ("read_id_dev", ctypes.c_void_p), ("flags_dev", ctypes.c_void_p),
+                ("text_dev", ctypes.c_void_p), ("text_bits", ctypes.c_uint32),
+                ("win_begin_dev", ctypes.c_void_p), ("win_end_dev", ctypes.c_void_p), ("n", ctypes.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    """the C-ABI library; raises (loudly) if it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NvbioError(5, "%s is missing: build it with __graft_entry__.build() "
+                                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.nvbio_amd_last_error.restype = ctypes.c_char_p
+        L.nvbio_amd_version.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != 0:
+        raise NvbioError(status, lib().nvbio_amd_last_error().decode())
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    lib().nvbio_amd_device_count(ctypes.byref(n))
+    return n.value
+
+
+def _dev_tensor(a, dtype, device):
+    """numpy array or tensor -> contiguous device tensor of the given torch dtype (bit pattern kept)"""
+    torch = _torch()
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        t = a
+        if t.dtype != dtype:
+            t = t.view(dtype) if t.element_size() == torch.empty(0, dtype=dtype).element_size() else t.to(dtype)
+        return t.to(device).contiguous()
+    a = np.ascontiguousarray(a)
+    np_of = {torch.int32: np.int32, torch.uint8: np.uint8, torch.int64: np.int64}[dtype]
+    if a.dtype.itemsize == np.dtype(np_of).itemsize:
+        a = a.view(np_of)
+    else:
+        a = a.astype(np_of)
+    return torch.from_numpy(a).to(device)
+
+
+# ---- string sets -------------------------------------------------------------------------------
+class PackedStringSet:
+    """A set of strings in HBM (the string-set concept of FMIndexFilter::rank, filter.h:52-231).
+
+    symbols : packed big-endian uint32 words (bits 2 or 4) or bytes (bits 8), numpy or tensor
+    offsets : None (string i = [i*stride, i*stride+fixed_len)), n start offsets (+ fixed_len),
+              or n+1 offsets with ranges=True (io::SequenceData sequence_index)
+    """
+
+    def __init__(self, symbols, bits, n, offsets=None, ranges=False, fixed_len=0, stride=None, device="cuda:0"):
+        torch = _torch()
+        self.bits, self.n = int(bits), int(n)
+        self.symbols = _dev_tensor(symbols, torch.uint8 if bits == 8 else torch.int32, device)
+        self.offsets = _dev_tensor(offsets, torch.int32, device)
+        self.ranges, self.fixed_len = bool(ranges), int(fixed_len)
+        self.stride = int(fixed_len if stride is None else stride)
+        self.device = device
+
+    def c_struct(self):
+        return _StringSet(_ptr(self.symbols), self.bits, _ptr(self.offsets), 1 if self.ranges else 0,
+                          self.fixed_len, self.stride, self.n)
+
+
+# ---- FM-index ----------------------------------------------------------------------------------
+class FMIndex:
+    """nvbio::fm_index over the production bwt_occ / ssa layout, resident in HBM."""
+
+    def __init__(self, handle, device, keep=()):
+        self._h, self.device, self._keep = handle, device, keep
+
+    @staticmethod
+    def _dev_index(device):
+        torch = _torch()
+        d = torch.device(device)
+        return d.index if d.index is not None else 0
+
+    @classmethod
+    def from_arrays(cls, length, primary, L2, bwt_occ, ssa, kmer_len=0, device="cuda:0"):
+        """wrap index arrays (numpy or tensors); replaces FMIndexDataDevice (fmindex_impl.cu:740-816)"""
+        torch = _torch()
+        b = _dev_tensor(bwt_occ, torch.int32, device)
+        s = _dev_tensor(ssa, torch.int32, device) if ssa is not None else None
+        v = _View()
+        v.length, v.primary = int(length), int(primary)
+        for i in range(5):
+            v.L2[i] = int(L2[i])
+        v.bwt_occ_dev, v.bwt_occ_words = b.data_ptr(), b.numel()
+        v.ssa_dev, v.ssa_words = (s.data_ptr(), s.numel()) if s is not None else (None, 0)
+        h = ctypes.c_void_p()
+        _check(lib().nvbio_fm_index_create(ctypes.byref(v), cls._dev_index(device), ctypes.c_uint32(kmer_len),
+                                           _stream_ptr(device), ctypes.byref(h)))
+        return cls(h, device, keep=(b, s))
+
+    @classmethod
+    def build(cls, text2, length, kmer_len=0, max_lcp=0, device="cuda:0"):
+        """build the index on the GPU from a 2-bit packed text (nvbio_fm_index_build)"""
+        torch = _torch()
+        t = _dev_tensor(text2, torch.int32, device)
+        h = ctypes.c_void_p()
+        _check(lib().nvbio_fm_index_build(_ptr(t), ctypes.c_uint32(length), cls._dev_index(device),
+                                          ctypes.c_uint32(kmer_len), ctypes.c_uint32(max_lcp), _stream_ptr(device),
+                                          ctypes.byref(h)))
+        return cls(h, device, keep=(t,))
+
+    def close(self):
+        if self._h is not None:
+            _torch().cuda.synchronize(self.device)
+            _check(lib().nvbio_fm_index_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def view(self):
+        v = _View()
+        _check(lib().nvbio_fm_index_get_view(self._h, ctypes.byref(v)))
+        return v
+
+    @property
+    def length(self):
+        return self.view().length
+
+    @property
+    def primary(self):
+        return self.view().primary
+
+    def arrays(self):
+        """(bwt_occ, ssa) copied out into fresh device int32 tensors (nvbio_fm_index_export)"""
+        torch = _torch()
+        v = self.view()
+        b = torch.empty(int(v.bwt_occ_words), dtype=torch.int32, device=self.device)
+        s = torch.empty(int(v.ssa_words), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_index_export(self._h, _ptr(b), _ptr(s), _stream_ptr(self.device)))
+        return b, s
+
+    def device_bytes(self):
+        b = ctypes.c_uint64()
+        _check(lib().nvbio_fm_index_device_bytes(self._h, ctypes.byref(b)))
+        return b.value
+
+    # -- free functions of nvbio/fmindex/fmindex.h:370-557 ---------------------------------------
+    def match(self, queries, flags=0, want_blocks=False):
+        """ranges[n,2] (int32 tensor holding uint32 bits) = match()/match_reverse() of every query"""
+        torch = _torch()
+        ranges = torch.empty((queries.n, 2), dtype=torch.int32, device=self.device)
+        blocks = torch.empty(queries.n, dtype=torch.int32, device=self.device) if want_blocks else None
+        qs = queries.c_struct()
+        _check(lib().nvbio_fm_match(self._h, ctypes.byref(qs), ctypes.c_uint32(flags), _ptr(ranges), _ptr(blocks),
+                                    _stream_ptr(self.device)))
+        return (ranges, blocks) if want_blocks else ranges
+
+    def rank(self, rows, syms):
+        torch = _torch()
+        rows = _dev_tensor(rows, torch.int32, self.device)
+        syms = _dev_tensor(syms, torch.uint8, self.device)
+        out = torch.empty(rows.numel(), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_rank(self._h, _ptr(rows), _ptr(syms), ctypes.c_uint32(rows.numel()), _ptr(out),
+                                   _stream_ptr(self.device)))
+        return out
+
+    def rank4(self, rows):
+        torch = _torch()
+        rows = _dev_tensor(rows, torch.int32, self.device)
+        out = torch.empty((rows.numel(), 4), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_rank4(self._h, _ptr(rows), ctypes.c_uint32(rows.numel()), _ptr(out),
+                                    _stream_ptr(self.device)))
+        return out
+
+    def locate(self, rows):
+        torch = _torch()
+        rows = _dev_tensor(rows, torch.int32, self.device)
+        pos = torch.empty(rows.numel(), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_locate(self._h, _ptr(rows), ctypes.c_uint32(rows.numel()), _ptr(pos),
+                                     _stream_ptr(self.device)))
+        return pos
+
+    def locate_ssa_iterator(self, rows):
+        torch = _torch()
+        rows = _dev_tensor(rows, torch.int32, self.device)
+        jt = torch.empty((rows.numel(), 2), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_locate_init(self._h, _ptr(rows), ctypes.c_uint32(rows.numel()), _ptr(jt),
+                                          _stream_ptr(self.device)))
+        return jt
+
+    def lookup_ssa_iterator(self, jt):
+        torch = _torch()
+        pos = torch.empty(jt.shape[0], dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_locate_lookup(self._h, _ptr(jt), ctypes.c_uint32(jt.shape[0]), _ptr(pos),
+                                            _stream_ptr(self.device)))
+        return pos
+
+
+class FMIndexFilter:
+    """nvbio::FMIndexFilter<device_tag, fm_index_type> (nvbio/fmindex/filter.h:136-231)."""
+
+    def __init__(self):
+        self._index = None
+        self._ranges = self._slots = None
+        self._n_hits = 0
+        self._n_queries = 0
+
+    def rank(self, index, string_set, flags=0):
+        """enact the filter; returns the total number of hits (filter_inl.h:261-293)"""
+        torch = _torch()
+        self._index, self._n_queries = index, string_set.n
+        self._ranges = torch.empty((string_set.n, 2), dtype=torch.int32, device=index.device)
+        self._slots = torch.empty(string_set.n, dtype=torch.int64, device=index.device)
+        total = ctypes.c_uint64(0)
+        qs = string_set.c_struct()
+        _check(lib().nvbio_fm_filter_rank(index._h, ctypes.byref(qs), ctypes.c_uint32(flags), _ptr(self._ranges),
+                                          _ptr(self._slots), ctypes.byref(total), _stream_ptr(index.device)))
+        self._n_hits = total.value
+        return self._n_hits
+
+    def locate(self, begin, end, hits=None):
+        """hits[h-begin] = (text_pos, query_id) for hit indices [begin,end) (filter_inl.h:299-393)"""
+        torch = _torch()
+        if hits is None:
+            hits = torch.empty((end - begin, 2), dtype=torch.int32, device=self._index.device)
+        _check(lib().nvbio_fm_filter_locate(self._index._h, _ptr(self._ranges), _ptr(self._slots),
+                                            ctypes.c_uint32(self._n_queries), ctypes.c_uint64(begin),
+                                            ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))
+        return hits
+
+    def n_hits(self):
+        return self._n_hits
+
+    def ranges(self):
+        return self._ranges
+
+    def slots(self):
+        return self._slots
+
+
+# ---- alignment ---------------------------------------------------------------------------------
+class GotohScheme:
+    """the Gotoh scoring-scheme concept as data (see nvbio_gotoh_scheme in include/nvbio_amd.h)"""
+
+    def __init__(self, match, mm_min, mm_max, pat_gap_open, pat_gap_ext, txt_gap_open, txt_gap_ext):
+        self.c = _Scheme(match, mm_min, mm_max, pat_gap_open, pat_gap_ext, txt_gap_open, txt_gap_ext)
+
+
+def SimpleGotohScheme(match, mismatch, gap_open, gap_ext):
+    """aln::SimpleGotohScheme (nvbio/alignment/utils.h:103-123)"""
+    return GotohScheme(match, -mismatch, -mismatch, gap_open, gap_ext, gap_open, gap_ext)
+
+
+class GotohAligner:
+    """aln::GotohAligner<TYPE, scheme> (nvbio/alignment/alignment.h:437-449)"""
+
+    def __init__(self, type, scheme):
+        self.type, self.scheme = type, scheme
+
+
+def make_gotoh_aligner(type, scheme):
+    return GotohAligner(type, scheme)
+
+
+class AlignmentBatch:
+    """The flattened stream of alignment jobs (see nvbio_alignment_batch)."""
+
+    def __init__(self, reads, read_bits, read_offsets, text, text_bits, win_begin, win_end, quals=None, read_id=None,
+                 flags=None, device="cuda:0"):
+        torch = _torch()
+        self.device = device
+        self.read_bits, self.text_bits = int(read_bits), int(text_bits)
+        self.reads = _dev_tensor(reads, torch.uint8 if read_bits == 8 else torch.int32, device)
+        self.read_offsets = _dev_tensor(read_offsets, torch.int32, device)
+        self.text = _dev_tensor(text, torch.uint8 if text_bits == 8 else torch.int32, device)
+        self.win_begin = _dev_tensor(win_begin, torch.int32, device)
+        self.win_end = _dev_tensor(win_end, torch.int32, device)
+        self.quals = _dev_tensor(quals, torch.uint8, device)
+        self.read_id = _dev_tensor(read_id, torch.int32, device)
+        self.flags = _dev_tensor(flags, torch.uint8, device)
+        self.n = int(self.win_begin.numel())
+
+    def size(self):
+        return self.n
+
+    def c_struct(self):
+        return _Batch(_ptr(self.reads), self.read_bits, _ptr(self.read_offsets), _ptr(self.quals), _ptr(self.read_id),
+                      _ptr(self.flags), _ptr(self.text), self.text_bits, _ptr(self.win_begin), _ptr(self.win_end),
+                      self.n)
+
+
+class BatchedBandedAlignmentScore:
+    """aln::BatchedBandedAlignmentScore<BAND_LEN, stream, scheduler> (nvbio/alignment/batched.h:298,
+    batched_banded_inl.h:90-157): enact() scores every job of the stream."""
+
+    def __init__(self, band_len, aligner):
+        self.band_len, self.aligner = int(band_len), aligner
+
+    @staticmethod
+    def min_temp_storage(max_pattern_len, max_text_len, stream_size):
+        return 0        # as the reference's Host/Device thread schedulers (batched_banded_inl.h:100-104)
+
+    max_temp_storage = min_temp_storage
+
+    def enact(self, batch, scores=None, sinks=None):
+        torch = _torch()
+        if scores is None:
+            scores = torch.empty(batch.n, dtype=torch.int32, device=batch.device)
+        if sinks is None:
+            sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
+        bs = batch.c_struct()
+        _check(lib().nvbio_banded_gotoh_score(FMIndex._dev_index(batch.device), ctypes.c_uint32(self.band_len),
+                                              ctypes.c_int(self.aligner.type), ctypes.byref(self.aligner.scheme.c),
+                                              ctypes.byref(bs), _ptr(scores), _ptr(sinks), _stream_ptr(batch.device)))
+        return scores, sinks
+
+
+def batch_banded_alignment_score(band_len, aligner, batch):
+    """aln::batch_banded_alignment_score<BAND_LEN> (nvbio/alignment/batched.h:185, batched_inl.h:1046-1086)"""
+    return BatchedBandedAlignmentScore(band_len, aligner).enact(batch)
+
+
+class BatchedAlignmentScore:
+    """aln::BatchedAlignmentScore<stream, scheduler> (full-matrix DP; batched.h:274, batched_inl.h:221-592)"""
+
+    def __init__(self, aligner, text_blocking=True):
+        self.aligner, self.text_blocking = aligner, bool(text_blocking)
+
+    def enact(self, batch, max_pattern_len, max_text_len, min_scores=None, scores=None, sinks=None):
+        torch = _torch()
+        if scores is None:
+            scores = torch.empty(batch.n, dtype=torch.int32, device=batch.device)
+        if sinks is None:
+            sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
+        ms = _dev_tensor(min_scores, torch.int32, batch.device)
+        bs = batch.c_struct()
+        _check(lib().nvbio_full_gotoh_score(FMIndex._dev_index(batch.device), ctypes.c_int(self.aligner.type),
+                                            ctypes.c_int(1 if self.text_blocking else 0),
+                                            ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs),
+                                            ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms),
+                                            _ptr(scores), _ptr(sinks), None, ctypes.c_uint64(0),
+                                            _stream_ptr(batch.device)))
+        return scores, sinks
+
+
+def u32(t):
+    """int32 device/host tensor -> numpy uint32 (results are uint32 bit patterns)"""
+    return t.detach().cpu().numpy().view(np.uint32)

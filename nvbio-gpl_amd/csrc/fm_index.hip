@@ -1,0 +1,462 @@
+// fm_index.hip -- FM-index seed pass for gfx950: match / rank / locate / filter, behind the C ABI.
+//
+// Reference behaviour reproduced (file:line relative to the reference tree):
+//   match / match_reverse                 nvbio/fmindex/fmindex_inl.h:181-278
+//   nvBowtie match_range + exact seeds    nvBowtie/bowtie2/cuda/mapping_inl.h:73-86,193-282
+//   rank / rank4                          nvbio/fmindex/fmindex_inl.h:27-173
+//   locate / locate_ssa_iterator / lookup nvbio/fmindex/fmindex_inl.h:360-460
+//   FMIndexFilter<device_tag>             nvbio/fmindex/filter_inl.h:261-393
+//
+// MI355X design: the pass is a dependent chain of random 32-byte gathers, bound by HBM
+// request rate, not by arithmetic.  One lane owns one query; kernels keep <= 64 VGPRs so that
+// 8 waves per SIMD (2048 lanes per CU) are in flight to cover the ~2 us loaded HBM latency, the
+// two ends of a range share one record when they fall in the same 64-symbol block, and the first
+// k steps (where the range still spans the whole index and both ends miss every cache) are
+// replaced by one 8-byte lookup in a 4^k-entry table of SA ranges built once per index
+// (k = 12 -> 128 MiB: served from the 256 MiB Infinity Cache / HBM; the table is exact, it stores
+// the reference's own early-exit values, so ranges are identical with and without it).
+#include "fm_device.h"
+#include <hipcub/hipcub.hpp>
+#include <new>
+
+namespace nvbio_amd {
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct FMIndexImpl
+{
+    int                  device;
+    nvbio_fm_index_view  view;        // host copy (device pointers inside)
+    uint2*               ktab;        // owned
+    uint32_t             kmer;
+    bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
+    uint64_t             owned_bytes;
+
+    DevIndex dev() const
+    {
+        DevIndex d;
+        d.length = view.length; d.primary = view.primary;
+        d.L2_0 = view.L2[0]; d.L2_1 = view.L2[1]; d.L2_2 = view.L2[2]; d.L2_3 = view.L2[3]; d.L2_4 = view.L2[4];
+        d.rec  = (const uint4*)view.bwt_occ_dev;
+        d.ssa  = view.ssa_dev;
+        d.ktab = ktab; d.kmer = kmer;
+        return d;
+    }
+};
+
+struct StringSetDev
+{
+    const void*     symbols;
+    const uint32_t* offsets;
+    uint32_t        ranges;      // offsets are [n+1] begin/end pairs
+    uint32_t        fixed_len;
+    uint32_t        stride;
+    uint32_t        n;
+};
+
+__device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint32_t i, uint32_t& begin, uint32_t& len)
+{
+    if (q.offsets)
+    {
+        begin = q.offsets[i];
+        len   = q.ranges ? q.offsets[i + 1] - begin : q.fixed_len;
+    }
+    else { begin = i * q.stride; len = q.fixed_len; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// match
+// ---------------------------------------------------------------------------------------------
+template <int BITS, bool COUNT>
+__global__ void __launch_bounds__(256)
+fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, uint2* __restrict__ ranges, uint32_t* __restrict__ blocks)
+{
+    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
+    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
+    const bool tab  = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
+
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x)
+    {
+        uint32_t begin, len;
+        string_bounds( q, i, begin, len );
+        SymbolReader<BITS> rd( q.symbols );
+
+        // symbol s in scan order
+        auto sym = [&](const uint32_t s) -> uint32_t {
+            const uint32_t c = rd.get( fwd ? begin + s : begin + len - 1u - s );
+            return (comp && c < 4u) ? 3u - c : c;
+        };
+
+        uint32_t x = 0, y = f.length, s = 0, nblk = 0;
+
+        if (tab && len >= f.kmer)
+        {
+            uint32_t key = 0; bool ok = true;
+            for (uint32_t t = 0; t < f.kmer; ++t)
+            {
+                const uint32_t c = sym( t );
+                ok = ok && (c < 4u);
+                key = (key << 2) | (c & 3u);
+            }
+            if (ok) { const uint2 r = f.ktab[key]; x = r.x; y = r.y; s = f.kmer; }
+        }
+
+        for (; s < len && x <= y; ++s)
+        {
+            const uint32_t c = sym( s );
+            if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
+            search_step<COUNT>( f, x, y, c, nblk );
+        }
+        ranges[i] = make_uint2( x, y );
+        if (COUNT) blocks[i] = nblk;
+    }
+}
+
+// level j of the k-mer table from level j-1: entry (key<<2 | c) = one search step on entry key
+// (or the entry itself when it is already empty: the reference's loop would have stopped there)
+__global__ void __launch_bounds__(256)
+fm_ktab_level_kernel(const DevIndex f, const uint2* __restrict__ prev, uint2* __restrict__ next, const uint64_t n_next)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_next; e += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint2 r = prev[e >> 2];
+        uint32_t x = r.x, y = r.y, nb = 0;
+        if (x <= y) search_step<false>( f, x, y, (uint32_t)(e & 3u), nb );
+        next[e] = make_uint2( x, y );
+    }
+}
+__global__ void fm_ktab_root_kernel(uint2* root, const uint32_t length) { root[0] = make_uint2( 0u, length ); }
+
+// ---------------------------------------------------------------------------------------------
+// rank / rank4
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fm_rank_kernel(const DevIndex f, const uint32_t* __restrict__ rows, const uint8_t* __restrict__ syms, const uint32_t n, uint32_t* __restrict__ out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = rank_row( f, rows[i], syms[i] & 3u );
+}
+__global__ void __launch_bounds__(256)
+fm_rank4_kernel(const DevIndex f, const uint32_t* __restrict__ rows, const uint32_t n, uint4* __restrict__ out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        uint32_t k = rows[i];
+        uint4 r;
+        if (k == 0xFFFFFFFFu)    r = make_uint4( 0, 0, 0, 0 );
+        else if (k == f.length)  r = make_uint4( f.L2_1 - f.L2_0, f.L2_2 - f.L2_1, f.L2_3 - f.L2_2, f.L2_4 - f.L2_3 );
+        else
+        {
+            if (k >= f.primary) --k;
+            if (k == 0xFFFFFFFFu) r = make_uint4( 0, 0, 0, 0 );
+            else
+            {
+                const uint4 b = f.rec[2u * (k >> 6)], o = f.rec[2u * (k >> 6) + 1u];
+                const uint4 cnt = count4_in_block( b, k & 63u );
+                r = make_uint4( o.x + cnt.x, o.y + cnt.y, o.z + cnt.z, o.w + cnt.w );
+            }
+        }
+        out[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// locate
+// ---------------------------------------------------------------------------------------------
+// MODE 0: pos = locate(row); MODE 1: (j,t) = locate_ssa_iterator(row)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+fm_locate_kernel(const DevIndex f, const uint32_t* rows, const uint32_t n, uint32_t* pos, uint2* jt)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        uint32_t j = rows[i], t = 0;
+        while (j & 15u) { j = lf_step( f, j ); ++t; }           // SSA_index_multiple_context<16>::has (ssa_inl.h:491-495)
+        if (MODE == 0) pos[i] = f.ssa[j >> 4] + t;
+        else           jt[i]  = make_uint2( j, t );
+    }
+}
+__global__ void __launch_bounds__(256)
+fm_lookup_kernel(const DevIndex f, const uint2* __restrict__ jt, const uint32_t n, uint32_t* __restrict__ pos)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        pos[i] = f.ssa[jt[i].x >> 4] + jt[i].y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter
+// ---------------------------------------------------------------------------------------------
+struct RangeSize
+{
+    __host__ __device__ __forceinline__ uint64_t operator()(const uint2 r) const { return (uint64_t)(uint32_t)(1u + r.y - r.x); }
+};
+
+// hits[h-begin] = (locate(range.x + local), query) for the global hit index h (filter_inl.h:66-118,359-392)
+__global__ void __launch_bounds__(256)
+fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint64_t* __restrict__ slots, const uint32_t n_queries,
+                        const uint64_t begin, const uint64_t end, uint2* __restrict__ hits)
+{
+    for (uint64_t h = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < end; h += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint32_t lo = 0, hi = n_queries;                        // upper_bound( h, slots )
+        while (lo < hi)
+        {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (slots[mid] <= h) lo = mid + 1u; else hi = mid;
+        }
+        const uint32_t slot  = lo;
+        const uint64_t base  = slot ? slots[slot - 1u] : 0ull;
+        uint32_t j = ranges[slot].x + (uint32_t)(h - base), t = 0;
+        while (j & 15u) { j = lf_step( f, j ); ++t; }
+        hits[h - begin] = make_uint2( f.ssa[j >> 4] + t, slot );
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static nvbio_status make_set(const nvbio_string_set* s, StringSetDev* d)
+{
+    NVB_REQUIRE( s != nullptr, "queries is NULL" );
+    NVB_REQUIRE( s->symbol_bits == 2 || s->symbol_bits == 4 || s->symbol_bits == 8, "symbol_bits must be 2, 4 or 8" );
+    NVB_REQUIRE( s->n == 0 || s->symbols_dev != nullptr, "symbols_dev is NULL" );
+    NVB_REQUIRE( !(s->offsets_are_ranges && s->offsets_dev == nullptr), "offsets_are_ranges without offsets_dev" );
+    d->symbols = s->symbols_dev; d->offsets = s->offsets_dev; d->ranges = s->offsets_are_ranges;
+    d->fixed_len = s->fixed_len; d->stride = s->stride; d->n = s->n;
+    return NVBIO_OK;
+}
+
+static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
+{
+    idx->ktab = nullptr; idx->kmer = 0;
+    if (k == 0) return NVBIO_OK;
+    const uint64_t entries = 1ull << (2 * k);
+    uint2 *a = nullptr, *b = nullptr;
+    if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (hipMalloc( (void**)&b, (entries / 4) * sizeof(uint2) ) != hipSuccess) { (void)hipFree( a ); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    // levels alternate between the two buffers so that level k lands in `a` (the large one)
+    uint2* cur = (k % 2 == 0) ? a : b;
+    uint2* oth = (k % 2 == 0) ? b : a;
+    DevIndex f = idx->dev(); f.ktab = nullptr; f.kmer = 0;
+    hipLaunchKernelGGL( fm_ktab_root_kernel, dim3(1), dim3(1), 0, stream, cur, idx->view.length );
+    for (uint32_t j = 1; j <= k; ++j)
+    {
+        const uint64_t n_next = 1ull << (2 * j);
+        hipLaunchKernelGGL( fm_ktab_level_kernel, dim3( grid_for( n_next ) ), dim3(256), 0, stream, f, (const uint2*)cur, oth, n_next );
+        uint2* t = cur; cur = oth; oth = t;
+    }
+    NVB_HIP( hipGetLastError() );
+    NVB_HIP( hipStreamSynchronize( stream ) );
+    // cur == a by construction
+    (void)hipFree( b );
+    idx->ktab = a; idx->kmer = k;
+    idx->owned_bytes += entries * sizeof(uint2);
+    return NVBIO_OK;
+}
+
+nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out)
+{
+    FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
+    if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
+    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0;
+    idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
+    const nvbio_status st = build_kmer_table( idx, kmer_len, stream );
+    if (st != NVBIO_OK)
+    {
+        if (owns) { (void)hipFree( (void*)view->bwt_occ_dev ); (void)hipFree( (void*)view->ssa_dev ); }
+        delete idx;
+        return st;
+    }
+    *out = (nvbio_fm_index_t)idx;
+    return NVBIO_OK;
+}
+
+} // namespace nvbio_amd
+
+using namespace nvbio_amd;
+
+extern "C" {
+
+nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, void* stream, nvbio_fm_index_t* out)
+{
+    NVB_REQUIRE( view && out, "view/out is NULL" );
+    NVB_REQUIRE( view->bwt_occ_dev != nullptr, "bwt_occ_dev is NULL" );
+    NVB_REQUIRE( ((uintptr_t)view->bwt_occ_dev & 31u) == 0, "bwt_occ_dev must be 32-byte aligned" );
+    NVB_REQUIRE( kmer_len <= 14, "kmer_len must be <= 14" );
+    NVB_REQUIRE( view->L2[4] == view->length, "L2[4] must equal length" );
+    NVB_REQUIRE( view->primary <= view->length, "primary out of range" );
+    const uint64_t need = 2ull * ((((uint64_t)view->length + 15u) / 16u + 3u) & ~3ull);
+    NVB_REQUIRE( view->bwt_occ_words >= need, "bwt_occ_words too small for length" );
+    NVB_REQUIRE( view->ssa_dev == nullptr || view->ssa_words >= ((uint64_t)view->length + 16u) / 16u, "ssa_words too small for length" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out );
+}
+
+nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
+{
+    if (!index) return NVBIO_OK;
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    if (idx->ktab) (void)hipFree( idx->ktab );
+    if (idx->owns_arrays) { (void)hipFree( (void*)idx->view.bwt_occ_dev ); (void)hipFree( (void*)idx->view.ssa_dev ); }
+    delete idx;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_index_get_view(nvbio_fm_index_t index, nvbio_fm_index_view* view)
+{
+    NVB_REQUIRE( index && view, "index/view is NULL" );
+    *view = ((FMIndexImpl*)index)->view;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_index_export(nvbio_fm_index_t index, uint32_t* bwt_occ_out_dev, uint32_t* ssa_out_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    if (bwt_occ_out_dev)
+        NVB_HIP( hipMemcpyAsync( bwt_occ_out_dev, idx->view.bwt_occ_dev, idx->view.bwt_occ_words * 4ull, hipMemcpyDeviceToDevice, (hipStream_t)stream ) );
+    if (ssa_out_dev && idx->view.ssa_dev)
+        NVB_HIP( hipMemcpyAsync( ssa_out_dev, idx->view.ssa_dev, idx->view.ssa_words * 4ull, hipMemcpyDeviceToDevice, (hipStream_t)stream ) );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_index_device_bytes(nvbio_fm_index_t index, uint64_t* bytes)
+{
+    NVB_REQUIRE( index && bytes, "index/bytes is NULL" );
+    *bytes = ((FMIndexImpl*)index)->owned_bytes;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_match(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                            nvbio_uint2* ranges_dev, uint32_t* blocks_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    StringSetDev q; NVB_CHECK( make_set( queries, &q ) );
+    if (q.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev != nullptr, "ranges_dev is NULL" );
+    NVB_REQUIRE( blocks_dev == nullptr || (flags & NVBIO_FM_NO_KMER_TABLE), "blocks_dev requires NVBIO_FM_NO_KMER_TABLE" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    const DevIndex f = idx->dev();
+    const dim3 grid( grid_for( q.n ) ), block( 256 );
+    hipStream_t s = (hipStream_t)stream;
+#define NVB_LAUNCH_MATCH(BITS)                                                                                              \
+    if (blocks_dev) hipLaunchKernelGGL( (fm_match_kernel<BITS,true>),  grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev ); \
+    else            hipLaunchKernelGGL( (fm_match_kernel<BITS,false>), grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev )
+    switch (queries->symbol_bits)
+    {
+    case 2: NVB_LAUNCH_MATCH(2); break;
+    case 4: NVB_LAUNCH_MATCH(4); break;
+    default: NVB_LAUNCH_MATCH(8); break;
+    }
+#undef NVB_LAUNCH_MATCH
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_rank(nvbio_fm_index_t index, const uint32_t* rows_dev, const uint8_t* syms_dev, uint32_t n, uint32_t* out_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( rows_dev && syms_dev && out_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_rank_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, syms_dev, n, out_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_rank4(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n, uint32_t* out_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( rows_dev && out_dev, "NULL device pointer" );
+    NVB_REQUIRE( ((uintptr_t)out_dev & 15u) == 0, "out_dev must be 16-byte aligned" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_rank4_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, (uint4*)out_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+static nvbio_status locate_common(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n, uint32_t* pos_dev, nvbio_uint2* jt_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( rows_dev && (pos_dev || jt_dev), "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    NVB_REQUIRE( jt_dev || idx->view.ssa_dev, "index has no sampled suffix array" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    if (pos_dev) hipLaunchKernelGGL( fm_locate_kernel<0>, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, pos_dev, (uint2*)nullptr );
+    else         hipLaunchKernelGGL( fm_locate_kernel<1>, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, (uint32_t*)nullptr, (uint2*)jt_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_locate(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n, uint32_t* pos_dev, void* stream)
+{
+    NVB_REQUIRE( pos_dev != nullptr || n == 0, "pos_dev is NULL" );
+    return locate_common( index, rows_dev, n, pos_dev, nullptr, stream );
+}
+nvbio_status nvbio_fm_locate_init(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n, nvbio_uint2* jt_dev, void* stream)
+{
+    NVB_REQUIRE( jt_dev != nullptr || n == 0, "jt_dev is NULL" );
+    return locate_common( index, rows_dev, n, nullptr, jt_dev, stream );
+}
+nvbio_status nvbio_fm_locate_lookup(nvbio_fm_index_t index, const nvbio_uint2* jt_dev, uint32_t n, uint32_t* pos_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( jt_dev && pos_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_lookup_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), (const uint2*)jt_dev, n, pos_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                                  nvbio_uint2* ranges_dev, uint64_t* slots_dev, uint64_t* n_hits, void* stream)
+{
+    NVB_REQUIRE( index && queries && n_hits, "NULL argument" );
+    *n_hits = 0;
+    if (queries->n == 0) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && slots_dev, "NULL device pointer" );
+    NVB_CHECK( nvbio_fm_match( index, queries, flags, ranges_dev, nullptr, stream ) );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+
+    hipcub::TransformInputIterator<uint64_t, RangeSize, const uint2*> sizes( (const uint2*)ranges_dev, RangeSize() );
+    size_t temp_bytes = 0;
+    NVB_HIP( hipcub::DeviceScan::InclusiveSum( nullptr, temp_bytes, sizes, slots_dev, (int)queries->n, s ) );
+    void* temp = nullptr;
+    if (hipMallocAsync( &temp, temp_bytes ? temp_bytes : 16, s ) != hipSuccess) { set_error( "filter_rank: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    const hipError_t e = hipcub::DeviceScan::InclusiveSum( temp, temp_bytes, sizes, slots_dev, (int)queries->n, s );
+    (void)hipFreeAsync( temp, s );
+    if (e != hipSuccess) { set_error( "filter_rank: scan failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    NVB_HIP( hipMemcpyAsync( n_hits, slots_dev + (queries->n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s ) );
+    NVB_HIP( hipStreamSynchronize( s ) );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                    uint32_t n_queries, uint64_t begin, uint64_t end, nvbio_uint2* hits_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (end <= begin) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && slots_dev && hits_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( end - begin ) ), dim3(256), 0, (hipStream_t)stream,
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+} // extern "C"

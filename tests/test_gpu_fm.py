@@ -1,0 +1,134 @@
+"""GPU parity: FM-index match / rank / locate / filter through the C-ABI vs the oracle and the
+golden vectors the reference produced.  Bit-exact (uint32 SA ranges, rows and positions)."""
+import numpy as np
+import pytest
+
+import oracle
+from util import make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_dev_index(amd, g, k=0):
+    return amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"], kmer_len=k)
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 6])
+def test_match_golden(amd, orc, fm_golden, k):
+    g = fm_golden
+    fmi = _golden_dev_index(amd, g, k)
+    Q = len(g["q_offs"]) - 1
+    # byte-per-symbol, concatenated ranges
+    qs = amd.PackedStringSet(g["q_syms"], 8, Q, offsets=g["q_offs"], ranges=True)
+    assert np.array_equal(amd.u32(fmi.match(qs)), g["ranges_bwd"])
+    assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_SCAN_FORWARD)), g["ranges_fwd"])
+    # the same queries 4-bit packed (N = 4 survives) and, without N's, 2-bit packed
+    qs4 = amd.PackedStringSet(orc.pack4(g["q_syms"]), 4, Q, offsets=g["q_offs"], ranges=True)
+    assert np.array_equal(amd.u32(fmi.match(qs4)), g["ranges_bwd"])
+    assert np.array_equal(amd.u32(fmi.match(qs4, amd.FM_SCAN_FORWARD)), g["ranges_fwd"])
+    clean = g["q_syms"].copy()
+    clean[clean > 3] = 0
+    idx = oracle.HostIndex(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"])
+    want = orc.match_batch(idx, clean, g["q_offs"])
+    qs2 = amd.PackedStringSet(orc.pack2(clean), 2, Q, offsets=g["q_offs"], ranges=True)
+    assert np.array_equal(amd.u32(fmi.match(qs2)), want)
+    # complement flag == matching the complemented string
+    comp = np.where(g["q_syms"] < 4, 3 - g["q_syms"], g["q_syms"]).astype(np.uint8)
+    want_c = orc.match_batch(idx, comp, g["q_offs"])
+    assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_COMPLEMENT)), want_c)
+    fmi.close()
+
+
+def test_rank_every_row_golden(amd, fm_golden):
+    g = fm_golden
+    fmi = _golden_dev_index(amd, g)
+    n = len(g["text"])
+    rows = np.repeat(np.arange(-1, n + 1, dtype=np.int64), 4).astype(np.uint32)
+    syms = np.tile(np.arange(4, dtype=np.uint8), n + 2)
+    got = amd.u32(fmi.rank(rows, syms)).reshape(n + 2, 4)
+    assert np.array_equal(got, g["ranks"])
+    got4 = amd.u32(fmi.rank4(np.arange(0, n + 1, dtype=np.uint32)))
+    assert np.array_equal(got4, g["ranks4"])
+    fmi.close()
+
+
+def test_locate_golden(amd, fm_golden):
+    g = fm_golden
+    fmi = _golden_dev_index(amd, g)
+    assert np.array_equal(amd.u32(fmi.locate(g["rows"])), g["pos"])
+    jt = fmi.locate_ssa_iterator(g["rows"])
+    assert np.array_equal(amd.u32(jt), g["jt"])
+    assert np.array_equal(amd.u32(fmi.lookup_ssa_iterator(jt)), g["pos"])
+    fmi.close()
+
+
+@pytest.fixture(scope="module")
+def big(orc):
+    rng = np.random.default_rng(42)
+    n = 1 << 20
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[5000:9000] = np.tile(np.array([2, 3, 2, 2, 0], dtype=np.uint8), 800)      # repeats -> wide ranges
+    return rng, text, orc.build_index(text)
+
+
+@pytest.mark.parametrize("k", [0, 8, 10])
+def test_match_locate_1M(amd, orc, big, k):
+    rng, text, hidx = big
+    fmi = amd.FMIndex.from_arrays(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa, kmer_len=k)
+    Q = 100000
+    syms, offs = make_queries(rng, text, Q, 1, 40, hit_every=3, n_count=200)
+    want, wblocks = orc.match_batch(hidx, syms, offs, want_blocks=True)
+    qs = amd.PackedStringSet(orc.pack4(syms), 4, Q, offsets=offs, ranges=True)
+    assert np.array_equal(amd.u32(fmi.match(qs)), want)
+    want_f = orc.match_batch(hidx, syms, offs, reverse=True)
+    assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_SCAN_FORWARD)), want_f)
+    r, blocks = fmi.match(qs, amd.FM_NO_KMER_TABLE, want_blocks=True)
+    assert np.array_equal(amd.u32(r), want)
+    assert np.array_equal(amd.u32(blocks), wblocks)         # algorithmic traffic unit
+    # fixed-length seeds addressed by start offset inside a read stream (nvBowtie seeds)
+    L = 22
+    starts = rng.integers(0, len(syms) - L, 50000).astype(np.uint32)
+    qs_f = amd.PackedStringSet(orc.pack4(syms), 4, len(starts), offsets=starts, fixed_len=L)
+    soffs = (np.arange(len(starts) + 1) * L).astype(np.uint32)
+    ssyms = np.concatenate([syms[s:s + L] for s in starts])
+    assert np.array_equal(amd.u32(fmi.match(qs_f)), orc.match_batch(hidx, ssyms, soffs))
+    rc = np.where(ssyms < 4, 3 - ssyms, ssyms).astype(np.uint8)
+    assert np.array_equal(amd.u32(fmi.match(qs_f, amd.FM_COMPLEMENT)), orc.match_batch(hidx, rc, soffs))
+    # locate: every row of the non-empty ranges (capped), and random rows
+    rows = np.concatenate([rng.integers(0, hidx.n + 1, 200000), [0, hidx.primary, hidx.n]]).astype(np.uint32)
+    assert np.array_equal(amd.u32(fmi.locate(rows)), orc.locate_batch(hidx, rows))
+    nz = rows > 0
+    assert np.array_equal(amd.u32(fmi.locate(rows))[nz], hidx.sa[rows[nz]])        # == the true SA
+    fmi.close()
+
+
+def test_filter_rank_locate(amd, orc, big):
+    rng, text, hidx = big
+    fmi = amd.FMIndex.from_arrays(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa, kmer_len=8)
+    Q = 20000
+    syms, offs = make_queries(rng, text, Q, 6, 30, hit_every=2, n_count=50)
+    total, ranges, slots = orc.filter_rank(hidx, syms, offs)
+    flt = amd.FMIndexFilter()
+    qs = amd.PackedStringSet(syms, 8, Q, offsets=offs, ranges=True)
+    assert flt.rank(fmi, qs) == total == flt.n_hits()
+    assert np.array_equal(amd.u32(flt.ranges()), ranges)
+    assert np.array_equal(flt.slots().cpu().numpy().view(np.uint64), slots)
+    for b, e in ((0, min(total, 50000)), (max(0, total - 1000), total), (total // 2, min(total, total // 2 + 7))):
+        if e > b:
+            assert np.array_equal(amd.u32(flt.locate(b, e)), orc.filter_locate(hidx, ranges, slots, b, e))
+    fmi.close()
+
+
+def test_empty_and_error_paths(amd, fm_golden):
+    g = fm_golden
+    fmi = _golden_dev_index(amd, g)
+    qs = amd.PackedStringSet(np.zeros(4, dtype=np.uint8), 8, 0, fixed_len=4)
+    assert fmi.match(qs).shape[0] == 0
+    # zero-length queries: the whole index (0, n)
+    qs0 = amd.PackedStringSet(np.zeros(4, dtype=np.uint8), 8, 3, fixed_len=0, stride=0)
+    assert np.array_equal(amd.u32(fmi.match(qs0)), np.array([[0, len(g["text"])]] * 3, dtype=np.uint32))
+    with pytest.raises(amd.NvbioError):
+        amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"][:8], g["ssa"])
+    with pytest.raises(amd.NvbioError):
+        amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"], kmer_len=15)
+    fmi.close()

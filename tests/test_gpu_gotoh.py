@@ -1,0 +1,112 @@
+"""GPU parity: batched banded Gotoh through the C-ABI vs the golden vectors of the reference and
+vs the oracle.  Integer scores and sinks must be exactly equal."""
+import numpy as np
+import pytest
+
+import oracle
+from util import mutate_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _scheme(amd, v):
+    return amd.GotohScheme(*[int(x) for x in v])
+
+
+@pytest.mark.parametrize("band", [3, 7, 15, 31])
+def test_banded_golden_bytes(amd, dp_golden, band):
+    """every golden pair, one symbol per byte (N = 4 in patterns), with and without qualities"""
+    g = dp_golden
+    S = len(g["schemes"])
+    n = len(g["pat_off"]) - 1
+    bi = list(g["bands"]).index(band)
+    for si in range(S):
+        for hq in (0, 1):
+            cases = np.array([i for i in range(n) if i % S == si and int(g["has_quals"][i]) == hq], dtype=np.uint32)
+            if len(cases) == 0:
+                continue
+            batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases],
+                                       g["txt_off"][cases + 1], quals=g["quals"] if hq else None, read_id=cases)
+            for typ in range(3):
+                sc, sk = amd.batch_banded_alignment_score(band, amd.make_gotoh_aligner(typ, _scheme(amd, g["schemes"][si])), batch)
+                want = g["banded"][cases, bi, typ]
+                assert np.array_equal(sc.cpu().numpy().astype(np.int64), want[:, 1]), (band, si, hq, typ)
+                assert np.array_equal(amd.u32(sk).astype(np.int64), want[:, 2:4]), (band, si, hq, typ)
+
+
+def test_banded_random_packed(amd, orc):
+    """nvBowtie-shaped batch: 4-bit reads (fw / reversed / complemented), windows on a 2-bit genome
+    including windows clipped at both genome ends, quality-dependent mismatches"""
+    rng = np.random.default_rng(3)
+    G = 300000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R, M = 6000, 150
+    starts = rng.integers(0, G - M - 8, R)
+    reads = mutate_reads(rng, text, starts, M)
+    reads[rng.random(reads.shape) < 0.002] = 4                  # a few N
+    lens = np.full(R, M); lens[::7] = rng.integers(30, 150, len(lens[::7]))
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[k, :lens[k]] for k in range(R)])
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    J = 20000
+    rid = rng.integers(0, R, J).astype(np.uint32)
+    flags = rng.integers(0, 4, J).astype(np.uint8)
+    flags[:J // 2] = 0
+    g_pos = starts[rid].astype(np.int64) + rng.integers(-3, 4, J)
+    g_pos[::50] = rng.integers(0, 10, len(g_pos[::50]))         # clipped at the genome start
+    g_pos[1::50] = G - rng.integers(100, 170, len(g_pos[1::50]))   # clipped at the genome end
+    g_pos = np.clip(g_pos, 0, G - 1)
+    for band in (31, 15, 7, 3):
+        # BestScoreStream window (nvBowtie/bowtie2/cuda/score_inl.h:100-106)
+        wb = np.where(g_pos > band // 2, g_pos - band // 2, 0).astype(np.uint32)
+        we = np.minimum(wb + band + lens[rid], G).astype(np.uint32)
+        we = np.maximum(we, wb + band - 1)                      # keep N >= BAND-1 (undefined in the reference below that)
+        we = np.minimum(we, G).astype(np.uint32)
+        ok = (we - wb) >= band - 1
+        sel = np.nonzero(ok)[0]
+        for typ, sv in ((oracle.LOCAL, (2, 2, 6, -8, -3, -8, -3)), (oracle.SEMI_GLOBAL, (0, 2, 6, -8, -3, -8, -3)),
+                        (oracle.GLOBAL, (1, 3, 3, -15, -4, -11, -2))):
+            for use_q in (True, False):
+                batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel],
+                                           quals=quals if use_q else None, read_id=rid[sel], flags=flags[sel])
+                sc, sk = amd.batch_banded_alignment_score(band, amd.make_gotoh_aligner(typ, _scheme(amd, sv)), batch)
+                wsc, wsk = orc.banded_gotoh_packed_batch(band, typ, oracle.Scheme(*sv), orc.pack4(flat), roffs,
+                                                         orc.pack2(text), wb[sel], we[sel], read_id=rid[sel],
+                                                         flags=flags[sel], quals=quals if use_q else None)
+                assert np.array_equal(sc.cpu().numpy(), wsc), (band, typ, use_q)
+                assert np.array_equal(amd.u32(sk), wsk), (band, typ, use_q)
+
+
+def test_quality_ramp_all_values(amd, orc):
+    """the float->int mismatch ramp (scoring.h:84-88) for every quality 0..255 and several ramps"""
+    pat = np.array([0], dtype=np.uint8)
+    txt = np.concatenate([[1], np.zeros(40, dtype=np.uint8)]).astype(np.uint8)
+    for mm_min, mm_max in ((2, 6), (0, 30), (1, 7), (3, 3), (6, 2), (0, 255)):
+        q = np.arange(256, dtype=np.uint8)
+        pats = np.zeros(256, dtype=np.uint8)
+        roffs = np.arange(257, dtype=np.uint32)
+        batch = amd.AlignmentBatch(pats, 8, roffs, txt, 8, np.zeros(256, dtype=np.uint32),
+                                   np.full(256, 31, dtype=np.uint32), quals=q)
+        sv = (5, mm_min, mm_max, -100, -100, -100, -100)
+        sc, _ = amd.batch_banded_alignment_score(3, amd.make_gotoh_aligner(oracle.GLOBAL, _scheme(amd, sv)), batch)
+        want = [orc.banded_gotoh(3, oracle.GLOBAL, oracle.Scheme(*sv), pat, txt[:31], np.array([v], dtype=np.uint8))[1]
+                for v in range(256)]
+        assert list(sc.cpu().numpy()) == want, (mm_min, mm_max)
+
+
+def test_banded_edge_cases(amd, orc):
+    """text shorter than the pattern (nothing reported), empty batch, unsupported band"""
+    txt = np.zeros(64, dtype=np.uint8)
+    pats = np.zeros(80, dtype=np.uint8)
+    roffs = np.array([0, 40, 80], dtype=np.uint32)
+    batch = amd.AlignmentBatch(pats, 8, roffs, txt, 8, np.array([0, 0], dtype=np.uint32),
+                               np.array([35, 64], dtype=np.uint32))
+    al = amd.make_gotoh_aligner(oracle.LOCAL, amd.SimpleGotohScheme(2, -1, -2, -1))
+    sc, sk = amd.batch_banded_alignment_score(31, al, batch)
+    assert sc.cpu().numpy()[0] == amd.SCORE_MIN and list(amd.u32(sk)[0]) == [0xFFFFFFFF, 0xFFFFFFFF]
+    assert sc.cpu().numpy()[1] == 80
+    with pytest.raises(amd.NvbioError):
+        amd.batch_banded_alignment_score(9, al, batch)
+    empty = amd.AlignmentBatch(pats, 8, roffs, txt, 8, np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint32))
+    sc, sk = amd.batch_banded_alignment_score(31, al, empty)
+    assert sc.numel() == 0
