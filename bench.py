@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on BASELINE.json's headline configuration.
+
+Workload (config.workload = "nvbowtie-se-150bp-3gbp", BASELINE.json configs[2]): per GPU, one
+step = one pass of the seed-and-extend path over a batch of 10 M synthetic 150 bp reads against
+a 3 Gbp synthetic reference: 2 x 9 exact 22-mer seeds per read through the FM-index (match +
+scan), expand + locate of every hit, candidate loci by diagonal, band-31 local Gotoh of every
+candidate window, best alignment per read.  Inputs (index, genome, reads) are resident in HBM
+when the timed region starts.  value = reads/s over all ranks (weak scaling: every rank maps its
+own 10 M-read shard against its own replica of the index; one RCCL gather of the per-read best
+(score, position) to rank 0 closes each step).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs (generated on the GPU, directly in packed form; seeds fixed)
+# ---------------------------------------------------------------------------------------------
+def make_reference(n, device, seed):
+    """3 Gbp i.i.d. uniform reference as 2-bit big-endian packed words (io::SequenceData<DNA> layout)"""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nw = (n + 15) // 16
+    words = torch.randint(-2 ** 31, 2 ** 31 - 1, (nw + 8,), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    return words
+
+
+def genome_symbols(words, idx):
+    """2-bit symbols at int64 indices idx"""
+    import torch
+    w = words[idx >> 4].to(torch.int64) & 0xFFFFFFFF
+    return ((w >> (30 - 2 * (idx & 15))) & 3).to(torch.uint8)
+
+
+def pack4(sym_flat):
+    """uint8 symbols (0..4) -> 4-bit big-endian packed int32 words (io::SequenceData<DNA_N> layout)"""
+    import torch
+    n = sym_flat.numel()
+    pad = (-n) % 8
+    if pad:
+        sym_flat = torch.cat([sym_flat, torch.zeros(pad, dtype=torch.uint8, device=sym_flat.device)])
+    s = sym_flat.view(-1, 8).to(torch.int64)
+    sh = torch.tensor([28, 24, 20, 16, 12, 8, 4, 0], device=sym_flat.device, dtype=torch.int64)
+    w = (s << sh[None, :]).sum(dim=1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
+    return torch.cat([w.to(torch.int32), torch.zeros(4, dtype=torch.int32, device=sym_flat.device)])
+
+
+def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000):
+    """150 bp reads drawn from the reference: 1 % substitutions, 0.1 %/base 1-3 bp indels,
+    50 % reverse-complemented.  Returns (reads uint8 [R,M], truth pos, rc)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out, pos_all, rc_all = [], [], []
+    for b in range(0, n_reads, chunk):
+        r = min(chunk, n_reads - b)
+        pos = torch.randint(0, n - M - 8, (r,), device=device, generator=g, dtype=torch.int64)
+        j = torch.arange(M, device=device, dtype=torch.int64)[None, :]
+        # indel: with probability 1-(1-0.001)^150 a read carries one indel of 1-3 bp
+        has = torch.rand(r, device=device, generator=g) < (1.0 - (1.0 - 0.001) ** M)
+        ip = torch.randint(5, M - 5, (r,), device=device, generator=g)[:, None]
+        ig = torch.randint(1, 4, (r,), device=device, generator=g)[:, None]
+        is_del = (torch.rand(r, device=device, generator=g) < 0.5)[:, None]
+        hasc = has[:, None]
+        src = torch.where(hasc & is_del & (j >= ip), j + ig, j)                     # deletion from the read
+        src = torch.where(hasc & ~is_del & (j >= ip + ig), j - ig, src)             # insertion into the read
+        sym = genome_symbols(words, pos[:, None] + src)
+        ins = hasc & ~is_del & (j >= ip) & (j < ip + ig)
+        rnd = torch.randint(0, 4, (r, M), device=device, generator=g, dtype=torch.uint8)
+        sym = torch.where(ins, rnd, sym)
+        sub = torch.rand(r, M, device=device, generator=g) < 0.01
+        sym = torch.where(sub, (sym + 1 + rnd % 3) % 4, sym)                         # a different base
+        rc = torch.rand(r, device=device, generator=g) < 0.5
+        sym = torch.where(rc[:, None], 3 - sym.flip(1), sym)
+        out.append(sym.contiguous()); pos_all.append(pos); rc_all.append(rc)
+    return torch.cat(out), torch.cat(pos_all), torch.cat(rc_all)
+
+
+# ---------------------------------------------------------------------------------------------
+def event_ms(pairs):
+    return [a.elapsed_time(b) for a, b in pairs]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ref-len", type=float, default=3e9, help="reference length (symbols)")
+    ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--kmer", type=int, default=12, help="k of the k-mer SA-range table (0 disables)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    amd = ge.load_package()
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    sharding = importlib.import_module("nvbio_gpl_amd.sharding")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    n = int(args.ref_len)
+    R = int(args.reads)
+    M = args.read_len
+    t0 = time.time()
+    genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
+    torch.cuda.synchronize()
+    t1 = time.time()
+    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    log("reference %d symbols generated in %.2fs, index built on the GPU in %.2fs (k-mer table k=%d, %.2f GB owned)"
+        % (n, t1 - t0, t2 - t1, args.kmer, fmi.device_bytes() / 1e9))
+    reads_sym, truth_pos, truth_rc = make_reads(genome, n, R, M, device, seed=1000 + rank)
+    reads4 = pack4(reads_sym.view(-1))
+    torch.cuda.synchronize()
+    log("%d reads x %d bp per rank generated in %.2fs" % (R, M, time.time() - t2))
+    batch = pipeline.ReadBatch(reads4, R, M)
+    params = pipeline.SeedExtendParams()
+    min_score = params.min_score_for(M)
+
+    def step(timers=None):
+        bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers)
+        if dist is not None:
+            # the only exchange of the path: per-read best (score, position*2+strand) to rank 0 over RCCL
+            sharding.gather_results(dist, sharding.pack_result(bs, bp, brc), world, rank, dst=0)
+        return bs, bp, brc, nc
+
+    for _ in range(args.warmup):
+        step()
+    timers = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    for _ in range(args.steps):
+        bs, bp, brc, nc = step(timers)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - w0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- quality of the result (not timed): reads aligned, and aligned where they came from ----
+    aligned = bs >= min_score
+    end_truth = truth_pos + M                                         # approximate end of the true locus
+    near = (bp - end_truth).abs() <= 40
+    frac_aligned = float(aligned.float().mean())
+    frac_correct = float((aligned & near & (brc.bool() == truth_rc)).float().mean())
+
+    # ---- stage times and the roofline of the dominant HBM kernel (the seed pass match kernel) --
+    stage_ms = {k: float(np.mean(event_ms(v))) for k, v in timers.items()}
+    spr = (M - params.seed_len) // params.interval_for(M) + 1
+    n_seeds = R * spr
+    # algorithmic bytes of one match launch: 32 B x distinct bwt_occ records the reference's
+    # backward search touches (counted by the kernel's NO_KMER_TABLE accounting mode, outside the
+    # timed region) + 11 B of query symbols (22 x 4 bit) + 8 B of result per query
+    read_off = torch.arange(R, device=device, dtype=torch.int64) * M
+    offs = (read_off[:, None] + torch.arange(spr, device=device, dtype=torch.int64)[None, :] * params.interval_for(M)).reshape(-1).to(torch.int32)
+    qs = amd.PackedStringSet(reads4, 4, n_seeds, offsets=offs, fixed_len=params.seed_len, device=device)
+    blocks = 0
+    for flags in (0, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT):
+        _, blk = fmi.match(qs, flags | amd.FM_NO_KMER_TABLE, want_blocks=True)
+        blocks += int((blk.to(torch.int64) & 0xFFFFFFFF).sum())
+    alg_bytes_per_launch = (blocks * 32 + 2 * n_seeds * (11 + 8)) / 2.0
+    match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
+    achieved = alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer:
+                traffic = tj.get("match_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    cells = float(nc) * params.band * M
+    extend_ms = stage_ms.get("extend", 0.0)
+
+    result = {
+        "metric": "aligned reads/sec (150 bp single-end, 3 Gbp ref); GCUPS of the banded extend pass in `extend`",
+        "value": world * R * args.steps / elapsed,
+        "unit": "reads/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32/i32", "data": "synthetic",
+        "config": {"workload": "nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150) else "custom",
+                   "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
+                   "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
+                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "parallelism": "read-shard x%d" % world},
+        "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
+        "stage_ms": stage_ms,
+        "roofline": {"kernel": "fm_match_kernel<4,false> (seed pass, one strand of %d seeds per launch)" % n_seeds,
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch, "ms_per_launch": match_ms,
+                     "queries_per_s": n_seeds / (match_ms * 1e-3) if match_ms > 0 else 0.0},
+        "extend": {"kernel": "banded_gotoh_kernel<31,LOCAL,4,2>", "bound": "valu (int32; MFMA not applicable)",
+                   "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
+                   "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
+    }
+
+    # ---- CPU baseline: the oracle (port of the reference's host path) on a bounded sample -------
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        from oracle import cpu_pipeline
+        O = oracle.Oracle()
+        b_occ, ssa = fmi.arrays()
+        v = fmi.view()
+        hidx = oracle.HostIndex(n, v.primary, [v.L2[i] for i in range(5)], amd.u32(b_occ), amd.u32(ssa))
+        del b_occ, ssa
+        g_host = amd.u32(genome)
+        probe = reads_sym[:20000].cpu().numpy()
+        c0 = time.perf_counter()
+        cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, probe, genome_is_packed=True)         # page in, estimate the rate
+        rate = len(probe) / (time.perf_counter() - c0)
+        Rs = args.cpu_sample or int(rate * args.cpu_seconds)
+        Rs = max(1000, min(Rs, R, 4_000_000))
+        rs = reads_sym[:Rs].cpu().numpy()
+        c0 = time.perf_counter()
+        cs, cp, crc, cnc = cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, rs, genome_is_packed=True)
+        cdt = time.perf_counter() - c0
+        same = bool(np.array_equal(cs, bs[:Rs].cpu().numpy()) and np.array_equal(cp, bp[:Rs].cpu().numpy()))
+        result["cpu_baseline"] = {"value": Rs / cdt, "unit": "reads/s", "cores": O.num_threads(), "kind": "port",
+                                  "sample": "first %d reads of rank 0's batch, whole path (seed, locate, band-31 extend), %.1f s" % (Rs, cdt),
+                                  "results_equal_gpu": same}
+        log("cpu baseline: %d reads in %.1fs on %d threads (equal to GPU results: %s)" % (Rs, cdt, O.num_threads(), same))
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

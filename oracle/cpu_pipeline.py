@@ -1,0 +1,79 @@
+"""oracle/cpu_pipeline.py -- TEST INFRASTRUCTURE ONLY.
+
+The reference-equivalent CPU path of the whole seed-and-extend composition, built from the
+oracle's restatement of the reference's host functions (match / locate in an OpenMP parallel
+for, as nvbio-test/fmindex_test.cu:375-407,879-890; BatchedBandedAlignmentScore<31,..,
+HostThreadScheduler>, nvbio/alignment/batched_banded_inl.h:113-121).  nvBowtie itself has no CPU
+path (its seeding / locate code is device-only), so "reference CPU aligned reads/s" is this
+composition: 2 x 9 exact 22-mer seeds -> locate -> banded score per 150 bp read.
+
+Used by tests/test_gpu_pipeline.py as the checker and by bench.py's cpu_baseline leg as the timed
+baseline.  Never imported by the product.
+"""
+import math
+
+import numpy as np
+
+from . import LOCAL, SCORE_MIN, Oracle, Scheme
+
+
+def revcomp(a):
+    return (3 - a[..., ::-1]).astype(np.uint8) if (a <= 3).all() else np.where(a[..., ::-1] < 4, 3 - a[..., ::-1], a[..., ::-1]).astype(np.uint8)
+
+
+def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
+                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False):
+    """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates)."""
+    scheme = scheme or Scheme(2, 2, 6, -8, -3, -8, -3)
+    R, M = reads.shape
+    L = seed_len
+    S_int = seed_interval or int(1 + 1.15 * math.sqrt(M))
+    spr = (M - L) // S_int + 1
+    starts = np.arange(spr) * S_int
+    cands = []
+    for strand in (0, 1):
+        seeds = np.stack([reads[:, s:s + L] for s in starts], axis=1)            # [R, spr, L]
+        if strand:
+            seeds = np.where(seeds[..., ::-1] < 4, 3 - seeds[..., ::-1], seeds[..., ::-1]).astype(np.uint8)
+        flat = np.ascontiguousarray(seeds.reshape(-1))
+        offs = (np.arange(R * spr + 1) * L).astype(np.uint32)
+        total, ranges, slots = O.filter_rank(hidx, flat, offs)
+        if total == 0:
+            continue
+        hits = O.filter_locate(hidx, ranges, slots, 0, total)
+        pos = hits[:, 0].astype(np.int64)
+        sid = hits[:, 1].astype(np.int64)
+        rid = sid // spr
+        p = (sid - rid * spr) * S_int
+        if strand:
+            p = M - p - L
+        cands.append((rid << 34) | (strand << 33) | (pos - p + 1024))
+    best_score = np.full(R, SCORE_MIN, dtype=np.int32)
+    best_pos = np.full(R, -1, dtype=np.int64)
+    best_rc = np.zeros(R, dtype=np.uint8)
+    if not cands:
+        return best_score, best_pos, best_rc, 0
+    keys = np.unique(np.concatenate(cands))
+    rid = keys >> 34
+    rc = (keys >> 33) & 1
+    diag = (keys & ((1 << 33) - 1)) - 1024
+    g_pos = np.maximum(diag, 0)
+    half = band // 2
+    wb = np.where(g_pos > half, g_pos - half, 0)
+    we = np.minimum(wb + band + M, genome_len)
+    flags = (rc * 3).astype(np.uint8)
+    reads4 = O.pack4(reads.reshape(-1))
+    genome2 = genome_syms_or_packed if genome_is_packed else O.pack2(genome_syms_or_packed)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    scores, sinks = O.banded_gotoh_packed_batch(band, aln_type, scheme, reads4, roffs, genome2, wb.astype(np.uint32),
+                                                we.astype(np.uint32), read_id=rid.astype(np.uint32), flags=flags,
+                                                quals=quals)
+    packed = (scores.astype(np.int64) << 32) | np.arange(len(keys), dtype=np.int64)
+    top = np.full(R, -(1 << 62), dtype=np.int64)
+    np.maximum.at(top, rid, packed)
+    has = top > -(1 << 62)
+    ci = (top & 0xFFFFFFFF)[has]
+    best_score[has] = scores[ci]
+    best_pos[has] = wb[ci] + sinks[ci, 0].astype(np.int64)
+    best_rc[has] = rc[ci].astype(np.uint8)
+    return best_score, best_pos, best_rc, len(keys)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
+#   1. kernel trace + stats (per-kernel time)   -> gpurun_out/prof/<tag>_stats
+#   2. PMC pass FETCH_SIZE (HBM read traffic)   -> gpurun_out/prof/<tag>_fetch
+#   3. PMC pass WRITE_SIZE                      -> gpurun_out/prof/<tag>_write
+# PMC passes run on their own (never combined with trace domains), as the pool requires.
+set -e
+TAG=${1:-r01}
+ARGS=${2:-"--steps 2 --warmup 1 --no-cpu-baseline"}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_stats.json 2> $OUT/${TAG}_stats.err
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.json 2> $OUT/${TAG}_fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_write.json 2> $OUT/${TAG}_write.err
+echo "write done"
+find $OUT -name "*.csv" | head -50
