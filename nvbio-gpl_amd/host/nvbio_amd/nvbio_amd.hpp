@@ -1,0 +1,281 @@
+// nvbio_amd.hpp -- C++ host-side mirror of the reference's operator API for the seed-and-extend
+// path, over the C ABI of include/nvbio_amd.h.  Header-only; no HIP code in here (it only needs
+// the HIP runtime API for device buffers), so it compiles with g++ or hipcc.
+//
+// It keeps the reference's names, argument meaning and ownership rules:
+//   nvbio_amd::fm_index            ~ nvbio::fm_index + io::FMIndexDataDevice (nvbio/fmindex/fmindex.h:320-361,
+//                                    nvbio/io/fmindex/fmindex.h:263-330): a storage-free view + its device owner
+//   match / locate                 ~ the free functions of nvbio/fmindex/fmindex.h:370-557, batched over a set
+//   FMIndexFilter<amd_device_tag>  ~ nvbio::FMIndexFilter<device_tag,fm_index> (nvbio/fmindex/filter.h:136-231):
+//                                    rank(index, string_set) -> n_hits ; locate(begin, end, hits) ; owns ranges/slots
+//   aln::SimpleGotohScheme, aln::GotohAligner<TYPE,scheme>, aln::make_gotoh_aligner<TYPE>()
+//                                  ~ nvbio/alignment/utils.h:103-123, alignment.h:437-462
+//   aln::BatchedBandedAlignmentScore<BAND, stream, AmdDeviceScheduler>
+//                                  ~ nvbio/alignment/batched.h:298 / batched_banded_inl.h:128-157:
+//                                    min_temp_storage / max_temp_storage / enact(stream, temp_size, temp)
+//   aln::batch_banded_alignment_score<BAND>(aligner, batch, scores, sinks)
+//                                  ~ nvbio/alignment/batched.h:185
+// Errors: the reference surfaces CUDA failures as nvbio::cuda_error exceptions
+// (nvbio/basic/cuda/arch_inl.h:228-237); this shim throws nvbio_amd::error carrying the C-ABI status.
+//
+// The reference's stream concept is a set of device functors (init_context / load_strings /
+// output); a functor cannot cross a C ABI, so the AMD scheduler accepts streams that expose their
+// jobs as flat arrays: `const nvbio_alignment_batch& batch() const`, `int32_t* scores()`,
+// `nvbio_uint2* sinks()`, `aligner()`.  aln::FlatAlignmentStream below is such a stream;
+// INTEGRATION.md shows how nvBowtie's BestScoreStream and sw-benchmark's stream fill one.
+#pragma once
+#include <nvbio_amd.h>
+#include <hip/hip_runtime_api.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <cstdint>
+
+namespace nvbio_amd {
+
+struct error : std::runtime_error
+{
+    nvbio_status status;
+    error(nvbio_status s, const std::string& what) : std::runtime_error( what ), status( s ) {}
+};
+inline void check(nvbio_status s)
+{
+    if (s != NVBIO_OK) throw error( s, std::string( "nvbio_amd: " ) + nvbio_amd_last_error() );
+}
+inline void check_hip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw error( NVBIO_ERR_HIP, std::string( what ) + ": " + hipGetErrorString( e ) );
+}
+
+struct amd_device_tag {};
+
+// minimal owning device array (the role nvbio::vector<device_tag,T> plays in the reference)
+template <typename T>
+class device_vector
+{
+public:
+    device_vector() : m_ptr( nullptr ), m_size( 0 ), m_cap( 0 ) {}
+    explicit device_vector(size_t n) : m_ptr( nullptr ), m_size( 0 ), m_cap( 0 ) { resize( n ); }
+    device_vector(const std::vector<T>& h) : m_ptr( nullptr ), m_size( 0 ), m_cap( 0 ) { assign( h.data(), h.size() ); }
+    device_vector(const device_vector&) = delete;
+    device_vector& operator=(const device_vector&) = delete;
+    ~device_vector() { if (m_ptr) (void)hipFree( m_ptr ); }
+    void resize(size_t n)
+    {
+        if (n > m_cap)
+        {
+            T* p = nullptr;
+            check_hip( hipMalloc( (void**)&p, (n ? n : 1) * sizeof(T) ), "hipMalloc" );
+            if (m_ptr) { if (m_size) check_hip( hipMemcpy( p, m_ptr, m_size * sizeof(T), hipMemcpyDeviceToDevice ), "hipMemcpy" ); (void)hipFree( m_ptr ); }
+            m_ptr = p; m_cap = n;
+        }
+        m_size = n;
+    }
+    void assign(const T* h, size_t n) { resize( n ); if (n) check_hip( hipMemcpy( m_ptr, h, n * sizeof(T), hipMemcpyHostToDevice ), "hipMemcpy H2D" ); }
+    std::vector<T> to_host() const
+    {
+        std::vector<T> h( m_size );
+        if (m_size) check_hip( hipMemcpy( h.data(), m_ptr, m_size * sizeof(T), hipMemcpyDeviceToHost ), "hipMemcpy D2H" );
+        return h;
+    }
+    T*       data()       { return m_ptr; }
+    const T* data() const { return m_ptr; }
+    size_t   size() const { return m_size; }
+private:
+    T* m_ptr; size_t m_size, m_cap;
+};
+
+// a set of strings in device memory (string-set concept flattened; see nvbio_string_set)
+struct string_set
+{
+    nvbio_string_set c;
+    uint32_t size() const { return c.n; }
+    // concatenated set with n+1 offsets (io::SequenceData layout)
+    static string_set concatenated(const void* symbols, uint32_t bits, const uint32_t* offsets, uint32_t n)
+    { string_set s; s.c = { symbols, bits, offsets, 1u, 0u, 0u, n }; return s; }
+    // fixed-length infixes addressed by their start (seeds inside a read stream)
+    static string_set infixes(const void* symbols, uint32_t bits, const uint32_t* starts, uint32_t len, uint32_t n)
+    { string_set s; s.c = { symbols, bits, starts, 0u, len, len, n }; return s; }
+    // n strings of equal length laid out back to back
+    static string_set uniform(const void* symbols, uint32_t bits, uint32_t len, uint32_t n)
+    { string_set s; s.c = { symbols, bits, nullptr, 0u, len, len, n }; return s; }
+};
+
+// FM-index resident in HBM (owner of the C-ABI handle)
+class fm_index
+{
+public:
+    typedef uint32_t    index_type;
+    typedef nvbio_uint2 range_type;
+
+    // wrap arrays already in device memory (reference layout; the caller keeps ownership)
+    fm_index(const nvbio_fm_index_view& view, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
+        : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_create( &view, device, kmer_len, stream, &m_h ) ); }
+    // build on the GPU from a 2-bit packed text in device memory
+    fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
+        : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_build( text2_dev, length, device, kmer_len, 0, stream, &m_h ) ); }
+    fm_index(const fm_index&) = delete;
+    fm_index& operator=(const fm_index&) = delete;
+    ~fm_index() { if (m_h) (void)nvbio_fm_index_destroy( m_h ); }
+
+    index_type length()  const { return view().length; }
+    index_type primary() const { return view().primary; }
+    index_type L2(uint32_t c) const { return view().L2[c]; }
+    index_type count(uint32_t c) const { const nvbio_fm_index_view v = view(); return v.L2[c+1] - v.L2[c]; }
+    nvbio_fm_index_view view() const { nvbio_fm_index_view v; check( nvbio_fm_index_get_view( m_h, &v ) ); return v; }
+    nvbio_fm_index_t handle() const { return m_h; }
+    int device() const { return m_device; }
+private:
+    nvbio_fm_index_t m_h;
+    int              m_device;
+};
+
+// batched forms of the free functions of nvbio/fmindex/fmindex.h:370-557
+inline void match(const fm_index& fmi, const string_set& patterns, nvbio_uint2* ranges_dev, hipStream_t stream = 0)
+{ check( nvbio_fm_match( fmi.handle(), &patterns.c, 0u, ranges_dev, nullptr, stream ) ); }
+inline void match_reverse(const fm_index& fmi, const string_set& patterns, nvbio_uint2* ranges_dev, hipStream_t stream = 0)
+{ check( nvbio_fm_match( fmi.handle(), &patterns.c, NVBIO_FM_SCAN_FORWARD, ranges_dev, nullptr, stream ) ); }
+inline void locate(const fm_index& fmi, const uint32_t* rows_dev, uint32_t n, uint32_t* pos_dev, hipStream_t stream = 0)
+{ check( nvbio_fm_locate( fmi.handle(), rows_dev, n, pos_dev, stream ) ); }
+inline void locate_ssa_iterator(const fm_index& fmi, const uint32_t* rows_dev, uint32_t n, nvbio_uint2* jt_dev, hipStream_t stream = 0)
+{ check( nvbio_fm_locate_init( fmi.handle(), rows_dev, n, jt_dev, stream ) ); }
+inline void lookup_ssa_iterator(const fm_index& fmi, const nvbio_uint2* jt_dev, uint32_t n, uint32_t* pos_dev, hipStream_t stream = 0)
+{ check( nvbio_fm_locate_lookup( fmi.handle(), jt_dev, n, pos_dev, stream ) ); }
+
+template <typename system_tag> class FMIndexFilter;
+
+template <>
+class FMIndexFilter<amd_device_tag>
+{
+public:
+    typedef fm_index    fm_index_type;
+    typedef nvbio_uint2 range_type;
+    typedef nvbio_uint2 hit_type;       // (text_pos, query_id)
+
+    FMIndexFilter() : m_index( nullptr ), m_n_queries( 0 ), m_n_occurrences( 0 ) {}
+
+    // enact the filter; returns the total number of hits (filter_inl.h:261-293)
+    uint64_t rank(const fm_index& index, const string_set& set, hipStream_t stream = 0)
+    {
+        m_index = &index; m_n_queries = set.size();
+        m_ranges.resize( m_n_queries ); m_slots.resize( m_n_queries );
+        check( nvbio_fm_filter_rank( index.handle(), &set.c, 0u, m_ranges.data(), m_slots.data(), &m_n_occurrences, stream ) );
+        return m_n_occurrences;
+    }
+    // enumerate the hits [begin,end) into caller-owned device memory (filter_inl.h:299-393)
+    void locate(uint64_t begin, uint64_t end, hit_type* hits_dev, hipStream_t stream = 0)
+    {
+        check( nvbio_fm_filter_locate( m_index->handle(), m_ranges.data(), m_slots.data(), m_n_queries, begin, end, hits_dev, stream ) );
+    }
+    uint32_t n_queries() const { return m_n_queries; }
+    uint64_t n_hits()    const { return m_n_occurrences; }
+    const range_type* ranges() const { return m_ranges.data(); }
+    const uint64_t*   slots()  const { return m_slots.data(); }
+private:
+    const fm_index*            m_index;
+    uint32_t                   m_n_queries;
+    uint64_t                   m_n_occurrences;
+    device_vector<range_type>  m_ranges;
+    device_vector<uint64_t>    m_slots;
+};
+
+namespace aln {
+
+enum AlignmentType { GLOBAL = NVBIO_GLOBAL, LOCAL = NVBIO_LOCAL, SEMI_GLOBAL = NVBIO_SEMI_GLOBAL };
+
+struct SimpleGotohScheme
+{
+    SimpleGotohScheme() {}
+    SimpleGotohScheme(int32_t match, int32_t mm, int32_t gap_open, int32_t gap_ext)
+        : m_match( match ), m_mismatch( mm ), m_gap_open( gap_open ), m_gap_ext( gap_ext ) {}
+    nvbio_gotoh_scheme flat() const { return { m_match, -m_mismatch, -m_mismatch, m_gap_open, m_gap_ext, m_gap_open, m_gap_ext }; }
+    int32_t m_match, m_mismatch, m_gap_open, m_gap_ext;
+};
+// nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as data (scoring.h:206-330)
+struct QualityGotohScheme
+{
+    int32_t match, mm_min, mm_max, read_gap_const, read_gap_coeff, ref_gap_const, ref_gap_coeff;
+    nvbio_gotoh_scheme flat() const
+    { return { match, mm_min, mm_max, -read_gap_const - read_gap_coeff, -read_gap_coeff, -ref_gap_const - ref_gap_coeff, -ref_gap_coeff }; }
+};
+
+template <AlignmentType T, typename scheme_type>
+struct GotohAligner
+{
+    static const AlignmentType TYPE = T;
+    GotohAligner() {}
+    GotohAligner(const scheme_type& s) : scheme( s ) {}
+    scheme_type scheme;
+};
+template <AlignmentType T, typename scheme_type>
+GotohAligner<T,scheme_type> make_gotoh_aligner(const scheme_type& s) { return GotohAligner<T,scheme_type>( s ); }
+
+struct AmdDeviceScheduler {};
+
+// a stream of alignment jobs in flat form (see nvbio_alignment_batch)
+template <typename aligner_t>
+struct FlatAlignmentStream
+{
+    typedef aligner_t aligner_type;
+    FlatAlignmentStream(const aligner_t& a, const nvbio_alignment_batch& b, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                        uint32_t max_pattern_len, uint32_t max_text_len)
+        : m_aligner( a ), m_batch( b ), m_scores( scores_dev ), m_sinks( sinks_dev ), m_max_p( max_pattern_len ), m_max_t( max_text_len ) {}
+    const aligner_t& aligner() const { return m_aligner; }
+    uint32_t size() const { return m_batch.n; }
+    uint32_t max_pattern_length() const { return m_max_p; }
+    uint32_t max_text_length()    const { return m_max_t; }
+    const nvbio_alignment_batch& batch() const { return m_batch; }
+    int32_t*     scores() const { return m_scores; }
+    nvbio_uint2* sinks()  const { return m_sinks; }
+    aligner_t m_aligner; nvbio_alignment_batch m_batch; int32_t* m_scores; nvbio_uint2* m_sinks; uint32_t m_max_p, m_max_t;
+};
+
+template <uint32_t BAND_LEN, typename stream_type, typename scheduler = AmdDeviceScheduler>
+struct BatchedBandedAlignmentScore
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    // no temporary storage, as the reference's thread schedulers (batched_banded_inl.h:100-104,138-142)
+    static uint64_t min_temp_storage(uint32_t, uint32_t, uint32_t) { return 0u; }
+    static uint64_t max_temp_storage(uint32_t, uint32_t, uint32_t) { return 0u; }
+    void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0)
+    {
+        (void)temp_size; (void)temp;
+        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
+        check( nvbio_banded_gotoh_score( device, BAND_LEN, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(),
+                                         stream.scores(), stream.sinks(), s ) );
+    }
+};
+
+template <typename stream_type, typename scheduler = AmdDeviceScheduler>
+struct BatchedAlignmentScore
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64_t min_temp_storage(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t stream_size)
+    {
+        uint64_t bytes = 0; nvbio_alignment_batch b = {}; b.n = stream_size;
+        check( nvbio_full_gotoh_temp_bytes( &b, max_pattern_len, max_text_len, 1, &bytes ) );
+        return bytes;
+    }
+    static uint64_t max_temp_storage(uint32_t p, uint32_t t, uint32_t n) { return min_temp_storage( p, t, n ); }
+    void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0,
+               bool text_blocking = true, const int32_t* min_scores_dev = nullptr)
+    {
+        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
+        check( nvbio_full_gotoh_score( device, (nvbio_alignment_type)aligner_type::TYPE, text_blocking ? 1 : 0, &sc, &stream.batch(),
+                                       stream.max_pattern_length(), stream.max_text_length(), min_scores_dev,
+                                       stream.scores(), stream.sinks(), temp, temp_size, s ) );
+    }
+};
+
+// convenience function (nvbio/alignment/batched.h:185): banded scores of a flat batch
+template <uint32_t BAND_LEN, typename aligner_type>
+void batch_banded_alignment_score(const aligner_type& aligner, const nvbio_alignment_batch& batch,
+                                  int32_t* scores_dev, nvbio_uint2* sinks_dev, int device = 0, hipStream_t s = 0)
+{
+    typedef FlatAlignmentStream<aligner_type> stream_type;
+    BatchedBandedAlignmentScore<BAND_LEN,stream_type> batched;
+    batched.enact( stream_type( aligner, batch, scores_dev, sinks_dev, 0, 0 ), 0u, nullptr, device, s );
+}
+
+} // namespace aln
+} // namespace nvbio_amd

@@ -1,0 +1,101 @@
+// tests/cpp/test_host_shim.cpp -- GPU parity test of the C++ host mirror (nvbio_amd.hpp), written
+// the way the reference's own tests are (self-checking, exit(1) on mismatch:
+// nvbio-test/fmindex_test.cu:575-657, alignment_test.cu:709-786), with the oracle as the checker.
+#include <nvbio_amd/nvbio_amd.hpp>
+#include "../../oracle/nvbio_oracle.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+using namespace nvbio_amd;
+
+#define REQUIRE(cond) do { if (!(cond)) { fprintf( stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond ); exit( 1 ); } } while (0)
+
+int main()
+{
+    std::mt19937 rng( 5 );
+    const uint32_t n = 300000;
+    std::vector<uint8_t> text( n );
+    for (auto& c : text) c = rng() & 3;
+
+    // oracle index (the checker)
+    std::vector<uint32_t> sa( n + 1 ), bwt_occ( 2 * orc_bwt_words( n ) ), ssa( (n + 16) / 16 );
+    orc_suffix_sort( text.data(), n, sa.data() );
+    orc_fm_index oidx; memset( &oidx, 0, sizeof(oidx) );
+    oidx.length = n; oidx.primary = orc_fm_build( text.data(), n, sa.data(), bwt_occ.data(), ssa.data(), oidx.L2 );
+    oidx.bwt_occ = bwt_occ.data(); oidx.ssa = ssa.data();
+
+    // device index built on the GPU through the shim
+    std::vector<uint32_t> text2( (n + 15) / 16 + 8, 0u );
+    orc_pack2( text.data(), n, text2.data() );
+    device_vector<uint32_t> d_text2( text2 );
+    fm_index fmi( d_text2.data(), n, 0, 8 );
+    REQUIRE( fmi.length() == n && fmi.primary() == oidx.primary );
+    for (int c = 0; c < 5; ++c) REQUIRE( fmi.L2( c ) == oidx.L2[c] );
+
+    // FMIndexFilter: rank + locate, against the oracle's host filter
+    const uint32_t Q = 5000, L = 20;
+    std::vector<uint8_t> qsyms( Q * L );
+    for (uint32_t q = 0; q < Q; ++q)
+    {
+        const uint32_t p = rng() % (n - L);
+        for (uint32_t k = 0; k < L; ++k) qsyms[q*L + k] = (q % 3) ? text[p + k] : (rng() & 3);
+    }
+    std::vector<uint32_t> offs( Q + 1 ); for (uint32_t q = 0; q <= Q; ++q) offs[q] = q * L;
+    std::vector<uint32_t> want_ranges( 2 * Q ); std::vector<uint64_t> want_slots( Q );
+    const uint64_t want_total = orc_filter_rank( &oidx, qsyms.data(), offs.data(), Q, want_ranges.data(), want_slots.data() );
+
+    device_vector<uint8_t> d_q( qsyms );
+    FMIndexFilter<amd_device_tag> filter;
+    const uint64_t total = filter.rank( fmi, string_set::uniform( d_q.data(), 8, L, Q ) );
+    REQUIRE( total == want_total && filter.n_hits() == total );
+    device_vector<nvbio_uint2> d_hits( total );
+    filter.locate( 0, total, d_hits.data() );
+    check_hip( hipDeviceSynchronize(), "sync" );
+    std::vector<nvbio_uint2> hits = d_hits.to_host();
+    std::vector<uint32_t> want_hits( 2 * total );
+    orc_filter_locate( &oidx, want_ranges.data(), want_slots.data(), Q, 0, total, want_hits.data() );
+    for (uint64_t h = 0; h < total; ++h) REQUIRE( hits[h].x == want_hits[2*h] && hits[h].y == want_hits[2*h+1] );
+
+    // banded Gotoh through BatchedBandedAlignmentScore, SimpleGotohScheme, all three types
+    const uint32_t J = 3000, M = 100;
+    std::vector<uint8_t> pats( J * M ); std::vector<uint32_t> poffs( J + 1 ), wb( J ), we( J );
+    for (uint32_t j = 0; j < J; ++j)
+    {
+        const uint32_t p = 15 + rng() % (n - M - 64);
+        for (uint32_t k = 0; k < M; ++k) pats[j*M + k] = (rng() % 50) ? text[p + k] : (rng() & 3);
+        poffs[j] = j * M; wb[j] = p - 15; we[j] = p - 15 + M + 31;
+    }
+    poffs[J] = J * M;
+    device_vector<uint8_t> d_p( pats ), d_t( text );
+    device_vector<uint32_t> d_po( poffs ), d_wb( wb ), d_we( we );
+    device_vector<int32_t> d_scores( J ); device_vector<nvbio_uint2> d_sinks( J );
+    nvbio_alignment_batch batch; memset( &batch, 0, sizeof(batch) );
+    batch.reads_dev = d_p.data(); batch.read_bits = 8; batch.read_offsets_dev = d_po.data();
+    batch.text_dev = d_t.data(); batch.text_bits = 8; batch.win_begin_dev = d_wb.data(); batch.win_end_dev = d_we.data(); batch.n = J;
+    const aln::SimpleGotohScheme scheme( 2, -1, -2, -1 );
+    const nvbio_gotoh_scheme fs = scheme.flat();
+    orc_gotoh_scheme os = { fs.match, fs.mm_min, fs.mm_max, fs.pat_gap_open, fs.pat_gap_ext, fs.txt_gap_open, fs.txt_gap_ext };
+    for (int type = 0; type < 3; ++type)
+    {
+        if (type == 0) aln::batch_banded_alignment_score<31>( aln::make_gotoh_aligner<aln::GLOBAL>( scheme ), batch, d_scores.data(), d_sinks.data() );
+        if (type == 1) aln::batch_banded_alignment_score<31>( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, d_scores.data(), d_sinks.data() );
+        if (type == 2) aln::batch_banded_alignment_score<31>( aln::make_gotoh_aligner<aln::SEMI_GLOBAL>( scheme ), batch, d_scores.data(), d_sinks.data() );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<int32_t> sc = d_scores.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host();
+        for (uint32_t j = 0; j < J; ++j)
+        {
+            int32_t ws; uint32_t wk[2];
+            orc_banded_gotoh( 31, type, &os, &pats[j*M], nullptr, M, &text[wb[j]], we[j] - wb[j], &ws, wk );
+            REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
+        }
+    }
+    // error behaviour: an unsupported band throws with the C-ABI status
+    bool threw = false;
+    try { aln::batch_banded_alignment_score<9>( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, d_scores.data(), d_sinks.data() ); }
+    catch (const error& e) { threw = (e.status == NVBIO_ERR_UNSUPPORTED); }
+    REQUIRE( threw );
+    printf( "host shim ok: %llu filter hits, %u x 3 banded alignments equal to the oracle\n", (unsigned long long)total, J );
+    return 0;
+}
