@@ -17,38 +17,9 @@
 // max per cell and one compare per row, which reproduces BestSink's row-major "last maximum
 // wins" rule exactly.  Reads and windows are consumed straight from the packed HBM streams
 // (one dword per 8 read symbols / 16 text symbols).
-#include "common.h"
+#include "gotoh_common.h"
 
 namespace nvbio_amd {
-
-struct BatchDev
-{
-    const void*     reads;
-    const uint32_t* read_offsets;
-    const uint8_t*  quals;
-    const uint32_t* read_id;
-    const uint8_t*  flags;
-    const void*     text;
-    const uint32_t* win_begin;
-    const uint32_t* win_end;
-    uint32_t        n;
-};
-
-struct SchemeDev
-{
-    int32_t match, mm_min, mm_max, pat_go, pat_ge, txt_go, txt_ge;
-};
-
-// QualCost (nvBowtie/bowtie2/cuda/scoring.h:84-88) negated (:280-281); IEEE float ops, no contraction
-__device__ __forceinline__ int32_t mismatch_score(const SchemeDev& sc, const uint32_t q)
-{
-    const int   qi   = (int)q < 40 ? (int)q : 40;
-    const float frac = (float)qi / 40.0f;
-    return -( sc.mm_min + (int)( frac * (float)(sc.mm_max - sc.mm_min) ) );
-}
-
-__device__ __forceinline__ int32_t max2(int32_t a, int32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ int32_t max3(int32_t a, int32_t b, int32_t c) { return max2( max2( a, b ), c ); }
 
 template <int BAND, int TYPE, int RBITS, int TBITS>
 __global__ void __launch_bounds__(128)
