@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=12, help="k of the k-mer SA-range table (0 disables)")
+    ap.add_argument("--sa-int", type=int, default=16, help="SA sampling interval of the index built for the run")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +149,7 @@ def main():
     genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
     torch.cuda.synchronize()
     t1 = time.time()
-    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer)
+    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int)
     torch.cuda.synchronize()
     t2 = time.time()
     log("reference %d symbols generated in %.2fs, index built on the GPU in %.2fs (k-mer table k=%d, %.2f GB owned)"
@@ -215,7 +216,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer:
+            if tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer and tj.get("sa_int", 16) == args.sa_int:
                 traffic = tj.get("match_hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -233,7 +234,8 @@ def main():
         "config": {"workload": "nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150) else "custom",
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
-                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "parallelism": "read-shard x%d" % world},
+                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "sa_int": args.sa_int,
+                   "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
         "roofline": {"kernel": "fm_match_kernel<4,false> (seed pass, one strand of %d seeds per launch)" % n_seeds,
@@ -253,7 +255,10 @@ def main():
         O = oracle.Oracle()
         b_occ, ssa = fmi.arrays()
         v = fmi.view()
-        hidx = oracle.HostIndex(n, v.primary, [v.L2[i] for i in range(5)], amd.u32(b_occ), amd.u32(ssa))
+        # the oracle restates the reference's K = 16 sampled SA: take every (16/sa_int)-th entry
+        assert 16 % args.sa_int == 0, "the CPU baseline needs sa_int <= 16"
+        hidx = oracle.HostIndex(n, v.primary, [v.L2[i] for i in range(5)], amd.u32(b_occ),
+                                np.ascontiguousarray(amd.u32(ssa)[::16 // args.sa_int]))
         del b_occ, ssa
         g_host = amd.u32(genome)
         probe = reads_sym[:20000].cpu().numpy()

@@ -62,7 +62,10 @@ typedef struct { uint32_t x, y; } nvbio_uint2;
  * (nvbio/io/fmindex/fmindex.h:75-177, :294-295):
  *   bwt_occ : 32-byte records; record k = 4 words of 2-bit big-endian BWT symbols [64k,64k+64)
  *             followed by 4 words occ{A,C,G,T} = counts in BWT[0,64k)   (fmindex_impl.cu:300-313)
- *   ssa     : ssa[j] = SA[16 j], ssa[0] = 0xFFFFFFFF                    (ssa_inl.h:254-301,477-495)
+ *   ssa     : ssa[j] = SA[sa_int j], ssa[0] = 0xFFFFFFFF                (ssa_inl.h:254-301,477-495)
+ *             sa_int = 16 is the reference's production layout (SA_INT, io/fmindex/fmindex.h:86);
+ *             indices built here may sample more densely (a power of two down to 1 = the full
+ *             suffix array, 12 GB for 3 Gbp): positions returned by locate() do not depend on it
  *   L2      : L2[c] = number of symbols < c, L2[4] = length             (fmindex.h:335-336)       */
 typedef struct
 {
@@ -72,7 +75,8 @@ typedef struct
     const uint32_t* bwt_occ_dev;     /* device pointer, 32-byte aligned                             */
     uint64_t        bwt_occ_words;   /* = 2 * ceil4(ceil(n/16))                                     */
     const uint32_t* ssa_dev;         /* device pointer, may be NULL (match-only index)              */
-    uint64_t        ssa_words;       /* = (n+16)/16                                                 */
+    uint64_t        ssa_words;       /* = n/sa_int + 1                                              */
+    uint32_t        sa_int;          /* SA sampling interval: power of two in [1,64]; 0 means 16    */
 } nvbio_fm_index_view;
 
 typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
@@ -81,7 +85,8 @@ typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
  * reference's storage-free views).  kmer_len > 0 additionally builds, on the GPU, a table with
  * the SA range of every kmer_len-mer (4^kmer_len x 8 bytes, owned by the handle) which match()
  * uses to replace its first kmer_len backward-search steps with one lookup; results are
- * identical with and without it.  kmer_len = 0 disables it; values up to 14 are accepted.
+ * identical with and without it.  kmer_len = 0 disables it; values up to 16 are accepted
+ * (k = 12: 128 MiB, k = 14: 2 GiB, k = 16: 32 GiB -- sized for 288 GB of HBM).
  * Replaces: constructing nvbio::fm_index / io::FMIndexDataDevice (nvbio/io/fmindex/fmindex_impl.cu:740-816). */
 nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len,
                                    void* stream, nvbio_fm_index_t* out);
@@ -91,10 +96,18 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
  * interleave, SSA.  All arrays are owned by the handle.  Replaces, for synthetic / benchmark
  * references, the offline nvBWT + FMIndexDataHost::load path (nvBWT/nvBWT.cu,
  * nvbio/io/fmindex/fmindex_impl.cu:111-331) and SSA_index_multiple's builder (ssa_inl.h:273-470).
- * Texts with repeats longer than max_lcp symbols (default 0 -> 4096) are rejected with
- * NVBIO_ERR_UNSUPPORTED rather than sorted slowly. */
-nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device, uint32_t kmer_len,
-                                  uint32_t max_lcp, void* stream, nvbio_fm_index_t* out);
+ * Texts with repeats longer than options->max_lcp symbols are rejected with NVBIO_ERR_UNSUPPORTED
+ * rather than sorted slowly. */
+typedef struct
+{
+    uint32_t kmer_len;   /* k of the k-mer SA-range table, 0..16 (0 = none)                                  */
+    uint32_t sa_int;     /* SA sampling interval, power of two in [1,64]; 0 = 16 (the reference's SA_INT)     */
+    uint32_t max_lcp;    /* give up on texts with repeats longer than this many symbols; 0 = 4096            */
+} nvbio_fm_build_options;
+
+nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
+                                  const nvbio_fm_build_options* options /* NULL = defaults */,
+                                  void* stream, nvbio_fm_index_t* out);
 
 nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index);
 nvbio_status nvbio_fm_index_get_view(nvbio_fm_index_t index, nvbio_fm_index_view* view);
@@ -152,7 +165,8 @@ nvbio_status nvbio_fm_locate(nvbio_fm_index_t index, const uint32_t* rows_dev, u
                              uint32_t* pos_dev, void* stream);
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)
- * pos_dev[i] = lookup_ssa_iterator(jt[i]) = ssa[j/16] + t          (fmindex_inl.h:445-460)      */
+ * pos_dev[i] = lookup_ssa_iterator(jt[i]) = ssa[j/sa_int] + t      (fmindex_inl.h:445-460)
+ * (the intermediate pair equals the reference's only for sa_int = 16; positions always do)      */
 nvbio_status nvbio_fm_locate_init(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
                                   nvbio_uint2* jt_dev, void* stream);
 nvbio_status nvbio_fm_locate_lookup(nvbio_fm_index_t index, const nvbio_uint2* jt_dev, uint32_t n,

@@ -43,7 +43,11 @@ class NvbioError(RuntimeError):
 class _View(ctypes.Structure):
     _fields_ = [("length", ctypes.c_uint32), ("primary", ctypes.c_uint32), ("L2", ctypes.c_uint32 * 5),
                 ("bwt_occ_dev", ctypes.c_void_p), ("bwt_occ_words", ctypes.c_uint64),
-                ("ssa_dev", ctypes.c_void_p), ("ssa_words", ctypes.c_uint64)]
+                ("ssa_dev", ctypes.c_void_p), ("ssa_words", ctypes.c_uint64), ("sa_int", ctypes.c_uint32)]
+
+
+class _BuildOptions(ctypes.Structure):
+    _fields_ = [("kmer_len", ctypes.c_uint32), ("sa_int", ctypes.c_uint32), ("max_lcp", ctypes.c_uint32)]
 
 
 class _StringSet(ctypes.Structure):
@@ -164,7 +168,7 @@ class FMIndex:
         return d.index if d.index is not None else 0
 
     @classmethod
-    def from_arrays(cls, length, primary, L2, bwt_occ, ssa, kmer_len=0, device="cuda:0"):
+    def from_arrays(cls, length, primary, L2, bwt_occ, ssa, kmer_len=0, sa_int=16, device="cuda:0"):
         """wrap index arrays (numpy or tensors); replaces FMIndexDataDevice (fmindex_impl.cu:740-816)"""
         torch = _torch()
         b = _dev_tensor(bwt_occ, torch.int32, device)
@@ -175,20 +179,21 @@ class FMIndex:
             v.L2[i] = int(L2[i])
         v.bwt_occ_dev, v.bwt_occ_words = b.data_ptr(), b.numel()
         v.ssa_dev, v.ssa_words = (s.data_ptr(), s.numel()) if s is not None else (None, 0)
+        v.sa_int = sa_int
         h = ctypes.c_void_p()
         _check(lib().nvbio_fm_index_create(ctypes.byref(v), cls._dev_index(device), ctypes.c_uint32(kmer_len),
                                            _stream_ptr(device), ctypes.byref(h)))
         return cls(h, device, keep=(b, s))
 
     @classmethod
-    def build(cls, text2, length, kmer_len=0, max_lcp=0, device="cuda:0"):
+    def build(cls, text2, length, kmer_len=0, max_lcp=0, sa_int=16, device="cuda:0"):
         """build the index on the GPU from a 2-bit packed text (nvbio_fm_index_build)"""
         torch = _torch()
         t = _dev_tensor(text2, torch.int32, device)
         h = ctypes.c_void_p()
+        opts = _BuildOptions(kmer_len, sa_int, max_lcp)
         _check(lib().nvbio_fm_index_build(_ptr(t), ctypes.c_uint32(length), cls._dev_index(device),
-                                          ctypes.c_uint32(kmer_len), ctypes.c_uint32(max_lcp), _stream_ptr(device),
-                                          ctypes.byref(h)))
+                                          ctypes.byref(opts), _stream_ptr(device), ctypes.byref(h)))
         return cls(h, device, keep=(t,))
 
     def close(self):

@@ -222,10 +222,10 @@ write_occ_kernel(const uint4* __restrict__ occ, const uint32_t n_blocks, uint32_
         ((uint4*)bwt_occ)[2u * b + 1u] = occ[b];
 }
 __global__ void __launch_bounds__(256)
-ssa_kernel(const uint32_t* __restrict__ sa, const uint32_t n, const uint32_t n_ssa, uint32_t* __restrict__ ssa)
+ssa_kernel(const uint32_t* __restrict__ sa, const uint32_t sa_int, const uint64_t n_ssa, uint32_t* __restrict__ ssa)
 {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_ssa; j += gridDim.x * blockDim.x)
-        ssa[j] = (j == 0) ? 0xFFFFFFFFu : sa[(size_t)16u * j - 1u];     // row 16j of the full SA
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_ssa; j += (uint64_t)gridDim.x * blockDim.x)
+        ssa[j] = (j == 0) ? 0xFFFFFFFFu : sa[(size_t)sa_int * j - 1u];  // row sa_int*j of the full SA
 }
 
 // ---- small RAII for device scratch ----------------------------------------------------------
@@ -309,7 +309,7 @@ static nvbio_status sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* 
 }
 
 static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, const int device, const uint32_t kmer_len,
-                               uint32_t max_lcp, hipStream_t s, nvbio_fm_index_t* out)
+                               const uint32_t sa_int, uint32_t max_lcp, hipStream_t s, nvbio_fm_index_t* out)
 {
     Scratch scratch;
     if (max_lcp == 0) max_lcp = 4096;
@@ -449,7 +449,7 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     // ---- 3. BWT, occ, L2, SSA ---------------------------------------------------------------
     const uint32_t words    = ((t.n_words + 3u) & ~3u);          // padded to whole 64-symbol blocks
     const uint32_t n_blocks = words / 4u;
-    const uint32_t n_ssa    = (uint32_t)(((uint64_t)n + 16u) / 16u);
+    const uint64_t n_ssa    = (uint64_t)n / sa_int + 1u;
 
     NVB_ALLOC( d_primary, uint32_t, 1 );
     NVB_HIP( hipMemsetAsync( d_primary, 0, sizeof(uint32_t), s ) );
@@ -458,7 +458,7 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     NVB_ALLOC( bwt_occ, uint32_t, (size_t)words * 2u );
     NVB_ALLOC( ssa,     uint32_t, n_ssa );
     hipLaunchKernelGGL( bwt_words_kernel, dim3( grid_for( words ) ), dim3(256), 0, s, t, (const uint32_t*)sa, (const uint32_t*)d_primary, words, bwt_occ, (uint4*)nullptr );
-    hipLaunchKernelGGL( ssa_kernel, dim3( grid_for( n_ssa ) ), dim3(256), 0, s, (const uint32_t*)sa, n, n_ssa, ssa );
+    hipLaunchKernelGGL( ssa_kernel, dim3( grid_for( n_ssa ) ), dim3(256), 0, s, (const uint32_t*)sa, sa_int, n_ssa, ssa );
     NVB_HIP( hipGetLastError() );
     NVB_HIP( hipStreamSynchronize( s ) );
     scratch.release( sa );
@@ -487,7 +487,7 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     view.primary = primary;
     view.L2[0] = 0; view.L2[1] = totals.x; view.L2[2] = view.L2[1] + totals.y; view.L2[3] = view.L2[2] + totals.z; view.L2[4] = view.L2[3] + totals.w;
     view.bwt_occ_dev = bwt_occ; view.bwt_occ_words = (uint64_t)words * 2u;
-    view.ssa_dev = ssa;         view.ssa_words = n_ssa;
+    view.ssa_dev = ssa;         view.ssa_words = n_ssa;   view.sa_int = sa_int;
     if (view.L2[4] != n || primary == 0)
     {
         set_error( "index build: inconsistent result (sum of counts %u, n %u, primary %u)", view.L2[4], n, primary );
@@ -502,13 +502,17 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
 
 using namespace nvbio_amd;
 
-extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device, uint32_t kmer_len,
-                                             uint32_t max_lcp, void* stream, nvbio_fm_index_t* out)
+extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
+                                             const nvbio_fm_build_options* options, void* stream, nvbio_fm_index_t* out)
 {
     NVB_REQUIRE( text2_dev && out, "text2_dev/out is NULL" );
     NVB_REQUIRE( length > 0, "empty text" );
     NVB_REQUIRE( length <= 0xFFFFFFFFu - 8192u, "text too long for 32-bit coordinates" );
-    NVB_REQUIRE( kmer_len <= 14, "kmer_len must be <= 14" );
+    const uint32_t kmer_len = options ? options->kmer_len : 0u;
+    const uint32_t sa_int   = (options && options->sa_int) ? options->sa_int : 16u;
+    const uint32_t max_lcp  = options ? options->max_lcp : 0u;
+    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
+    NVB_REQUIRE( sa_int <= 64 && (sa_int & (sa_int - 1u)) == 0, "sa_int must be a power of two in [1,64]" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    return build_impl( text2_dev, length, device, kmer_len, max_lcp, (hipStream_t)stream, out );
+    return build_impl( text2_dev, length, device, kmer_len, sa_int, max_lcp, (hipStream_t)stream, out );
 }

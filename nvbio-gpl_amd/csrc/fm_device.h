@@ -22,7 +22,8 @@ struct DevIndex
     uint32_t        primary;
     uint32_t        L2_0, L2_1, L2_2, L2_3, L2_4;
     const uint4*    rec;      // record k: rec[2k] = 64 BWT symbols, rec[2k+1] = occ{A,C,G,T}
-    const uint32_t* ssa;      // ssa[j] = SA[16 j], ssa[0] = 0xFFFFFFFF
+    const uint32_t* ssa;      // ssa[j] = SA[j << sa_log], ssa[0] = 0xFFFFFFFF
+    uint32_t        sa_log;   // log2 of the SA sampling interval (4 in the reference's layout)
     const uint2*    ktab;     // optional: SA range of every kmer-mer (in scan order), or NULL
     uint32_t        kmer;
 };

@@ -18,6 +18,7 @@
 #include "fm_device.h"
 #include <hipcub/hipcub.hpp>
 #include <new>
+#include <stdlib.h>
 
 namespace nvbio_amd {
 
@@ -40,6 +41,7 @@ struct FMIndexImpl
         d.L2_0 = view.L2[0]; d.L2_1 = view.L2[1]; d.L2_2 = view.L2[2]; d.L2_3 = view.L2[3]; d.L2_4 = view.L2[4];
         d.rec  = (const uint4*)view.bwt_occ_dev;
         d.ssa  = view.ssa_dev;
+        d.sa_log = 0; while ((1u << d.sa_log) < (view.sa_int ? view.sa_int : 16u)) ++d.sa_log;
         d.ktab = ktab; d.kmer = kmer;
         return d;
     }
@@ -164,24 +166,41 @@ fm_rank4_kernel(const DevIndex f, const uint32_t* __restrict__ rows, const uint3
 // ---------------------------------------------------------------------------------------------
 // locate
 // ---------------------------------------------------------------------------------------------
+// The LF walk takes 0..sa_int-1 dependent gathers per row, so a wave that waits for its slowest
+// lane keeps most lanes idle.  Both locate kernels therefore REFILL lanes: a lane that reaches a
+// sampled row writes its result and immediately starts its next row while its neighbours keep
+// walking, so every iteration of the wave-uniform loop issues (nearly) 64 gathers.
+//
 // MODE 0: pos = locate(row); MODE 1: (j,t) = locate_ssa_iterator(row)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 fm_locate_kernel(const DevIndex f, const uint32_t* rows, const uint32_t n, uint32_t* pos, uint2* jt)
 {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    const uint32_t mask   = (1u << f.sa_log) - 1u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool     have = i < n;
+    uint32_t j = have ? rows[i] : 0u, t = 0;
+    while (__any( have ))
     {
-        uint32_t j = rows[i], t = 0;
-        while (j & 15u) { j = lf_step( f, j ); ++t; }           // SSA_index_multiple_context<16>::has (ssa_inl.h:491-495)
-        if (MODE == 0) pos[i] = f.ssa[j >> 4] + t;
-        else           jt[i]  = make_uint2( j, t );
+        if (have)
+        {
+            if ((j & mask) == 0)                                 // SSA_index_multiple_context<K>::has (ssa_inl.h:491-495)
+            {
+                if (MODE == 0) pos[i] = f.ssa[j >> f.sa_log] + t;
+                else           jt[i]  = make_uint2( j, t );
+                i += stride; have = i < n;
+                if (have) { j = rows[i]; t = 0; }
+            }
+            else { j = lf_step( f, j ); ++t; }
+        }
     }
 }
 __global__ void __launch_bounds__(256)
 fm_lookup_kernel(const DevIndex f, const uint2* __restrict__ jt, const uint32_t n, uint32_t* __restrict__ pos)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        pos[i] = f.ssa[jt[i].x >> 4] + jt[i].y;
+        pos[i] = f.ssa[jt[i].x >> f.sa_log] + jt[i].y;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,24 +211,61 @@ struct RangeSize
     __host__ __device__ __forceinline__ uint64_t operator()(const uint2 r) const { return (uint64_t)(uint32_t)(1u + r.y - r.x); }
 };
 
-// hits[h-begin] = (locate(range.x + local), query) for the global hit index h (filter_inl.h:66-118,359-392)
+// hits[h-begin] = (locate(range.x + local), query) for the global hit index h (filter_inl.h:66-118,359-392).
+// A workgroup owns a tile of consecutive hit indices; their queries form a contiguous slice of
+// `slots`, found once per tile (two binary searches by two lanes), so that each hit's own
+// upper_bound runs over a few cached entries instead of log2(n_queries) HBM round trips.
+constexpr uint32_t FILTER_TILE = 256u * 8u;
+
+__device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t* __restrict__ a, uint32_t lo, uint32_t hi, const uint64_t v)
+{
+    while (lo < hi)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] <= v) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(256)
 fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint64_t* __restrict__ slots, const uint32_t n_queries,
                         const uint64_t begin, const uint64_t end, uint2* __restrict__ hits)
 {
-    for (uint64_t h = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < end; h += (uint64_t)gridDim.x * blockDim.x)
+    __shared__ uint32_t s_q[2];
+    const uint32_t mask    = (1u << f.sa_log) - 1u;
+    const uint64_t n_tiles = (end - begin + FILTER_TILE - 1u) / FILTER_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
     {
-        uint32_t lo = 0, hi = n_queries;                        // upper_bound( h, slots )
-        while (lo < hi)
+        const uint64_t t_first = begin + tile * FILTER_TILE;
+        const uint64_t t_end   = (t_first + FILTER_TILE < end) ? t_first + FILTER_TILE : end;
+        __syncthreads();
+        if (threadIdx.x < 2)
+            s_q[threadIdx.x] = upper_bound_u64( slots, 0u, n_queries, threadIdx.x ? t_end - 1u : t_first );
+        __syncthreads();
+        const uint32_t q_lo = s_q[0], q_hi = s_q[1] + 1u < n_queries ? s_q[1] + 1u : n_queries;
+
+        uint64_t h    = t_first + threadIdx.x;
+        bool     have = h < t_end;
+        uint32_t slot = 0, j = 0, t = 0;
+        auto start = [&]() {
+            slot = upper_bound_u64( slots, q_lo, q_hi, h );
+            const uint64_t base = slot ? slots[slot - 1u] : 0ull;
+            j = ranges[slot].x + (uint32_t)(h - base); t = 0;
+        };
+        if (have) start();
+        while (__any( have ))
         {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (slots[mid] <= h) lo = mid + 1u; else hi = mid;
+            if (have)
+            {
+                if ((j & mask) == 0)
+                {
+                    hits[h - begin] = make_uint2( f.ssa[j >> f.sa_log] + t, slot );
+                    h += 256u; have = h < t_end;
+                    if (have) start();
+                }
+                else { j = lf_step( f, j ); ++t; }
+            }
         }
-        const uint32_t slot  = lo;
-        const uint64_t base  = slot ? slots[slot - 1u] : 0ull;
-        uint32_t j = ranges[slot].x + (uint32_t)(h - base), t = 0;
-        while (j & 15u) { j = lf_step( f, j ); ++t; }
-        hits[h - begin] = make_uint2( f.ssa[j >> 4] + t, slot );
     }
 }
 
@@ -260,6 +316,7 @@ nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_
     FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
     idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0;
+    if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     const nvbio_status st = build_kmer_table( idx, kmer_len, stream );
     if (st != NVBIO_OK)
@@ -283,12 +340,14 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
     NVB_REQUIRE( view && out, "view/out is NULL" );
     NVB_REQUIRE( view->bwt_occ_dev != nullptr, "bwt_occ_dev is NULL" );
     NVB_REQUIRE( ((uintptr_t)view->bwt_occ_dev & 31u) == 0, "bwt_occ_dev must be 32-byte aligned" );
-    NVB_REQUIRE( kmer_len <= 14, "kmer_len must be <= 14" );
+    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
     NVB_REQUIRE( view->L2[4] == view->length, "L2[4] must equal length" );
+    const uint32_t K = view->sa_int ? view->sa_int : 16u;
+    NVB_REQUIRE( K <= 64 && (K & (K - 1u)) == 0, "sa_int must be a power of two in [1,64]" );
     NVB_REQUIRE( view->primary <= view->length, "primary out of range" );
     const uint64_t need = 2ull * ((((uint64_t)view->length + 15u) / 16u + 3u) & ~3ull);
     NVB_REQUIRE( view->bwt_occ_words >= need, "bwt_occ_words too small for length" );
-    NVB_REQUIRE( view->ssa_dev == nullptr || view->ssa_words >= ((uint64_t)view->length + 16u) / 16u, "ssa_words too small for length" );
+    NVB_REQUIRE( view->ssa_dev == nullptr || view->ssa_words >= (uint64_t)view->length / K + 1u, "ssa_words too small for length" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out );
 }
@@ -453,7 +512,7 @@ nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* r
     FMIndexImpl* idx = (FMIndexImpl*)index;
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( end - begin ) ), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
                         idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;

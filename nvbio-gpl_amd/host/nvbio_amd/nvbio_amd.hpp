@@ -112,8 +112,12 @@ public:
     fm_index(const nvbio_fm_index_view& view, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
         : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_create( &view, device, kmer_len, stream, &m_h ) ); }
     // build on the GPU from a 2-bit packed text in device memory
-    fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
-        : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_build( text2_dev, length, device, kmer_len, 0, stream, &m_h ) ); }
+    fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0, uint32_t sa_int = 16)
+        : m_h( nullptr ), m_device( device )
+    {
+        const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u };
+        check( nvbio_fm_index_build( text2_dev, length, device, &opts, stream, &m_h ) );
+    }
     fm_index(const fm_index&) = delete;
     fm_index& operator=(const fm_index&) = delete;
     ~fm_index() { if (m_h) (void)nvbio_fm_index_destroy( m_h ); }

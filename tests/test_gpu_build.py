@@ -79,3 +79,32 @@ def test_built_index_answers_queries(amd, orc):
     for k in range(0, Q, 97):
         assert np.array_equal(text[pos[k]:pos[k] + L], syms[k * L:(k + 1) * L])
     fmi.close()
+
+
+@pytest.mark.parametrize("sa_int", [1, 2, 4, 8, 32, 64])
+def test_denser_and_sparser_sa_sampling_gives_the_same_positions(amd, orc, sa_int):
+    """the handle may sample the SA at any power of two (1 = the full suffix array, sized for
+    288 GB of HBM): locate() and the filter return the positions of the reference's K = 16 index"""
+    rng = np.random.default_rng(13)
+    n = 200003
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[777:1200] = 2
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=6, sa_int=sa_int)
+    v = fmi.view()
+    assert v.sa_int == sa_int and v.ssa_words == n // sa_int + 1
+    b, s = fmi.arrays()
+    assert np.array_equal(amd.u32(b), hidx.bwt_occ)
+    want_ssa = np.concatenate([[0xFFFFFFFF], hidx.sa[sa_int::sa_int]]).astype(np.uint32)
+    assert np.array_equal(amd.u32(s), want_ssa)
+    rows = np.concatenate([np.arange(0, 3000), rng.integers(0, n + 1, 50000), [hidx.primary, n]]).astype(np.uint32)
+    assert np.array_equal(amd.u32(fmi.locate(rows)), orc.locate_batch(hidx, rows))
+    jt = fmi.locate_ssa_iterator(rows)
+    assert np.array_equal(amd.u32(fmi.lookup_ssa_iterator(jt)), orc.locate_batch(hidx, rows))
+    from util import make_queries
+    syms, offs = make_queries(rng, text, 5000, 4, 30, hit_every=2, n_count=20)
+    total, ranges, slots = orc.filter_rank(hidx, syms, offs)
+    flt = amd.FMIndexFilter()
+    assert flt.rank(fmi, amd.PackedStringSet(syms, 8, 5000, offsets=offs, ranges=True)) == total
+    assert np.array_equal(amd.u32(flt.locate(0, total)), orc.filter_locate(hidx, ranges, slots, 0, total))
+    fmi.close()
