@@ -222,6 +222,9 @@ typedef struct
     const uint32_t* win_begin_dev;     /* n entries: window begin (symbol index into text)                  */
     const uint32_t* win_end_dev;       /* n entries: window end (exclusive)                                 */
     uint32_t        n;
+    uint32_t        max_read_len;      /* the stream's max_pattern_length() (batched.h stream concept), or 0 if
+                                          unknown.  A hint only: it lets the library pick 16-bit packed kernels
+                                          when every score provably fits; results do not depend on it.       */
 } nvbio_alignment_batch;
 
 enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };

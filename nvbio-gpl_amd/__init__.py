@@ -67,7 +67,8 @@ class _Batch(ctypes.Structure):
                 ("read_offsets_dev", ctypes.c_void_p), ("quals_dev", ctypes.c_void_p),
                 ("read_id_dev", ctypes.c_void_p), ("flags_dev", ctypes.c_void_p),
                 ("text_dev", ctypes.c_void_p), ("text_bits", ctypes.c_uint32),
-                ("win_begin_dev", ctypes.c_void_p), ("win_end_dev", ctypes.c_void_p), ("n", ctypes.c_uint32)]
+                ("win_begin_dev", ctypes.c_void_p), ("win_end_dev", ctypes.c_void_p), ("n", ctypes.c_uint32),
+                ("max_read_len", ctypes.c_uint32)]
 
 
 _lib = None
@@ -357,7 +358,7 @@ class AlignmentBatch:
     """The flattened stream of alignment jobs (see nvbio_alignment_batch)."""
 
     def __init__(self, reads, read_bits, read_offsets, text, text_bits, win_begin, win_end, quals=None, read_id=None,
-                 flags=None, device="cuda:0"):
+                 flags=None, device="cuda:0", max_read_len=0):
         torch = _torch()
         self.device = device
         self.read_bits, self.text_bits = int(read_bits), int(text_bits)
@@ -370,6 +371,7 @@ class AlignmentBatch:
         self.read_id = _dev_tensor(read_id, torch.int32, device)
         self.flags = _dev_tensor(flags, torch.uint8, device)
         self.n = int(self.win_begin.numel())
+        self.max_read_len = int(max_read_len)       # max_pattern_length() of the stream concept; 0 = unknown
 
     def size(self):
         return self.n
@@ -377,7 +379,7 @@ class AlignmentBatch:
     def c_struct(self):
         return _Batch(_ptr(self.reads), self.read_bits, _ptr(self.read_offsets), _ptr(self.quals), _ptr(self.read_id),
                       _ptr(self.flags), _ptr(self.text), self.text_bits, _ptr(self.win_begin), _ptr(self.win_end),
-                      self.n)
+                      self.n, self.max_read_len)
 
 
 class BatchedBandedAlignmentScore:

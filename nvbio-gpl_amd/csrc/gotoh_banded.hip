@@ -18,6 +18,7 @@
 // wins" rule exactly.  Reads and windows are consumed straight from the packed HBM streams
 // (one dword per 8 read symbols / 16 text symbols).
 #include "gotoh_common.h"
+#include <stdlib.h>
 
 namespace nvbio_amd {
 
@@ -163,10 +164,172 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
     sinks[job]  = make_uint2( best_x, best_y );
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit packed variant for the production case (band 31, LOCAL): one lane owns TWO alignments,
+// one in each half of every register, so H[31]/F[31] of both take the registers one alignment
+// took before and every add / max is a v_pk_*_i16 doing two cells.  Exactness conditions,
+// checked on the host (else the int32 kernel runs): all LOCAL scores fit 10 bits
+// (match * max_read_len <= 1000, so that (score << 5 | column) fits an int16) and penalties are
+// < 4096, so that the -16384 stand-in for the reference's infimum can never win a max against a
+// real score nor wrap.  The row-0 / column-30 infimum cells behave exactly as in the int32 kernel.
+// ---------------------------------------------------------------------------------------------
+typedef short    v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s pk(const int a, const int b) { v2s r; r.x = (short)a; r.y = (short)b; return r; }
+__device__ __forceinline__ v2s pk_max(const v2s a, const v2s b) { return __builtin_elementwise_max( a, b ); }
+__device__ __forceinline__ v2s pk_from_bits(const uint32_t u) { return __builtin_bit_cast( v2s, u ); }
+
+template <int RBITS, int TBITS>
+__global__ void __launch_bounds__(128)
+banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+{
+    constexpr int BAND = 31;
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2u * pair >= b.n) return;
+
+    uint32_t first[2], M[2], tb[2], N[2];
+    bool     rev[2], comp[2], valid[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        const uint32_t job = 2u * pair + u;
+        valid[u] = job < b.n;
+        const uint32_t jj  = valid[u] ? job : 2u * pair;
+        const uint32_t rid = b.read_id ? b.read_id[jj] : jj;
+        first[u] = b.read_offsets[rid];
+        M[u]     = b.read_offsets[rid + 1] - first[u];
+        const uint32_t fl = b.flags ? b.flags[jj] : 0u;
+        rev[u]  = (fl & NVBIO_READ_REVERSE) != 0;
+        comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
+        tb[u]   = b.win_begin[jj];
+        N[u]    = b.win_end[jj] - tb[u];
+    }
+    // rows each half really computes: none when the text is shorter than the pattern (nothing reported)
+    const uint32_t rows0 = (valid[0] && N[0] >= M[0]) ? M[0] : 0u;
+    const uint32_t rows1 = (valid[1] && N[1] >= M[1]) ? M[1] : 0u;
+    const uint32_t rows  = rows0 > rows1 ? rows0 : rows1;
+
+    SymbolReader<TBITS> trd0( b.text ), trd1( b.text );
+    SymbolReader<RBITS> prd0( b.reads ), prd1( b.reads );
+
+    uint64_t cache0 = 0, cache1 = 0;                             // 30 cached text symbols per alignment
+    #pragma unroll
+    for (int j = 0; j < BAND - 1; ++j)
+    {
+        const uint32_t g0 = ((uint32_t)j < N[0]) ? trd0.get( tb[0] + j ) : 255u;
+        const uint32_t g1 = ((uint32_t)j < N[1]) ? trd1.get( tb[1] + j ) : 255u;
+        cache0 |= (uint64_t)(g0 & 3u) << (2 * j);
+        cache1 |= (uint64_t)(g1 & 3u) << (2 * j);
+    }
+
+    const v2s GO = pk( sc.pat_go, sc.pat_go ), GE = pk( sc.pat_ge, sc.pat_ge );
+    const v2s INF = pk( -16384, -16384 ), ZERO = pk( 0, 0 ), K32 = pk( 32, 32 );
+    const int V = sc.match;
+
+    v2s H[BAND], F[BAND];
+    #pragma unroll
+    for (int j = 0; j < BAND; ++j) { H[j] = ZERO; F[j] = INF; }
+
+    int32_t  best[2]   = { NVBIO_SCORE_MIN, NVBIO_SCORE_MIN };
+    uint32_t best_x[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, best_y[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu };
+
+    for (uint32_t i = 0; i < rows; ++i)
+    {
+        // the row's pattern symbols and mismatch scores
+        uint32_t q0 = 255u, q1 = 255u; int S0 = 0, S1 = 0;
+        if (i < rows0)
+        {
+            const uint32_t pidx = rev[0] ? first[0] + M[0] - 1u - i : first[0] + i;
+            q0 = prd0.get( pidx ); if (comp[0] && q0 < 4u) q0 = 3u - q0;
+            const uint32_t qq = b.quals ? b.quals[pidx] : 0u; S0 = s_mm[qq < 63u ? qq : 63u];
+        }
+        if (i < rows1)
+        {
+            const uint32_t pidx = rev[1] ? first[1] + M[1] - 1u - i : first[1] + i;
+            q1 = prd1.get( pidx ); if (comp[1] && q1 < 4u) q1 = 3u - q1;
+            const uint32_t qq = b.quals ? b.quals[pidx] : 0u; S1 = s_mm[qq < 63u ? qq : 63u];
+        }
+        const uint32_t gn0 = (i + (uint32_t)(BAND - 1) < N[0]) ? trd0.get( tb[0] + i + (BAND - 1) ) : 255u;
+        const uint32_t gn1 = (i + (uint32_t)(BAND - 1) < N[1]) ? trd1.get( tb[1] + i + (BAND - 1) ) : 255u;
+
+        // match flags of the 30 cached columns: alignment 0 at bit 2j, alignment 1 at bit 2j+1
+        uint64_t e0 = 0, e1 = 0;
+        if (q0 < 4u) { const uint64_t t = cache0 ^ ((uint64_t)q0 * 0x5555555555555555ull); e0 = ~(t | (t >> 1)) & 0x5555555555555555ull; }
+        if (q1 < 4u) { const uint64_t t = cache1 ^ ((uint64_t)q1 * 0x5555555555555555ull); e1 = ~(t | (t >> 1)) & 0x5555555555555555ull; }
+        const uint64_t EQ = e0 | (e1 << 1);
+
+        const v2s SS = pk( S0, S1 );                              // mismatch scores of the two rows
+        const v2s DV = pk( V - S0, V - S1 );                      // match - mismatch
+
+        v2s E = ZERO;
+        v2s key = pk( -1, -1 );
+        #pragma unroll
+        for (int j = 0; j < BAND; ++j)
+        {
+            const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
+            F[j] = f;
+
+            uint32_t eq01;
+            if (j == BAND - 1) eq01 = (gn0 == q0 ? 1u : 0u) | (gn1 == q1 ? 0x10000u : 0u);
+            else               eq01 = (uint32_t)((EQ >> (2 * j)) & 1ull) | ((uint32_t)((EQ >> (2 * j + 1)) & 1ull) << 16);
+            const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
+
+            v2s h;
+            if (j == 0)             h = pk_max( f, d );
+            else if (j == BAND - 1) h = pk_max( E, d );
+            else                    h = pk_max( pk_max( f, E ), d );
+            h = pk_max( h, ZERO );
+            key = pk_max( key, h * K32 + pk( j, j ) );
+            H[j] = h;
+            E = (j == 0) ? h + GO : pk_max( h + GO, E + GE );
+        }
+
+        cache0 = (cache0 >> 2) | ((uint64_t)(gn0 & 3u) << (2 * (BAND - 2)));
+        cache1 = (cache1 >> 2) | ((uint64_t)(gn1 & 3u) << (2 * (BAND - 2)));
+
+        // BestSink: row-major reports, the LAST maximum wins
+        const int k0 = key.x, k1 = key.y;
+        if (i < rows0 && (k0 >> 5) >= best[0]) { best[0] = k0 >> 5; best_x[0] = i + (uint32_t)(k0 & 31) + 1u; best_y[0] = i + 1u; }
+        if (i < rows1 && (k1 >> 5) >= best[1]) { best[1] = k1 >> 5; best_x[1] = i + (uint32_t)(k1 & 31) + 1u; best_y[1] = i + 1u; }
+    }
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (valid[u]) { scores[2u * pair + u] = best[u]; sinks[2u * pair + u] = make_uint2( best_x[u], best_y[u] ); }
+}
+
+// the packed kernel is exact iff every LOCAL score fits 10 bits and penalties are small
+static bool packed_local_ok(const SchemeDev& sc, const uint32_t max_read_len)
+{
+    if (max_read_len == 0) return false;
+    if (sc.match < 0 || (uint64_t)sc.match * max_read_len > 1000u) return false;
+    const int lim = 4096;
+    if (sc.mm_min < 0 || sc.mm_max < 0 || sc.mm_min > lim || sc.mm_max > lim) return false;
+    if (sc.pat_go > 0 || sc.pat_ge > 0 || sc.pat_go < -lim || sc.pat_ge < -lim) return false;
+    return true;
+}
+
+template <int RB, int TBITS_>
+static void launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
+{
+    const uint32_t pairs = (b.n + 1u) / 2u;
+    hipLaunchKernelGGL( (banded_gotoh_local31_pk_kernel<RB,TBITS_>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
+}
+
 template <int BAND, int TYPE>
 static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
                                 int32_t* scores, uint2* sinks, hipStream_t s)
 {
+    if (BAND == 31 && TYPE == NVBIO_LOCAL && packed_local_ok( sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
+    {
+        if      (rbits == 4 && tbits == 2) { launch_pk<4,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        else if (rbits == 2 && tbits == 2) { launch_pk<2,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        else if (rbits == 8 && tbits == 8) { launch_pk<8,8>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+    }
     const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
 #define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
@@ -207,7 +370,7 @@ nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
     }
     b->reads = in->reads_dev; b->read_offsets = in->read_offsets_dev; b->quals = in->quals_dev;
     b->read_id = in->read_id_dev; b->flags = in->flags_dev; b->text = in->text_dev;
-    b->win_begin = in->win_begin_dev; b->win_end = in->win_end_dev; b->n = in->n;
+    b->win_begin = in->win_begin_dev; b->win_end = in->win_end_dev; b->n = in->n; b->max_read_len = in->max_read_len;
     return NVBIO_OK;
 }
 

@@ -16,6 +16,7 @@ struct BatchDev
     const uint32_t* win_begin;
     const uint32_t* win_end;
     uint32_t        n;
+    uint32_t        max_read_len;
 };
 
 struct SchemeDev

@@ -128,7 +128,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     # 6. banded Gotoh of every candidate window
     e = tick("extend")
     batch = AlignmentBatch(reads.reads4, 4, read_off.to(torch.int32), genome2, 2, wb.to(torch.int32),
-                           we.to(torch.int32), quals=reads.quals, read_id=rid.to(torch.int32), flags=flags, device=dev)
+                           we.to(torch.int32), quals=reads.quals, read_id=rid.to(torch.int32), flags=flags, device=dev,
+                           max_read_len=M)
     scores, sinks = BatchedBandedAlignmentScore(params.band, GotohAligner(params.aln_type, params.scheme)).enact(batch)
     tock(e)
 

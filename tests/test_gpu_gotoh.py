@@ -110,3 +110,52 @@ def test_banded_edge_cases(amd, orc):
     empty = amd.AlignmentBatch(pats, 8, roffs, txt, 8, np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint32))
     sc, sk = amd.batch_banded_alignment_score(31, al, empty)
     assert sc.numel() == 0
+
+
+def test_packed_local31_kernel_equals_int32_and_oracle(amd, orc):
+    """the 16-bit two-alignments-per-lane kernel (picked when max_read_len is given and every score
+    fits) against the oracle: odd batch sizes, ragged lengths, pairs of different length, short
+    texts (N < M on one half of a pair), reversed/complemented reads, qualities, clipped windows"""
+    rng = np.random.default_rng(77)
+    G = 200000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R = 5001
+    lens = rng.integers(20, 151, R); lens[::3] = 150
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(0, G - 200, R)
+    flat = np.concatenate([text[s:s + l] for s, l in zip(starts, lens)]).copy()
+    flat[rng.random(len(flat)) < 0.03] = rng.integers(0, 5)
+    flat[rng.integers(0, len(flat), 300)] = 4
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    J = 20001
+    rid = rng.integers(0, R, J).astype(np.uint32)
+    flags = rng.integers(0, 4, J).astype(np.uint8)
+    flags[: J // 2] = 0
+    g_pos = starts[rid].astype(np.int64) + rng.integers(-3, 4, J)
+    g_pos[::40] = rng.integers(0, 10, len(g_pos[::40]))
+    g_pos[1::40] = G - rng.integers(20, 170, len(g_pos[1::40]))
+    g_pos = np.clip(g_pos, 0, G - 1)
+    wb = np.where(g_pos > 15, g_pos - 15, 0).astype(np.uint32)
+    we = np.minimum(wb + 31 + lens[rid], G).astype(np.uint32)
+    we = np.minimum(np.maximum(we, wb + 30), G).astype(np.uint32)
+    sel = np.nonzero((we - wb) >= 30)[0]
+    assert (we[sel] - wb[sel] < lens[rid[sel]]).any()           # some N < M jobs are in
+    for sv in ((2, 2, 6, -8, -3, -8, -3), (1, 3, 3, -11, -4, -11, -4), (3, 0, 9, -5, -5, -2, -1)):
+        for use_q in (True, False):
+            kw = dict(quals=quals if use_q else None, read_id=rid[sel], flags=flags[sel])
+            wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.LOCAL, oracle.Scheme(*sv), orc.pack4(flat), roffs,
+                                                     orc.pack2(text), wb[sel], we[sel], **kw)
+            for hint in (150, 0):                               # packed kernel / int32 kernel
+                batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel],
+                                           max_read_len=hint, **kw)
+                sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.LOCAL, _scheme(amd, sv)), batch)
+                assert np.array_equal(sc.cpu().numpy(), wsc), (sv, use_q, hint)
+                assert np.array_equal(amd.u32(sk), wsk), (sv, use_q, hint)
+    # a scheme whose scores do not fit 10 bits must fall back to the int32 kernel and still be exact
+    sv = (9, 2, 6, -8, -3, -8, -3)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel], max_read_len=150,
+                               read_id=rid[sel], flags=flags[sel])
+    sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.LOCAL, _scheme(amd, sv)), batch)
+    wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.LOCAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text),
+                                             wb[sel], we[sel], read_id=rid[sel], flags=flags[sel])
+    assert np.array_equal(sc.cpu().numpy(), wsc) and np.array_equal(amd.u32(sk), wsk)
