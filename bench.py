@@ -114,8 +114,8 @@ def main():
     ap.add_argument("--ref-len", type=float, default=3e9, help="reference length (symbols)")
     ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--kmer", type=int, default=12, help="k of the k-mer SA-range table (0 disables)")
-    ap.add_argument("--sa-int", type=int, default=16, help="SA sampling interval of the index built for the run")
+    ap.add_argument("--kmer", type=int, default=16, help="k of the k-mer SA-range table (0 disables)")
+    ap.add_argument("--sa-int", type=int, default=1, help="SA sampling interval of the index built for the run")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,9 +201,8 @@ def main():
     # algorithmic bytes of one match launch: 32 B x distinct bwt_occ records the reference's
     # backward search touches (counted by the kernel's NO_KMER_TABLE accounting mode, outside the
     # timed region) + 11 B of query symbols (22 x 4 bit) + 8 B of result per query
-    read_off = torch.arange(R, device=device, dtype=torch.int64) * M
-    offs = (read_off[:, None] + torch.arange(spr, device=device, dtype=torch.int64)[None, :] * params.interval_for(M)).reshape(-1).to(torch.int32)
-    qs = amd.PackedStringSet(reads4, 4, n_seeds, offsets=offs, fixed_len=params.seed_len, device=device)
+    qs = amd.PackedStringSet(reads4, 4, n_seeds, fixed_len=params.seed_len, stride=M, device=device, seeds_per_string=spr,
+                             seed_interval=params.interval_for(M))
     blocks = 0
     for flags in (0, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT):
         _, blk = fmi.match(qs, flags | amd.FM_NO_KMER_TABLE, want_blocks=True)
@@ -241,9 +240,11 @@ def main():
         "roofline": {"kernel": "fm_match_kernel<4,false> (seed pass, one strand of %d seeds per launch)" % n_seeds,
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch, "ms_per_launch": match_ms,
                      "queries_per_s": n_seeds / (match_ms * 1e-3) if match_ms > 0 else 0.0},
-        "extend": {"kernel": "banded_gotoh_kernel<31,LOCAL,4,2>", "bound": "valu (int32; MFMA not applicable)",
+        "extend": {"kernel": "banded_gotoh_local31_pk_kernel<4,2> (two alignments per lane, int16 packed)",
+                   "bound": "valu (integer; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
     }
@@ -262,8 +263,9 @@ def main():
         del b_occ, ssa
         g_host = amd.u32(genome)
         probe = reads_sym[:20000].cpu().numpy()
+        cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, probe, genome_is_packed=True)         # page the index in
         c0 = time.perf_counter()
-        cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, probe, genome_is_packed=True)         # page in, estimate the rate
+        cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, probe, genome_is_packed=True)         # estimate the rate
         rate = len(probe) / (time.perf_counter() - c0)
         Rs = args.cpu_sample or int(rate * args.cpu_seconds)
         Rs = max(1000, min(Rs, R, 4_000_000))

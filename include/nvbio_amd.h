@@ -133,6 +133,12 @@ typedef struct
     uint32_t        fixed_len;
     uint32_t        stride;
     uint32_t        n;
+    /* seed enumeration (uniform_seeds_functor, nvbio/strings/seeds.h; nvBowtie mapping_inl.h:485-556):
+     * if seeds_per_string > 0 the set is the seeds of a set of n / seeds_per_string strings: query i is
+     * seed j = i % seeds_per_string of string r = i / seeds_per_string,
+     *   [ base(r) + j*seed_interval, + fixed_len ),  base(r) = offsets_dev ? offsets_dev[r] : r*stride   */
+    uint32_t        seeds_per_string;
+    uint32_t        seed_interval;
 } nvbio_string_set;
 
 enum
@@ -181,6 +187,26 @@ nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set
 nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
                                     uint32_t n_queries, uint64_t begin, uint64_t end,
                                     nvbio_uint2* hits_dev, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * seed hits -> candidate windows: the two index-arithmetic functors between FMIndexFilter::locate
+ * and the banded aligner in the reference's smallest seed-and-extend caller (examples/fmmap/fmmap.cu)
+ * ------------------------------------------------------------------------------------------- */
+
+/* hit_to_diagonal (examples/fmmap/fmmap.cu:92-117) for uniformly enumerated seeds: for hit
+ * (text_pos, seed_id), read = seed_id / seeds_per_read, seed offset p = (seed_id % seeds_per_read) *
+ * seed_interval (on the reverse-complement strand p -> read_len - p - seed_len), diagonal = text_pos - p.
+ * keys_dev[h] = read << 34 | strand << 33 | (diagonal + 1024): sortable, one per hit.               */
+nvbio_status nvbio_hits_to_diagonals(int device, const nvbio_uint2* hits_dev, uint64_t n_hits, uint32_t seeds_per_read,
+                                     uint32_t seed_interval, uint32_t seed_len, uint32_t read_len, uint32_t strand,
+                                     uint64_t* keys_dev, void* stream);
+
+/* genome_infixes (examples/fmmap/fmmap.cu:169-196) with nvBowtie's window rule (BestScoreStream::init_context,
+ * nvBowtie/bowtie2/cuda/score_inl.h:100-106): g_pos = max(diagonal,0); begin = g_pos > band/2 ? g_pos - band/2 : 0;
+ * end = min(begin + band + read_len, genome_len); flags = strand ? REVERSE|COMPLEMENT : 0.                */
+nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, uint32_t read_len,
+                                        uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                        uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Gotoh scoring

@@ -53,7 +53,8 @@ class _BuildOptions(ctypes.Structure):
 class _StringSet(ctypes.Structure):
     _fields_ = [("symbols_dev", ctypes.c_void_p), ("symbol_bits", ctypes.c_uint32),
                 ("offsets_dev", ctypes.c_void_p), ("offsets_are_ranges", ctypes.c_uint32),
-                ("fixed_len", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("n", ctypes.c_uint32)]
+                ("fixed_len", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("n", ctypes.c_uint32),
+                ("seeds_per_string", ctypes.c_uint32), ("seed_interval", ctypes.c_uint32)]
 
 
 class _Scheme(ctypes.Structure):
@@ -141,7 +142,8 @@ class PackedStringSet:
               or n+1 offsets with ranges=True (io::SequenceData sequence_index)
     """
 
-    def __init__(self, symbols, bits, n, offsets=None, ranges=False, fixed_len=0, stride=None, device="cuda:0"):
+    def __init__(self, symbols, bits, n, offsets=None, ranges=False, fixed_len=0, stride=None, device="cuda:0",
+                 seeds_per_string=0, seed_interval=0):
         torch = _torch()
         self.bits, self.n = int(bits), int(n)
         self.symbols = _dev_tensor(symbols, torch.uint8 if bits == 8 else torch.int32, device)
@@ -149,10 +151,12 @@ class PackedStringSet:
         self.ranges, self.fixed_len = bool(ranges), int(fixed_len)
         self.stride = int(fixed_len if stride is None else stride)
         self.device = device
+        # seed enumeration: n = n_strings * seeds_per_string queries [base(r) + j*seed_interval, + fixed_len)
+        self.seeds_per_string, self.seed_interval = int(seeds_per_string), int(seed_interval)
 
     def c_struct(self):
         return _StringSet(_ptr(self.symbols), self.bits, _ptr(self.offsets), 1 if self.ranges else 0,
-                          self.fixed_len, self.stride, self.n)
+                          self.fixed_len, self.stride, self.n, self.seeds_per_string, self.seed_interval)
 
 
 # ---- FM-index ----------------------------------------------------------------------------------
@@ -434,6 +438,31 @@ class BatchedAlignmentScore:
                                             _ptr(scores), _ptr(sinks), None, ctypes.c_uint64(0),
                                             _stream_ptr(batch.device)))
         return scores, sinks
+
+
+def hits_to_diagonals(hits, seeds_per_read, seed_interval, seed_len, read_len, strand):
+    """hit_to_diagonal (examples/fmmap/fmmap.cu:92-117): int64 keys read<<34 | strand<<33 | diagonal+1024"""
+    torch = _torch()
+    keys = torch.empty(hits.shape[0], dtype=torch.int64, device=hits.device)
+    _check(lib().nvbio_hits_to_diagonals(FMIndex._dev_index(hits.device), _ptr(hits), ctypes.c_uint64(hits.shape[0]),
+                                         ctypes.c_uint32(seeds_per_read), ctypes.c_uint32(seed_interval),
+                                         ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), ctypes.c_uint32(strand),
+                                         _ptr(keys), _stream_ptr(hits.device)))
+    return keys
+
+
+def diagonals_to_windows(keys, band, read_len, genome_len):
+    """genome_infixes + nvBowtie's window rule: (read_id, flags, win_begin, win_end) of every candidate key"""
+    torch = _torch()
+    n, dev = keys.numel(), keys.device
+    rid = torch.empty(n, dtype=torch.int32, device=dev)
+    fl = torch.empty(n, dtype=torch.uint8, device=dev)
+    wb = torch.empty(n, dtype=torch.int32, device=dev)
+    we = torch.empty(n, dtype=torch.int32, device=dev)
+    _check(lib().nvbio_diagonals_to_windows(FMIndex._dev_index(dev), _ptr(keys), ctypes.c_uint64(n), ctypes.c_uint32(band),
+                                            ctypes.c_uint32(read_len), ctypes.c_uint32(genome_len), _ptr(rid), _ptr(fl),
+                                            _ptr(wb), _ptr(we), _stream_ptr(dev)))
+    return rid, fl, wb, we
 
 
 def u32(t):

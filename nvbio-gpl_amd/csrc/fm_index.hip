@@ -55,11 +55,19 @@ struct StringSetDev
     uint32_t        fixed_len;
     uint32_t        stride;
     uint32_t        n;
+    uint32_t        spr;         // seeds per string (0: plain string set)
+    uint32_t        interval;    // seed interval
 };
 
 __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint32_t i, uint32_t& begin, uint32_t& len)
 {
-    if (q.offsets)
+    if (q.spr)
+    {
+        const uint32_t r = i / q.spr, j = i - r * q.spr;
+        begin = (q.offsets ? q.offsets[r] : r * q.stride) + j * q.interval;
+        len   = q.fixed_len;
+    }
+    else if (q.offsets)
     {
         begin = q.offsets[i];
         len   = q.ranges ? q.offsets[i + 1] - begin : q.fixed_len;
@@ -280,6 +288,8 @@ static nvbio_status make_set(const nvbio_string_set* s, StringSetDev* d)
     NVB_REQUIRE( !(s->offsets_are_ranges && s->offsets_dev == nullptr), "offsets_are_ranges without offsets_dev" );
     d->symbols = s->symbols_dev; d->offsets = s->offsets_dev; d->ranges = s->offsets_are_ranges;
     d->fixed_len = s->fixed_len; d->stride = s->stride; d->n = s->n;
+    d->spr = s->seeds_per_string; d->interval = s->seed_interval;
+
     return NVBIO_OK;
 }
 

@@ -1,0 +1,78 @@
+// seed_extend.hip -- the index arithmetic between FMIndexFilter::locate and the banded aligner.
+//
+// Reference behaviour reproduced (file:line relative to the reference tree):
+//   hit_to_diagonal functor          examples/fmmap/fmmap.cu:92-117
+//   genome_infixes functor           examples/fmmap/fmmap.cu:169-196
+//   nvBowtie scoring window          nvBowtie/bowtie2/cuda/score_inl.h:100-106 (BestScoreStream::init_context)
+//   read orientation flags           nvBowtie/bowtie2/cuda/alignment_utils.h:291-296
+// Both kernels are pure streaming (coalesced 8-16 B per element in, 8-13 B out): HBM-bound.
+#include "common.h"
+
+namespace nvbio_amd {
+
+__global__ void __launch_bounds__(256)
+hits_to_diagonals_kernel(const uint2* __restrict__ hits, const uint64_t n, const uint32_t spr, const uint32_t interval,
+                         const uint32_t seed_len, const uint32_t read_len, const uint32_t strand, uint64_t* __restrict__ keys)
+{
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint2    hit = hits[h];
+        const uint32_t rid = hit.y / spr;
+        uint32_t       p   = (hit.y - rid * spr) * interval;
+        if (strand) p = read_len - p - seed_len;                 // offset of the seed in the reverse-complemented read
+        const uint64_t diag = (uint64_t)hit.x + 1024u - p;
+        keys[h] = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | diag;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n, const uint32_t band, const uint32_t read_len,
+                            const uint32_t genome_len, uint32_t* __restrict__ read_id, uint8_t* __restrict__ flags,
+                            uint32_t* __restrict__ wb, uint32_t* __restrict__ we)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t k    = keys[i];
+        const uint64_t d    = k & ((1ull << 33) - 1ull);
+        const uint32_t g    = d > 1024u ? (uint32_t)(d - 1024u) : 0u;          // clamp the diagonal at the genome start
+        const uint32_t half = band / 2u;
+        const uint32_t b    = g > half ? g - half : 0u;
+        const uint64_t e    = (uint64_t)b + band + read_len;
+        read_id[i] = (uint32_t)(k >> 34);
+        flags[i]   = ((k >> 33) & 1ull) ? (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT) : (uint8_t)0;
+        wb[i]      = b;
+        we[i]      = e < genome_len ? (uint32_t)e : genome_len;
+    }
+}
+
+} // namespace nvbio_amd
+
+using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_hits_to_diagonals(int device, const nvbio_uint2* hits_dev, uint64_t n_hits, uint32_t seeds_per_read,
+                                                uint32_t seed_interval, uint32_t seed_len, uint32_t read_len, uint32_t strand,
+                                                uint64_t* keys_dev, void* stream)
+{
+    if (n_hits == 0) return NVBIO_OK;
+    NVB_REQUIRE( hits_dev && keys_dev, "NULL device pointer" );
+    NVB_REQUIRE( seeds_per_read > 0, "seeds_per_read must be positive" );
+    NVB_REQUIRE( (uint64_t)(seeds_per_read - 1u) * seed_interval + seed_len <= read_len, "seeds do not fit the read" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( hits_to_diagonals_kernel, dim3( grid_for( n_hits ) ), dim3(256), 0, (hipStream_t)stream,
+                        (const uint2*)hits_dev, n_hits, seeds_per_read, seed_interval, seed_len, read_len, strand, keys_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, uint32_t read_len,
+                                                   uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                                   uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && read_id_dev && flags_dev && win_begin_dev && win_end_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( diagonals_to_windows_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        keys_dev, n, band, read_len, genome_len, read_id_dev, flags_dev, win_begin_dev, win_end_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}

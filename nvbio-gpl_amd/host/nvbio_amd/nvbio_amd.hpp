@@ -96,6 +96,14 @@ struct string_set
     // fixed-length infixes addressed by their start (seeds inside a read stream)
     static string_set infixes(const void* symbols, uint32_t bits, const uint32_t* starts, uint32_t len, uint32_t n)
     { string_set s; s.c = { symbols, bits, starts, 0u, len, len, n }; return s; }
+    // the uniformly spaced seeds of n_strings equal-length strings laid out back to back
+    // (uniform_seeds_functor; nvBowtie mapping_inl.h:485-556): n_strings * seeds_per_string queries
+    static string_set seeds(const void* symbols, uint32_t bits, uint32_t string_len, uint32_t n_strings,
+                            uint32_t seed_len, uint32_t seed_interval)
+    {
+        const uint32_t spr = (string_len - seed_len) / seed_interval + 1u;
+        string_set s; s.c = { symbols, bits, nullptr, 0u, seed_len, string_len, n_strings * spr, spr, seed_interval }; return s;
+    }
     // n strings of equal length laid out back to back
     static string_set uniform(const void* symbols, uint32_t bits, uint32_t len, uint32_t n)
     { string_set s; s.c = { symbols, bits, nullptr, 0u, len, len, n }; return s; }

@@ -47,10 +47,22 @@ class ReadBatch:
         self.reads4, self.n, self.read_len, self.quals = reads4, int(n_reads), int(read_len), quals
 
 
+SCORE_BIAS = 1 << 20
+
+
+def pack_best_key(torch, scores, rc, pos):
+    """order-independent selection key: highest score, then reverse strand, then the larger end
+    position (fmmap only reduces the score per read, examples/fmmap/fmmap.cu:367-376; the locus
+    tie-break is this pipeline's own and does not depend on the order candidates are listed in)"""
+    s = torch.clamp(scores.to(torch.int64) + SCORE_BIAS, min=0)
+    return (s << 34) | (rc.to(torch.int64) << 33) | pos.to(torch.int64)
+
+
 def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
-    """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end - or -1),
-    best_rc[uint8 R], n_candidates).  timers: optional dict name -> (start_event, end_event) lists."""
+    """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end, or -1),
+    best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events."""
     import torch
+    from . import diagonals_to_windows, hits_to_diagonals
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
@@ -68,41 +80,33 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
         if b is not None:
             b.record()
 
-    # 1. seeds: infixes [r*M + j*S, +L) of the read stream (uniform_seeds_functor semantics)
-    e = tick("seed_offsets")
-    read_off = torch.arange(R + 1, device=dev, dtype=torch.int64) * M
-    offs = (read_off[:-1, None] + torch.arange(spr, device=dev, dtype=torch.int64)[None, :] * S_int).reshape(-1)
-    offs32 = offs.to(torch.int32)
-    qs = PackedStringSet(reads.reads4, 4, R * spr, offsets=offs32, fixed_len=L, device=dev)
-    tock(e)
+    if params.max_seed_hits is not None:
+        raise NotImplementedError("max_seed_hits policy is not built yet")
+
+    # 1. seeds: infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernel
+    #    (uniform_seeds_functor semantics; no offset array is materialised)
+    qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
+                         seed_interval=S_int)
 
     cands = []
-    n_hits_total = 0
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
         flt = FMIndexFilter()
         e = tick("match_fw" if strand == 0 else "match_rc")
         n_hits = flt.rank(fmi, qs, flags)
         tock(e)
-        if params.max_seed_hits is not None:
-            raise NotImplementedError("max_seed_hits policy is not built yet")
-        n_hits_total += n_hits
         if n_hits == 0:
             continue
         # 3. SA rows -> text positions, tagged with their seed
         e = tick("locate")
         hits = flt.locate(0, n_hits)
         tock(e)
-        # 4. hit -> diagonal (examples/fmmap/fmmap.cu:92-117)
+        # 4. hit -> diagonal (examples/fmmap/fmmap.cu:92-117); consecutive seeds of a read that agree on
+        #    the diagonal collapse to one candidate (hits arrive in seed order, so an adjacent compare
+        #    removes nearly all duplicates without a sort; a survivor only costs a repeated extension)
         e = tick("diagonals")
-        pos = hits[:, 0].to(torch.int64) & 0xFFFFFFFF
-        sid = hits[:, 1].to(torch.int64)
-        rid = sid // spr
-        p = (sid - rid * spr) * S_int
-        if strand:
-            p = M - p - L                                         # offset of the seed in the reverse-complemented read
-        diag = pos - p + 1024
-        cands.append((rid << 34) | (strand << 33) | diag)
+        keys = torch.unique_consecutive(hits_to_diagonals(hits, spr, S_int, L, M, strand))
+        cands.append(keys)
         tock(e)
 
     best_score = torch.full((R,), SCORE_MIN, dtype=torch.int32, device=dev)
@@ -111,37 +115,31 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     if not cands:
         return best_score, best_pos, best_rc, 0
 
-    # 5. candidate loci: unique (read, strand, diagonal), sorted by read
-    e = tick("unique")
-    keys = torch.unique(torch.cat(cands))
+    # 5. candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106)
+    e = tick("windows")
+    keys = torch.cat(cands) if len(cands) > 1 else cands[0]
     C = keys.numel()
-    rid = keys >> 34
-    rc = (keys >> 33) & 1
-    diag = (keys & ((1 << 33) - 1)) - 1024
-    g_pos = torch.clamp(diag, min=0)
-    half = params.band // 2
-    wb = torch.where(g_pos > half, g_pos - half, torch.zeros_like(g_pos))          # score_inl.h:102-106
-    we = torch.clamp(wb + params.band + M, max=genome_len)
-    flags = (rc * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8)
+    rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len)
+    read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
     tock(e)
 
     # 6. banded Gotoh of every candidate window
     e = tick("extend")
-    batch = AlignmentBatch(reads.reads4, 4, read_off.to(torch.int32), genome2, 2, wb.to(torch.int32),
-                           we.to(torch.int32), quals=reads.quals, read_id=rid.to(torch.int32), flags=flags, device=dev,
-                           max_read_len=M)
+    batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, read_id=rid, flags=flags,
+                           device=dev, max_read_len=M)
     scores, sinks = BatchedBandedAlignmentScore(params.band, GotohAligner(params.aln_type, params.scheme)).enact(batch)
     tock(e)
 
-    # 7. best candidate per read (ties: the last candidate in (strand, diagonal) order)
+    # 7. best candidate per read
     e = tick("reduce")
-    packed = (scores.to(torch.int64) << 32) | torch.arange(C, device=dev, dtype=torch.int64)
-    top = torch.full((R,), -(1 << 62), dtype=torch.int64, device=dev)
-    top.scatter_reduce_(0, rid, packed, "amax", include_self=True)
-    has = top > -(1 << 62)
-    ci = (top & 0xFFFFFFFF)[has]
-    best_score[has] = scores[ci]
-    best_pos[has] = wb[ci] + (sinks[ci, 0].to(torch.int64) & 0xFFFFFFFF)           # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
-    best_rc[has] = rc[ci].to(torch.uint8)
+    rc = (keys >> 33) & 1
+    pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
+    top = torch.full((R,), -1, dtype=torch.int64, device=dev)
+    top.scatter_reduce_(0, rid.to(torch.int64), pack_best_key(torch, scores, rc, pos), "amax", include_self=True)
+    has = top >= 0
+    sv = top >> 34
+    best_score = torch.where(has & (sv > 0), (sv - SCORE_BIAS).to(torch.int32), best_score)
+    best_pos = torch.where(has, top & ((1 << 33) - 1), best_pos)
+    best_rc = torch.where(has, ((top >> 33) & 1).to(torch.uint8), best_rc)
     tock(e)
     return best_score, best_pos, best_rc, int(C)

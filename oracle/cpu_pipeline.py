@@ -68,12 +68,15 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
     scores, sinks = O.banded_gotoh_packed_batch(band, aln_type, scheme, reads4, roffs, genome2, wb.astype(np.uint32),
                                                 we.astype(np.uint32), read_id=rid.astype(np.uint32), flags=flags,
                                                 quals=quals)
-    packed = (scores.astype(np.int64) << 32) | np.arange(len(keys), dtype=np.int64)
-    top = np.full(R, -(1 << 62), dtype=np.int64)
+    # best candidate per read: highest score, then reverse strand, then the larger end position
+    # (an order-independent rule; fmmap itself only reduces the score, examples/fmmap/fmmap.cu:367-376)
+    pos = wb.astype(np.int64) + sinks[:, 0].astype(np.int64)
+    packed = (np.maximum(scores.astype(np.int64) + (1 << 20), 0) << 34) | (rc.astype(np.int64) << 33) | pos
+    top = np.full(R, -1, dtype=np.int64)
     np.maximum.at(top, rid, packed)
-    has = top > -(1 << 62)
-    ci = (top & 0xFFFFFFFF)[has]
-    best_score[has] = scores[ci]
-    best_pos[has] = wb[ci] + sinks[ci, 0].astype(np.int64)
-    best_rc[has] = rc[ci].astype(np.uint8)
+    has = top >= 0
+    sv = top >> 34
+    best_score = np.where(has & (sv > 0), sv - (1 << 20), best_score).astype(np.int32)
+    best_pos = np.where(has, top & ((1 << 33) - 1), best_pos)
+    best_rc = np.where(has, (top >> 33) & 1, best_rc).astype(np.uint8)
     return best_score, best_pos, best_rc, len(keys)

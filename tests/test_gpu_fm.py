@@ -132,3 +132,48 @@ def test_empty_and_error_paths(amd, fm_golden):
     with pytest.raises(amd.NvbioError):
         amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"], kmer_len=17)
     fmi.close()
+
+
+def test_seed_enumeration_and_diagonal_helpers(amd, orc, big):
+    """seeds enumerated inside the kernel (uniform_seeds_functor) == the same seeds passed as explicit
+    infixes; hit_to_diagonal / genome_infixes helpers == their definition (fmmap.cu:92-117,169-196)"""
+    import torch
+    rng, text, hidx = big
+    fmi = amd.FMIndex.from_arrays(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa, kmer_len=8)
+    R, M, L, S = 3000, 150, 22, 15
+    spr = (M - L) // S + 1
+    starts = rng.integers(0, hidx.n - M, R)
+    reads = np.stack([text[s:s + M] for s in starts]).copy()
+    reads[rng.random(reads.shape) < 0.01] = 4
+    flat4 = orc.pack4(reads.reshape(-1))
+    offs = (np.arange(R)[:, None] * M + np.arange(spr)[None, :] * S).reshape(-1).astype(np.uint32)
+    explicit = amd.PackedStringSet(flat4, 4, R * spr, offsets=offs, fixed_len=L)
+    enumerated = amd.PackedStringSet(flat4, 4, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
+    for flags in (0, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT):
+        assert torch.equal(fmi.match(explicit, flags), fmi.match(enumerated, flags))
+    # with per-read offsets (ragged read stream)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    enum2 = amd.PackedStringSet(flat4, 4, R * spr, offsets=roffs, fixed_len=L, seeds_per_string=spr, seed_interval=S)
+    assert torch.equal(fmi.match(explicit), fmi.match(enum2))
+
+    hits = np.stack([rng.integers(0, 2 ** 32 - 1, 5000, dtype=np.uint64).astype(np.uint32),
+                     rng.integers(0, R * spr, 5000).astype(np.uint32)], axis=1)
+    hits[:50, 0] = rng.integers(0, 40, 50)                         # diagonals below zero
+    ht = torch.from_numpy(hits.view(np.int32)).cuda()
+    G = 3_000_000_000
+    for strand in (0, 1):
+        keys = amd.hits_to_diagonals(ht, spr, S, L, M, strand)
+        rid = hits[:, 1].astype(np.int64) // spr
+        p = (hits[:, 1].astype(np.int64) % spr) * S
+        if strand:
+            p = M - p - L
+        want = (rid << 34) | (strand << 33) | (hits[:, 0].astype(np.int64) - p + 1024)
+        assert np.array_equal(keys.cpu().numpy(), want)
+        r, fl, wb, we = amd.diagonals_to_windows(keys, 31, M, G)
+        g = np.maximum(hits[:, 0].astype(np.int64) - p, 0)
+        wwb = np.where(g > 15, g - 15, 0)
+        assert np.array_equal(amd.u32(wb).astype(np.int64), wwb)
+        assert np.array_equal(amd.u32(we).astype(np.int64), np.minimum(wwb + 31 + M, G))
+        assert np.array_equal(amd.u32(r).astype(np.int64), rid)
+        assert (fl.cpu().numpy() == (3 if strand else 0)).all()
+    fmi.close()
