@@ -182,6 +182,10 @@ nvbio_status nvbio_fm_locate_lookup(nvbio_fm_index_t index, const nvbio_uint2* j
  * the range sizes (uint64).  *n_hits receives the total (host value; this call synchronizes). */
 nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
                                   nvbio_uint2* ranges_dev, uint64_t* slots_dev, uint64_t* n_hits, void* stream);
+/* the second half of FMIndexFilter::rank on its own (filter_inl.h:279-292): the inclusive scan of the sizes of
+ * ranges that are already in HBM (e.g. from nvbio_fm_match) and the total; synchronizes like filter_rank. */
+nvbio_status nvbio_fm_filter_scan(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, uint32_t n_queries,
+                                  uint64_t* slots_dev, uint64_t* n_hits, void* stream);
 /* FMIndexFilter<device_tag>::locate (filter_inl.h:299-393): hits_dev[h-begin] = (text_pos, query_id)
  * for the global hit indices h in [begin, end). */
 nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,

@@ -314,6 +314,17 @@ class FMIndexFilter:
         self._n_hits = total.value
         return self._n_hits
 
+    def rank_ranges(self, index, ranges):
+        """the scan half of rank() over ranges already computed by FMIndex.match (nvbio_fm_filter_scan)"""
+        torch = _torch()
+        self._index, self._n_queries, self._ranges = index, ranges.shape[0], ranges
+        self._slots = torch.empty(ranges.shape[0], dtype=torch.int64, device=index.device)
+        total = ctypes.c_uint64(0)
+        _check(lib().nvbio_fm_filter_scan(index._h, _ptr(ranges), ctypes.c_uint32(ranges.shape[0]), _ptr(self._slots),
+                                          ctypes.byref(total), _stream_ptr(index.device)))
+        self._n_hits = total.value
+        return self._n_hits
+
     def locate(self, begin, end, hits=None):
         """hits[h-begin] = (text_pos, query_id) for hit indices [begin,end) (filter_inl.h:299-393)"""
         torch = _torch()

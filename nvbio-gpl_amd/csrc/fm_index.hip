@@ -488,6 +488,30 @@ nvbio_status nvbio_fm_locate_lookup(nvbio_fm_index_t index, const nvbio_uint2* j
     return NVBIO_OK;
 }
 
+nvbio_status nvbio_fm_filter_scan(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, uint32_t n_queries,
+                                  uint64_t* slots_dev, uint64_t* n_hits, void* stream)
+{
+    NVB_REQUIRE( index && n_hits, "NULL argument" );
+    *n_hits = 0;
+    if (n_queries == 0) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && slots_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+
+    hipcub::TransformInputIterator<uint64_t, RangeSize, const uint2*> sizes( (const uint2*)ranges_dev, RangeSize() );
+    size_t temp_bytes = 0;
+    NVB_HIP( hipcub::DeviceScan::InclusiveSum( nullptr, temp_bytes, sizes, slots_dev, (int)n_queries, s ) );
+    void* temp = nullptr;
+    if (hipMallocAsync( &temp, temp_bytes ? temp_bytes : 16, s ) != hipSuccess) { set_error( "filter_scan: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    const hipError_t e = hipcub::DeviceScan::InclusiveSum( temp, temp_bytes, sizes, slots_dev, (int)n_queries, s );
+    (void)hipFreeAsync( temp, s );
+    if (e != hipSuccess) { set_error( "filter_scan: scan failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    NVB_HIP( hipMemcpyAsync( n_hits, slots_dev + (n_queries - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s ) );
+    NVB_HIP( hipStreamSynchronize( s ) );
+    return NVBIO_OK;
+}
+
 nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
                                   nvbio_uint2* ranges_dev, uint64_t* slots_dev, uint64_t* n_hits, void* stream)
 {
@@ -496,21 +520,7 @@ nvbio_status nvbio_fm_filter_rank(nvbio_fm_index_t index, const nvbio_string_set
     if (queries->n == 0) return NVBIO_OK;
     NVB_REQUIRE( ranges_dev && slots_dev, "NULL device pointer" );
     NVB_CHECK( nvbio_fm_match( index, queries, flags, ranges_dev, nullptr, stream ) );
-    FMIndexImpl* idx = (FMIndexImpl*)index;
-    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-
-    hipcub::TransformInputIterator<uint64_t, RangeSize, const uint2*> sizes( (const uint2*)ranges_dev, RangeSize() );
-    size_t temp_bytes = 0;
-    NVB_HIP( hipcub::DeviceScan::InclusiveSum( nullptr, temp_bytes, sizes, slots_dev, (int)queries->n, s ) );
-    void* temp = nullptr;
-    if (hipMallocAsync( &temp, temp_bytes ? temp_bytes : 16, s ) != hipSuccess) { set_error( "filter_rank: out of device memory" ); return NVBIO_ERR_NOMEM; }
-    const hipError_t e = hipcub::DeviceScan::InclusiveSum( temp, temp_bytes, sizes, slots_dev, (int)queries->n, s );
-    (void)hipFreeAsync( temp, s );
-    if (e != hipSuccess) { set_error( "filter_rank: scan failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
-    NVB_HIP( hipMemcpyAsync( n_hits, slots_dev + (queries->n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s ) );
-    NVB_HIP( hipStreamSynchronize( s ) );
-    return NVBIO_OK;
+    return nvbio_fm_filter_scan( index, ranges_dev, queries->n, slots_dev, n_hits, stream );
 }
 
 nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,

@@ -180,19 +180,39 @@ __device__ __forceinline__ v2s pk(const int a, const int b) { v2s r; r.x = (shor
 __device__ __forceinline__ v2s pk_max(const v2s a, const v2s b) { return __builtin_elementwise_max( a, b ); }
 __device__ __forceinline__ v2s pk_from_bits(const uint32_t u) { return __builtin_bit_cast( v2s, u ); }
 
-template <int RBITS, int TBITS>
+// 32 bits of a big-endian packed stream starting at absolute bit position `bit`, assembled from the
+// two words (a = word bit>>5, b = the next one) that were loaded one chunk earlier
+__device__ __forceinline__ uint32_t funnel32(const uint32_t a, const uint32_t b, const uint32_t bit)
+{
+    const uint32_t sh = bit & 31u;
+    return sh ? ((a << sh) | (b >> (32u - sh))) : a;
+}
+__device__ __forceinline__ uint32_t clamp_u32(const int64_t v, const uint32_t lo, const uint32_t hi)
+{
+    return v < (int64_t)lo ? lo : (v > (int64_t)hi ? hi : (uint32_t)v);
+}
+
+// Rows are processed in chunks of 8.  At the top of a chunk every lane assembles the chunk's 8 read
+// symbols and 8 incoming text symbols (per alignment) from words loaded one chunk EARLIER, then
+// issues the loads for the next chunk: one wave-uniform wait point per 8 rows with an 8-row
+// (~5,000 instruction) head start, and no per-row branches.  Reads are packed RBITS (2 or 4) per
+// symbol, the text 2 bits per symbol.
+template <int RBITS>
 __global__ void __launch_bounds__(128)
 banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
 {
     constexpr int BAND = 31;
+    constexpr uint32_t RMASK = (1u << RBITS) - 1u;
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
     __syncthreads();
 
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (2u * pair >= b.n) return;
+    const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
+    const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
 
-    uint32_t first[2], M[2], tb[2], N[2];
+    uint32_t first[2], M[2], tb[2], N[2], rows_u[2];
     bool     rev[2], comp[2], valid[2];
     #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -208,26 +228,83 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
         comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
         tb[u]   = b.win_begin[jj];
         N[u]    = b.win_end[jj] - tb[u];
+        // rows this half really computes: none when the text is shorter than the pattern (nothing reported)
+        rows_u[u] = (valid[u] && N[u] >= M[u]) ? M[u] : 0u;
     }
-    // rows each half really computes: none when the text is shorter than the pattern (nothing reported)
-    const uint32_t rows0 = (valid[0] && N[0] >= M[0]) ? M[0] : 0u;
-    const uint32_t rows1 = (valid[1] && N[1] >= M[1]) ? M[1] : 0u;
-    const uint32_t rows  = rows0 > rows1 ? rows0 : rows1;
+    const uint32_t rows = rows_u[0] > rows_u[1] ? rows_u[0] : rows_u[1];
 
-    SymbolReader<TBITS> trd0( b.text ), trd1( b.text );
-    SymbolReader<RBITS> prd0( b.reads ), prd1( b.reads );
-
-    uint64_t cache0 = 0, cache1 = 0;                             // 30 cached text symbols per alignment
+    // word ranges a stream may touch (loads are clamped into them; symbols outside are never used)
+    uint32_t r_lo[2], r_hi[2], t_lo[2], t_hi[2];
     #pragma unroll
-    for (int j = 0; j < BAND - 1; ++j)
+    for (int u = 0; u < 2; ++u)
     {
-        const uint32_t g0 = ((uint32_t)j < N[0]) ? trd0.get( tb[0] + j ) : 255u;
-        const uint32_t g1 = ((uint32_t)j < N[1]) ? trd1.get( tb[1] + j ) : 255u;
-        cache0 |= (uint64_t)(g0 & 3u) << (2 * j);
-        cache1 |= (uint64_t)(g1 & 3u) << (2 * j);
+        r_lo[u] = (uint32_t)(((uint64_t)first[u] * RBITS) >> 5);
+        r_hi[u] = (uint32_t)(((uint64_t)(first[u] + (M[u] ? M[u] - 1u : 0u)) * RBITS) >> 5);
+        t_lo[u] = tb[u] >> 4;
+        t_hi[u] = (tb[u] + (N[u] ? N[u] - 1u : 0u)) >> 4;
     }
+
+    // storage position (symbol index) where the read chunk of rows [r0, r0+8) starts, and the nibble
+    // step inside it: forward reads start at first+r0 and walk up; reversed reads cover
+    // [first+M-1-r0-7, first+M-1-r0] and walk down from its top
+    auto read_chunk_start = [&](const int u, const uint32_t r0) -> int64_t {
+        return rev[u] ? (int64_t)first[u] + (int64_t)M[u] - 1 - (int64_t)r0 - 7 : (int64_t)first[u] + r0;
+    };
+
+    // ---- text cache: columns 0..29 of row 0, big-endian (column j at bits [62-2j, 63-2j]) ------------
+    uint64_t cache[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        const uint32_t w  = tb[u] >> 4;
+        const uint32_t w0 = twords[clamp_u32( w,      t_lo[u], t_hi[u] )];
+        const uint32_t w1 = twords[clamp_u32( w + 1u, t_lo[u], t_hi[u] )];
+        const uint32_t w2 = twords[clamp_u32( w + 2u, t_lo[u], t_hi[u] )];
+        const uint32_t bit = (tb[u] & 15u) * 2u;
+        const uint64_t hi = ((uint64_t)funnel32( w0, w1, bit ) << 32) | funnel32( w1, w2, bit );
+        uint64_t c = hi & ~0xFull;                                   // 30 symbols = top 60 bits
+        // symbols at or past the text end read as 3 (the 255 sentinel through a 2-bit cache)
+        if (N[u] < 30u) c |= (~0ull >> (2u * N[u])) & ~0xFull;
+        cache[u] = c;
+    }
+
+    // ---- stream words for chunk 0 (loaded now, consumed at the top of the loop) ----------------------
+    uint32_t ra[2], rb[2], ta[2], tbw[2];
+    uint32_t qa[2] = { 0, 0 }, qb[2] = { 0, 0 }, qc[2] = { 0, 0 };  // quality bytes of the chunk: 3 words cover 8 unaligned bytes
+    const uint32_t qadj = (uint32_t)((uintptr_t)b.quals & 3u);      // the quality stream need not be 4-byte aligned
+    const uint32_t* __restrict__ qwords = (const uint32_t*)((uintptr_t)b.quals - qadj);
+    const bool has_quals = (b.quals != nullptr);
+    auto issue_loads = [&](const uint32_t r0) {
+        if (has_quals)
+        {
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const int64_t qw  = (read_chunk_start( u, r0 ) + qadj) >> 2;        // byte position / 4
+                const uint32_t lo = (first[u] + qadj) >> 2, hi = (first[u] + qadj + (M[u] ? M[u] - 1u : 0u)) >> 2;
+                qa[u] = qwords[clamp_u32( qw,     lo, hi )];
+                qb[u] = qwords[clamp_u32( qw + 1, lo, hi )];
+                qc[u] = qwords[clamp_u32( qw + 2, lo, hi )];
+            }
+        }
+        #pragma unroll
+        for (int u = 0; u < 2; ++u)
+        {
+            const int64_t  rbit = read_chunk_start( u, r0 ) * RBITS;
+            const int64_t  rw   = rbit >> 5;                          // arithmetic shift: floor for negatives
+            ra[u]  = rwords[clamp_u32( rw,     r_lo[u], r_hi[u] )];
+            rb[u]  = rwords[clamp_u32( rw + 1, r_lo[u], r_hi[u] )];
+            const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);  // text symbol entering column 30 at row r0
+            const int64_t  tw   = (int64_t)(tpos >> 4);
+            ta[u]  = twords[clamp_u32( tw,     t_lo[u], t_hi[u] )];
+            tbw[u] = twords[clamp_u32( tw + 1, t_lo[u], t_hi[u] )];
+        }
+    };
+    issue_loads( 0 );
 
     const v2s GO = pk( sc.pat_go, sc.pat_go ), GE = pk( sc.pat_ge, sc.pat_ge );
+    const int gm = sc.pat_go > sc.pat_ge ? sc.pat_go : sc.pat_ge;
+    const v2s GM = pk( gm, gm );                                     // max(GO,GE): E' = max(t + GO, E + GM)
     const v2s INF = pk( -16384, -16384 ), ZERO = pk( 0, 0 ), K32 = pk( 32, 32 );
     const int V = sc.match;
 
@@ -238,64 +315,98 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
     int32_t  best[2]   = { NVBIO_SCORE_MIN, NVBIO_SCORE_MIN };
     uint32_t best_x[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, best_y[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu };
 
-    for (uint32_t i = 0; i < rows; ++i)
+    for (uint32_t r0 = 0; r0 < rows; r0 += 8u)
     {
-        // the row's pattern symbols and mismatch scores
-        uint32_t q0 = 255u, q1 = 255u; int S0 = 0, S1 = 0;
-        if (i < rows0)
-        {
-            const uint32_t pidx = rev[0] ? first[0] + M[0] - 1u - i : first[0] + i;
-            q0 = prd0.get( pidx ); if (comp[0] && q0 < 4u) q0 = 3u - q0;
-            const uint32_t qq = b.quals ? b.quals[pidx] : 0u; S0 = s_mm[qq < 63u ? qq : 63u];
-        }
-        if (i < rows1)
-        {
-            const uint32_t pidx = rev[1] ? first[1] + M[1] - 1u - i : first[1] + i;
-            q1 = prd1.get( pidx ); if (comp[1] && q1 < 4u) q1 = 3u - q1;
-            const uint32_t qq = b.quals ? b.quals[pidx] : 0u; S1 = s_mm[qq < 63u ? qq : 63u];
-        }
-        const uint32_t gn0 = (i + (uint32_t)(BAND - 1) < N[0]) ? trd0.get( tb[0] + i + (BAND - 1) ) : 255u;
-        const uint32_t gn1 = (i + (uint32_t)(BAND - 1) < N[1]) ? trd1.get( tb[1] + i + (BAND - 1) ) : 255u;
-
-        // match flags of the 30 cached columns: alignment 0 at bit 2j, alignment 1 at bit 2j+1
-        uint64_t e0 = 0, e1 = 0;
-        if (q0 < 4u) { const uint64_t t = cache0 ^ ((uint64_t)q0 * 0x5555555555555555ull); e0 = ~(t | (t >> 1)) & 0x5555555555555555ull; }
-        if (q1 < 4u) { const uint64_t t = cache1 ^ ((uint64_t)q1 * 0x5555555555555555ull); e1 = ~(t | (t >> 1)) & 0x5555555555555555ull; }
-        const uint64_t EQ = e0 | (e1 << 1);
-
-        const v2s SS = pk( S0, S1 );                              // mismatch scores of the two rows
-        const v2s DV = pk( V - S0, V - S1 );                      // match - mismatch
-
-        v2s E = ZERO;
-        v2s key = pk( -1, -1 );
+        // ---- assemble this chunk from the words loaded a chunk ago, then request the next chunk ----
+        uint32_t rchunk[2], tchunk[2]; int rsh[2], rstep[2];
+        uint64_t qchunk[2] = { 0, 0 }; int qsh[2], qstep[2];
         #pragma unroll
-        for (int j = 0; j < BAND; ++j)
+        for (int u = 0; u < 2; ++u)
         {
-            const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
-            F[j] = f;
-
-            uint32_t eq01;
-            if (j == BAND - 1) eq01 = (gn0 == q0 ? 1u : 0u) | (gn1 == q1 ? 0x10000u : 0u);
-            else               eq01 = (uint32_t)((EQ >> (2 * j)) & 1ull) | ((uint32_t)((EQ >> (2 * j + 1)) & 1ull) << 16);
-            const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
-
-            v2s h;
-            if (j == 0)             h = pk_max( f, d );
-            else if (j == BAND - 1) h = pk_max( E, d );
-            else                    h = pk_max( pk_max( f, E ), d );
-            h = pk_max( h, ZERO );
-            key = pk_max( key, h * K32 + pk( j, j ) );
-            H[j] = h;
-            E = (j == 0) ? h + GO : pk_max( h + GO, E + GE );
+            if (has_quals)
+            {
+                // 8 quality bytes of the chunk, byte k of the chunk at bits [8k, 8k+7] (memory order)
+                const uint32_t bs = ((uint32_t)((read_chunk_start( u, r0 ) + qadj) & 3)) * 8u;
+                const uint32_t lo = bs ? ((qa[u] >> bs) | (qb[u] << (32u - bs))) : qa[u];
+                const uint32_t hi = bs ? ((qb[u] >> bs) | (qc[u] << (32u - bs))) : qb[u];
+                qchunk[u] = ((uint64_t)hi << 32) | lo;
+            }
+            qsh[u] = rev[u] ? 56 : 0; qstep[u] = rev[u] ? -8 : 8;
+            const int64_t rbit = read_chunk_start( u, r0 ) * RBITS;
+            rchunk[u] = funnel32( ra[u], rb[u], (uint32_t)(rbit & 31) );
+            rsh[u]    = rev[u] ? (32 - RBITS) - 7 * RBITS : (32 - RBITS);   // row 0 of the chunk: last / first symbol
+            rstep[u]  = rev[u] ? RBITS : -RBITS;
+            const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);
+            tchunk[u] = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
         }
+        if (r0 + 8u < rows) issue_loads( r0 + 8u );
 
-        cache0 = (cache0 >> 2) | ((uint64_t)(gn0 & 3u) << (2 * (BAND - 2)));
-        cache1 = (cache1 >> 2) | ((uint64_t)(gn1 & 3u) << (2 * (BAND - 2)));
+        const uint32_t r_end = (r0 + 8u < rows) ? 8u : rows - r0;
+        for (uint32_t t = 0; t < r_end; ++t)
+        {
+            const uint32_t i = r0 + t;
+            // the row's pattern symbols / mismatch scores and the text symbols entering column 30
+            uint32_t q[2], gn[2]; int S[2];
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                uint32_t qq = (rchunk[u] >> rsh[u]) & RMASK; rsh[u] += rstep[u];
+                if (comp[u] && qq < 4u) qq = 3u - qq;
+                q[u] = (i < rows_u[u]) ? qq : 255u;
+                uint32_t ql = (uint32_t)(qchunk[u] >> qsh[u]) & 0xFFu; qsh[u] += qstep[u];
+                if (i >= rows_u[u]) ql = 0;
+                S[u] = s_mm[ql < 63u ? ql : 63u];
+                gn[u] = (i + (uint32_t)(BAND - 1) < N[u]) ? (tchunk[u] >> 30) : 255u;
+                tchunk[u] <<= 2;
+            }
 
-        // BestSink: row-major reports, the LAST maximum wins
-        const int k0 = key.x, k1 = key.y;
-        if (i < rows0 && (k0 >> 5) >= best[0]) { best[0] = k0 >> 5; best_x[0] = i + (uint32_t)(k0 & 31) + 1u; best_y[0] = i + 1u; }
-        if (i < rows1 && (k1 >> 5) >= best[1]) { best[1] = k1 >> 5; best_x[1] = i + (uint32_t)(k1 & 31) + 1u; best_y[1] = i + 1u; }
+            // match flags of the 30 cached columns: alignment 0 at bit 63-2j, alignment 1 at bit 62-2j... built as
+            // e(u) at the LOW bit of each 2-bit slot, then alignment 1 moved to the high bit
+            uint64_t e[2];
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                e[u] = 0;
+                if (q[u] < 4u) { const uint64_t x = cache[u] ^ ((uint64_t)q[u] * 0x5555555555555555ull); e[u] = ~(x | (x >> 1)) & 0x5555555555555555ull; }
+            }
+            const uint64_t EQ = e[0] | (e[1] << 1);                  // column j: bits 62-2j (alignment 0), 63-2j (alignment 1)
+
+            const v2s SS = pk( S[0], S[1] );
+            const v2s DV = pk( V - S[0], V - S[1] );
+
+            v2s E = ZERO;
+            v2s key = pk( -1, -1 );
+            #pragma unroll
+            for (int j = 0; j < BAND; ++j)
+            {
+                const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
+                F[j] = f;
+
+                uint32_t eq01;
+                if (j == BAND - 1) eq01 = (gn[0] == q[0] ? 1u : 0u) | (gn[1] == q[1] ? 0x10000u : 0u);
+                else               eq01 = (uint32_t)((EQ >> (62 - 2 * j)) & 1ull) | ((uint32_t)((EQ >> (63 - 2 * j)) & 1ull) << 16);
+                const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
+
+                // everything that does not depend on E first: t = max(f, d, 0); then h = max(t, E) and the
+                // E recurrence E' = max(t + GO, E + max(GO,GE)) (== max(h + GO, E + GE)): two dependent ops per cell
+                v2s tt;
+                if (j == BAND - 1) tt = pk_max( d, ZERO );
+                else               tt = pk_max( pk_max( f, d ), ZERO );
+                const v2s h = (j == 0) ? tt : pk_max( tt, E );
+                key = pk_max( key, h * K32 + pk( j, j ) );
+                H[j] = h;
+                E = (j == 0) ? tt + GO : pk_max( tt + GO, E + GM );
+            }
+
+            // shift the caches by one column and append the new symbols
+            #pragma unroll
+            for (int u = 0; u < 2; ++u) cache[u] = ((cache[u] << 2) & ~0xFull) | ((uint64_t)(gn[u] & 3u) << 4);
+
+            // BestSink: row-major reports, the LAST maximum wins
+            const int k0 = key.x, k1 = key.y;
+            if (i < rows_u[0] && (k0 >> 5) >= best[0]) { best[0] = k0 >> 5; best_x[0] = i + (uint32_t)(k0 & 31) + 1u; best_y[0] = i + 1u; }
+            if (i < rows_u[1] && (k1 >> 5) >= best[1]) { best[1] = k1 >> 5; best_x[1] = i + (uint32_t)(k1 & 31) + 1u; best_y[1] = i + 1u; }
+        }
     }
     #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -313,11 +424,11 @@ static bool packed_local_ok(const SchemeDev& sc, const uint32_t max_read_len)
     return true;
 }
 
-template <int RB, int TBITS_>
+template <int RB>
 static void launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
     const uint32_t pairs = (b.n + 1u) / 2u;
-    hipLaunchKernelGGL( (banded_gotoh_local31_pk_kernel<RB,TBITS_>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
+    hipLaunchKernelGGL( (banded_gotoh_local31_pk_kernel<RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
 }
 
 template <int BAND, int TYPE>
@@ -326,9 +437,8 @@ static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t
 {
     if (BAND == 31 && TYPE == NVBIO_LOCAL && packed_local_ok( sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
     {
-        if      (rbits == 4 && tbits == 2) { launch_pk<4,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
-        else if (rbits == 2 && tbits == 2) { launch_pk<2,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
-        else if (rbits == 8 && tbits == 8) { launch_pk<8,8>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        if      (rbits == 4 && tbits == 2) { launch_pk<4>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        else if (rbits == 2 && tbits == 2) { launch_pk<2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
     }
     const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
 #define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks )

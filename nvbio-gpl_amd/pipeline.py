@@ -91,9 +91,14 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     cands = []
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
+        #    (FMIndexFilter::rank = match + scan; the two halves are called separately so that the
+        #    match kernel can be timed on its own)
         flt = FMIndexFilter()
         e = tick("match_fw" if strand == 0 else "match_rc")
-        n_hits = flt.rank(fmi, qs, flags)
+        ranges = fmi.match(qs, flags)
+        tock(e)
+        e = tick("scan")
+        n_hits = flt.rank_ranges(fmi, ranges)
         tock(e)
         if n_hits == 0:
             continue

@@ -17,4 +17,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_write.json 2> $OUT/${TAG}_write.err
 echo "write done"
+# 4. SQ issue/stall counters (VALU utilisation of the extend kernel) and 5. L2 hit/miss, each in its own pass
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/${TAG}_sq -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_sq.json 2> $OUT/${TAG}_sq.err
+echo "sq done"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_tcc -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_tcc.json 2> $OUT/${TAG}_tcc.err
+echo "tcc done"
 find $OUT -name "*.csv" | head -50

@@ -44,6 +44,18 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if "nvbio_amd" in k:
             pmc.setdefault(k, {})[ctr + "_KiB_mean"] = sum(v) / len(v)
             pmc[k]["launches_" + sub] = len(v)
+# issue / stall / L2 counters (means per launch), for the kernels of the hot path
+for sub in ("sq", "tcc"):
+    files = glob.glob(os.path.join(src, tag + "_" + sub, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(files[0])):
+        agg[row["Kernel_Name"][:120]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, d in agg.items():
+        if "nvbio_amd" in k and any(x in k for x in ("fm_match_kernel", "gotoh", "fm_filter_locate")):
+            for c, v in d.items():
+                pmc.setdefault(k, {})[c + "_mean"] = sum(v) / len(v)
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 
 key = [k for k in pmc if "fm_match_kernel<4, false>" in k]
