@@ -165,6 +165,11 @@ nvbio_status nvbio_fm_rank(nvbio_fm_index_t index, const uint32_t* rows_dev, con
 nvbio_status nvbio_fm_rank4(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
                             uint32_t* out_dev, void* stream);
 
+/* out_dev[i] = basic_inv_psi(fmi, rows_dev[i]): one LF step, the row of the suffix one symbol to the
+ * left (nvbio/fmindex/fmindex_inl.h:286-309); rows_dev == out_dev is allowed */
+nvbio_status nvbio_fm_basic_inv_psi(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
+                                    uint32_t* out_dev, void* stream);
+
 /* pos_dev[i] = text position of SA row rows_dev[i]: nvbio::locate (fmindex_inl.h:360-394).
  * rows_dev == pos_dev is allowed (nvBowtie locates in place, locate_inl.h:113-138). */
 nvbio_status nvbio_fm_locate(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,

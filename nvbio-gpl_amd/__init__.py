@@ -268,6 +268,14 @@ class FMIndex:
                                     _stream_ptr(self.device)))
         return out
 
+    def basic_inv_psi(self, rows):
+        torch = _torch()
+        rows = _dev_tensor(rows, torch.int32, self.device)
+        out = torch.empty(rows.numel(), dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_basic_inv_psi(self._h, _ptr(rows), ctypes.c_uint32(rows.numel()), _ptr(out),
+                                            _stream_ptr(self.device)))
+        return out
+
     def locate(self, rows):
         torch = _torch()
         rows = _dev_tensor(rows, torch.int32, self.device)

@@ -205,6 +205,12 @@ fm_locate_kernel(const DevIndex f, const uint32_t* rows, const uint32_t n, uint3
     }
 }
 __global__ void __launch_bounds__(256)
+fm_inv_psi_kernel(const DevIndex f, const uint32_t* rows, const uint32_t n, uint32_t* out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = lf_step( f, rows[i] );
+}
+__global__ void __launch_bounds__(256)
 fm_lookup_kernel(const DevIndex f, const uint2* __restrict__ jt, const uint32_t n, uint32_t* __restrict__ pos)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -461,6 +467,18 @@ static nvbio_status locate_common(nvbio_fm_index_t index, const uint32_t* rows_d
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     if (pos_dev) hipLaunchKernelGGL( fm_locate_kernel<0>, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, pos_dev, (uint2*)nullptr );
     else         hipLaunchKernelGGL( fm_locate_kernel<1>, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, (uint32_t*)nullptr, (uint2*)jt_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_basic_inv_psi(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n, uint32_t* out_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( rows_dev && out_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_inv_psi_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, idx->dev(), rows_dev, n, out_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

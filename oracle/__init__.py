@@ -104,6 +104,7 @@ class Oracle:
         L.orc_rank.restype = ctypes.c_uint32
         L.orc_dict_rank.restype = ctypes.c_uint32
         L.orc_locate.restype = ctypes.c_uint32
+        L.orc_basic_inv_psi.restype = ctypes.c_uint32
         L.orc_filter_rank.restype = ctypes.c_uint64
         L.orc_mismatch.restype = ctypes.c_int32
         L.orc_popc_2bit.restype = ctypes.c_uint32
@@ -181,6 +182,10 @@ class Oracle:
         self.lib.orc_match_batch(ctypes.byref(v), _p(syms, _u8p), _p(offsets, _u32p), ctypes.c_uint32(n),
                                  ctypes.c_int(1 if reverse else 0), _p(ranges, _u32p), _p(blocks, _u32p))
         return (ranges, blocks) if want_blocks else ranges
+
+    def basic_inv_psi(self, idx, rows):
+        v = idx.view()
+        return np.array([self.lib.orc_basic_inv_psi(ctypes.byref(v), ctypes.c_uint32(int(r))) for r in rows], dtype=np.uint32)
 
     def locate_batch(self, idx, rows):
         v = idx.view()

@@ -52,6 +52,21 @@ def test_rank_every_row_golden(amd, fm_golden):
     fmi.close()
 
 
+def test_basic_inv_psi(amd, orc, fm_golden):
+    """one LF step (fmindex_inl.h:286-309): SA[inv_psi(i)] == SA[i] - 1, and equal to the oracle for every row"""
+    g = fm_golden
+    fmi = _golden_dev_index(amd, g)
+    n = len(g["text"])
+    rows = np.arange(0, n + 1, dtype=np.uint32)
+    got = amd.u32(fmi.basic_inv_psi(rows))
+    idx = oracle.HostIndex(n, int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"])
+    assert np.array_equal(got, orc.basic_inv_psi(idx, rows))
+    sa = g["sa"].astype(np.int64); sa[0] = n
+    nz = sa[rows] > 0
+    assert np.array_equal(sa[got[nz]], sa[rows[nz]] - 1)
+    fmi.close()
+
+
 def test_locate_golden(amd, fm_golden):
     g = fm_golden
     fmi = _golden_dev_index(amd, g)
