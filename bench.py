@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=16, help="k of the k-mer SA-range table (0 disables)")
     ap.add_argument("--sa-int", type=int, default=1, help="SA sampling interval of the index built for the run")
+    ap.add_argument("--verify", action="store_true", help="build the index with the SA/ISA/text verification shortcut (needs --sa-int 1)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +150,7 @@ def main():
     genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
     torch.cuda.synchronize()
     t1 = time.time()
-    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int)
+    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
     torch.cuda.synchronize()
     t2 = time.time()
     log("reference %d symbols generated in %.2fs, index built on the GPU in %.2fs (k-mer table k=%d, %.2f GB owned)"
@@ -244,7 +245,7 @@ def main():
         "config": {"workload": "nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150) else "custom",
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
-                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "sa_int": args.sa_int,
+                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "sa_int": args.sa_int, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,

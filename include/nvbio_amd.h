@@ -103,6 +103,10 @@ typedef struct
     uint32_t kmer_len;   /* k of the k-mer SA-range table, 0..16 (0 = none)                                  */
     uint32_t sa_int;     /* SA sampling interval, power of two in [1,64]; 0 = 16 (the reference's SA_INT)     */
     uint32_t max_lcp;    /* give up on texts with repeats longer than this many symbols; 0 = 4096            */
+    uint32_t verify;     /* 1: also keep the inverse suffix array (4(n+1) bytes) and a copy of the text, so that
+                            match() can finish a search whose range has collapsed to ONE row by comparing the
+                            rest of the pattern with the text at SA[row] and jumping to ISA[position] (3 gathers
+                            instead of one per remaining symbol).  Requires sa_int = 1.  Results are identical. */
 } nvbio_fm_build_options;
 
 nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
@@ -147,7 +151,8 @@ enum
                                     match_range, mapping_inl.h:73-86); default is len-1..0 (match, :181-239) */
     NVBIO_FM_COMPLEMENT   = 2,   /* search the complement (c < 4 ? 3-c : c), as nvBowtie's rc seeds
                                     (mapping_inl.h:264-279)                                                   */
-    NVBIO_FM_NO_KMER_TABLE = 4   /* step every symbol through rank() even if the handle has a table         */
+    NVBIO_FM_NO_KMER_TABLE = 4,  /* step every symbol through rank() even if the handle has a table         */
+    NVBIO_FM_NO_VERIFY     = 8   /* never take the SA/ISA verification shortcut even if the handle has it   */
 };
 
 /* ranges_dev[i] = SA range (inclusive; empty iff x > y) of query i: nvbio::match / match_reverse

@@ -27,7 +27,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
-FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE = 1, 2, 4
+FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY = 1, 2, 4, 8
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 
 _STATUS = {0: "OK", 1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "UNSUPPORTED", 5: "NO_DEVICE"}
@@ -47,7 +47,8 @@ class _View(ctypes.Structure):
 
 
 class _BuildOptions(ctypes.Structure):
-    _fields_ = [("kmer_len", ctypes.c_uint32), ("sa_int", ctypes.c_uint32), ("max_lcp", ctypes.c_uint32)]
+    _fields_ = [("kmer_len", ctypes.c_uint32), ("sa_int", ctypes.c_uint32), ("max_lcp", ctypes.c_uint32),
+                ("verify", ctypes.c_uint32)]
 
 
 class _StringSet(ctypes.Structure):
@@ -191,12 +192,12 @@ class FMIndex:
         return cls(h, device, keep=(b, s))
 
     @classmethod
-    def build(cls, text2, length, kmer_len=0, max_lcp=0, sa_int=16, device="cuda:0"):
+    def build(cls, text2, length, kmer_len=0, max_lcp=0, sa_int=16, verify=False, device="cuda:0"):
         """build the index on the GPU from a 2-bit packed text (nvbio_fm_index_build)"""
         torch = _torch()
         t = _dev_tensor(text2, torch.int32, device)
         h = ctypes.c_void_p()
-        opts = _BuildOptions(kmer_len, sa_int, max_lcp)
+        opts = _BuildOptions(kmer_len, sa_int, max_lcp, 1 if verify else 0)
         _check(lib().nvbio_fm_index_build(_ptr(t), ctypes.c_uint32(length), cls._dev_index(device),
                                           ctypes.byref(opts), _stream_ptr(device), ctypes.byref(h)))
         return cls(h, device, keep=(t,))

@@ -26,7 +26,8 @@
 
 namespace nvbio_amd {
 
-nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out);
+nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out,
+                            uint32_t* isa, uint32_t* text);
 
 namespace {
 
@@ -157,6 +158,17 @@ __global__ void __launch_bounds__(256)
 gather_u_kernel(const uint32_t* __restrict__ U, const uint32_t* __restrict__ sel, const uint32_t m2, uint32_t* __restrict__ U2)
 {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < m2; k += gridDim.x * blockDim.x) U2[k] = U[sel[k]];
+}
+
+// inverse suffix array over the rows of the full BWT matrix: isa[sa[s]] = s + 1, isa[n] = 0
+__global__ void __launch_bounds__(256)
+isa_kernel(const uint32_t* __restrict__ sa, const uint64_t n, uint32_t* __restrict__ isa)
+{
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n; s += (uint64_t)gridDim.x * blockDim.x)
+    {
+        if (s == n) isa[n] = 0u;
+        else        isa[sa[s]] = (uint32_t)s + 1u;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -309,7 +321,7 @@ static nvbio_status sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* 
 }
 
 static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, const int device, const uint32_t kmer_len,
-                               const uint32_t sa_int, uint32_t max_lcp, hipStream_t s, nvbio_fm_index_t* out)
+                               const uint32_t sa_int, uint32_t max_lcp, const bool verify, hipStream_t s, nvbio_fm_index_t* out)
 {
     Scratch scratch;
     if (max_lcp == 0) max_lcp = 4096;
@@ -459,6 +471,16 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     NVB_ALLOC( ssa,     uint32_t, n_ssa );
     hipLaunchKernelGGL( bwt_words_kernel, dim3( grid_for( words ) ), dim3(256), 0, s, t, (const uint32_t*)sa, (const uint32_t*)d_primary, words, bwt_occ, (uint4*)nullptr );
     hipLaunchKernelGGL( ssa_kernel, dim3( grid_for( n_ssa ) ), dim3(256), 0, s, (const uint32_t*)sa, sa_int, n_ssa, ssa );
+    uint32_t* isa = nullptr; uint32_t* text_copy = nullptr;
+    if (verify)
+    {
+        NVB_ALLOC( isa_, uint32_t, (size_t)n + 1u );
+        NVB_ALLOC( txt_, uint32_t, (size_t)t.n_words + 4u );
+        hipLaunchKernelGGL( isa_kernel, dim3( grid_for( (uint64_t)n + 1u ) ), dim3(256), 0, s, (const uint32_t*)sa, (uint64_t)n, isa_ );
+        NVB_HIP( hipMemsetAsync( txt_ + t.n_words, 0, 4u * sizeof(uint32_t), s ) );
+        NVB_HIP( hipMemcpyAsync( txt_, text2_dev, (size_t)t.n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s ) );
+        isa = isa_; text_copy = txt_;
+    }
     NVB_HIP( hipGetLastError() );
     NVB_HIP( hipStreamSynchronize( s ) );
     scratch.release( sa );
@@ -494,7 +516,8 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
         return NVBIO_ERR_HIP;
     }
     scratch.forget( bwt_occ ); scratch.forget( ssa );           // ownership moves to the handle
-    return fm_index_adopt( &view, device, kmer_len, true, s, out );
+    if (isa) { scratch.forget( isa ); scratch.forget( text_copy ); }
+    return fm_index_adopt( &view, device, kmer_len, true, s, out, isa, text_copy );
 }
 
 } // anonymous namespace
@@ -513,6 +536,8 @@ extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t
     const uint32_t max_lcp  = options ? options->max_lcp : 0u;
     NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
     NVB_REQUIRE( sa_int <= 64 && (sa_int & (sa_int - 1u)) == 0, "sa_int must be a power of two in [1,64]" );
+    const bool verify = options && options->verify;
+    NVB_REQUIRE( !verify || sa_int == 1, "verify needs the full suffix array (sa_int = 1)" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    return build_impl( text2_dev, length, device, kmer_len, sa_int, max_lcp, (hipStream_t)stream, out );
+    return build_impl( text2_dev, length, device, kmer_len, sa_int, max_lcp, verify, (hipStream_t)stream, out );
 }

@@ -26,6 +26,8 @@ struct DevIndex
     uint32_t        sa_log;   // log2 of the SA sampling interval (4 in the reference's layout)
     const uint2*    ktab;     // optional: SA range of every kmer-mer (in scan order), or NULL
     uint32_t        kmer;
+    const uint32_t* isa;      // optional (with a full SA): isa[p] = row of suffix p, isa[length] = 0
+    const uint32_t* text;     // optional: the 2-bit packed text the index was built from
 };
 
 __device__ __forceinline__ uint32_t pick4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t i)

@@ -33,6 +33,8 @@ struct FMIndexImpl
     uint32_t             kmer;
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
+    uint32_t*            isa;         // owned, optional (verify mode)
+    uint32_t*            text;        // owned, optional (verify mode)
 
     DevIndex dev() const
     {
@@ -43,6 +45,7 @@ struct FMIndexImpl
         d.ssa  = view.ssa_dev;
         d.sa_log = 0; while ((1u << d.sa_log) < (view.sa_int ? view.sa_int : 16u)) ++d.sa_log;
         d.ktab = ktab; d.kmer = kmer;
+        d.isa = isa; d.text = text;
         return d;
     }
 };
@@ -85,6 +88,7 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
     const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
     const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
     const bool tab  = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
+    const bool verify = (f.isa != nullptr) && (f.sa_log == 0) && !(flags & NVBIO_FM_NO_VERIFY) && !COUNT;
 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x)
     {
@@ -114,6 +118,31 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
 
         for (; s < len && x <= y; ++s)
         {
+            if (verify && x == y && len - s >= 2u)
+            {
+                // The range is ONE row: the match can only continue along the text to the left of
+                // SA[x].  Compare the rest of the pattern with the text there and jump to the row of
+                // the position reached (ISA): 3 gathers instead of one per remaining symbol.  On a
+                // mismatch the loop resumes at the offending symbol from the exact row the reference
+                // would be at, so the (empty) range it returns is the reference's.
+                const uint32_t sv = f.ssa[x];
+                const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
+                const uint32_t r  = len - s;
+                // the row reached if everything matches is requested together with the text words
+                // (speculatively: both depend only on p), so the tail costs two dependent rounds
+                const uint32_t full = (p >= r) ? f.isa[p - r] : 0u;
+                SymbolReader<2> tr( f.text );
+                uint32_t t = 0;
+                while (t < r && t < p)
+                {
+                    const uint32_t c = sym( s + t );
+                    if (c > 3u || c != tr.get( p - 1u - t )) break;
+                    ++t;
+                }
+                if (t == r)  { x = y = full; s = len; }
+                else if (t)  { x = y = f.isa[p - t]; s += t; }
+                if (s >= len) break;
+            }
             const uint32_t c = sym( s );
             if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
             search_step<COUNT>( f, x, y, c, nblk );
@@ -327,17 +356,23 @@ static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t s
     return NVBIO_OK;
 }
 
-nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out)
+nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out,
+                            uint32_t* isa, uint32_t* text)
 {
     FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
-    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0;
+    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->isa = nullptr; idx->text = nullptr;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
+    idx->isa = isa; idx->text = text;
+    if (isa)  idx->owned_bytes += ((uint64_t)view->length + 1u) * 4ull;
+    if (text) idx->owned_bytes += (((uint64_t)view->length + 15u) / 16u) * 4ull;
     const nvbio_status st = build_kmer_table( idx, kmer_len, stream );
     if (st != NVBIO_OK)
     {
         if (owns) { (void)hipFree( (void*)view->bwt_occ_dev ); (void)hipFree( (void*)view->ssa_dev ); }
+        if (isa)  (void)hipFree( isa );
+        if (text) (void)hipFree( text );
         delete idx;
         return st;
     }
@@ -365,7 +400,7 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
     NVB_REQUIRE( view->bwt_occ_words >= need, "bwt_occ_words too small for length" );
     NVB_REQUIRE( view->ssa_dev == nullptr || view->ssa_words >= (uint64_t)view->length / K + 1u, "ssa_words too small for length" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out );
+    return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out, nullptr, nullptr );
 }
 
 nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
@@ -374,6 +409,8 @@ nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
     FMIndexImpl* idx = (FMIndexImpl*)index;
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     if (idx->ktab) (void)hipFree( idx->ktab );
+    if (idx->isa)  (void)hipFree( idx->isa );
+    if (idx->text) (void)hipFree( idx->text );
     if (idx->owns_arrays) { (void)hipFree( (void*)idx->view.bwt_occ_dev ); (void)hipFree( (void*)idx->view.ssa_dev ); }
     delete idx;
     return NVBIO_OK;

@@ -108,3 +108,52 @@ def test_denser_and_sparser_sa_sampling_gives_the_same_positions(amd, orc, sa_in
     assert flt.rank(fmi, amd.PackedStringSet(syms, 8, 5000, offsets=offs, ranges=True)) == total
     assert np.array_equal(amd.u32(flt.locate(0, total)), orc.filter_locate(hidx, ranges, slots, 0, total))
     fmi.close()
+
+
+@pytest.mark.parametrize("k", [0, 6, 9])
+def test_sa_isa_verification_shortcut_is_exact(amd, orc, k):
+    """verify mode (full SA + ISA + text copy): a search whose range has collapsed to one row is
+    finished by comparing the pattern with the text; ranges must stay bit-identical to the
+    reference's, for hits, for misses at every remaining position, for N's, for patterns that run
+    off the start of the text, in both scan directions and with the complement flag"""
+    from util import make_queries
+    rng = np.random.default_rng(31 + k)
+    n = 150001
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[5000:5600] = np.tile(np.array([1, 1, 2, 0, 3], dtype=np.uint8), 120)      # repeats: wide ranges that collapse late
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, verify=True)
+    Q = 30000
+    syms, offs = make_queries(rng, text, Q, 2, 40, hit_every=1)
+    # break a third of the hits at a random position (a miss somewhere in the middle)
+    for q in range(0, Q, 3):
+        pos = int(rng.integers(offs[q], offs[q + 1]))
+        syms[pos] = (syms[pos] + 1 + rng.integers(0, 3)) % 4
+    syms[rng.integers(0, len(syms), 300)] = 4
+    # patterns that extend past the start of the text: X + text[0:m]
+    for q in range(1, 400, 4):
+        L = offs[q + 1] - offs[q]
+        if L > 6:
+            m = int(rng.integers(3, L - 2))
+            syms[offs[q + 1] - m:offs[q + 1]] = text[:m]
+    # ... and past its end (forward scans): text[n-m:] + X
+    for q in range(2, 400, 4):
+        L = offs[q + 1] - offs[q]
+        if L > 6:
+            m = int(rng.integers(3, L - 2))
+            syms[offs[q]:offs[q] + m] = text[n - m:]
+    comp = np.where(syms < 4, 3 - syms, syms).astype(np.uint8)
+    for bits, packed in ((8, syms), (4, orc.pack4(syms))):
+        qs = amd.PackedStringSet(packed, bits, Q, offsets=offs, ranges=True)
+        want = orc.match_batch(hidx, syms, offs)
+        assert np.array_equal(amd.u32(fmi.match(qs)), want)
+        assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_NO_VERIFY)), want)
+        assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_SCAN_FORWARD)), orc.match_batch(hidx, syms, offs, reverse=True))
+        assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_COMPLEMENT)), orc.match_batch(hidx, comp, offs))
+        assert np.array_equal(amd.u32(fmi.match(qs, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT)),
+                              orc.match_batch(hidx, comp, offs, reverse=True))
+    rows = rng.integers(0, n + 1, 20000).astype(np.uint32)
+    assert np.array_equal(amd.u32(fmi.locate(rows)), orc.locate_batch(hidx, rows))
+    fmi.close()
+    with pytest.raises(amd.NvbioError):
+        amd.FMIndex.build(orc.pack2(text), n, sa_int=16, verify=True)
