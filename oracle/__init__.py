@@ -292,6 +292,7 @@ class Reference:
     def __init__(self):
         self.lib = L = ctypes.CDLL(os.path.join(_HERE, "_ref", "libnvbio_ref.so"))
         L.ref_fm_create.restype = ctypes.c_void_p
+        L.ref_fm_adopt.restype = ctypes.c_void_p
         L.ref_fm_primary.restype = ctypes.c_uint32
         L.ref_fm_words.restype = ctypes.c_uint32
         L.ref_fm_ssa_words.restype = ctypes.c_uint32
@@ -311,6 +312,30 @@ class Reference:
         idx = HostIndex(n, self.lib.ref_fm_primary(h), L2, bwt_occ, ssa, sa=sa.view(np.uint32), text=text)
         idx.handle = h
         return idx
+
+    def adopt_index(self, hidx):
+        """hand an index held in numpy arrays (e.g. built on the GPU) to the reference's host code"""
+        h = ctypes.c_void_p(self.lib.ref_fm_adopt(
+            ctypes.c_uint32(hidx.n), ctypes.c_uint32(hidx.primary), _p(_c32(hidx.L2), _u32p), _p(hidx.bwt_occ, _u32p),
+            ctypes.c_uint64(len(hidx.bwt_occ)), _p(hidx.ssa, _u32p), ctypes.c_uint64(len(hidx.ssa))))
+        hidx.handle = h
+        return hidx
+
+    def num_threads(self):
+        return int(self.lib.ref_num_threads())
+
+    def banded_gotoh_batch(self, band, typ, scheme, pats, pat_off, txts, txt_off, quals=None):
+        pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)
+        pat_off, txt_off = _c32(pat_off), _c32(txt_off)
+        n = len(pat_off) - 1
+        arr = scheme.as_array()
+        scores = np.zeros(n, dtype=np.int32)
+        sinks = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.ref_banded_gotoh_ex_batch(ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pats, _u8p),
+                                           _p(quals, _u8p), _p(pat_off, _u32p), _p(txts, _u8p), _p(txt_off, _u32p),
+                                           ctypes.c_uint32(n), ctypes.c_int32(SCORE_MIN), _p(scores, _i32p),
+                                           _p(sinks, _u32p))
+        return scores, sinks
 
     def destroy(self, idx):
         self.lib.ref_fm_destroy(idx.handle)

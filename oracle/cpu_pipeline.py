@@ -21,6 +21,91 @@ def revcomp(a):
     return (3 - a[..., ::-1]).astype(np.uint8) if (a <= 3).all() else np.where(a[..., ::-1] < 4, 3 - a[..., ::-1], a[..., ::-1]).astype(np.uint8)
 
 
+def unpack2(words, begin, length):
+    """2-bit big-endian packed words -> symbols [begin, begin+length) (vectorised)"""
+    idx = begin + np.arange(length, dtype=np.int64)
+    return ((words[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
+
+
+def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, seed_interval=None, band=31, aln_type=LOCAL,
+                        scheme=None, timing=None):
+    """The same composition run through the REFERENCE's own host code (oracle/_ref): match() and
+    locate() in an OpenMP parallel for, banded_alignment_score<31> in an OpenMP parallel for.  The
+    index arithmetic between them is numpy, as in seed_and_extend_cpu; unpacking the strings the
+    reference's templates consume one symbol per byte is not counted in timing["ref_seconds"]."""
+    import time
+    scheme = scheme or Scheme(2, 2, 6, -8, -3, -8, -3)
+    R, M = reads.shape
+    L = seed_len
+    S_int = seed_interval or int(1 + 1.15 * math.sqrt(M))
+    spr = (M - L) // S_int + 1
+    starts = np.arange(spr) * S_int
+    t_ref = 0.0
+    cands = []
+    for strand in (0, 1):
+        seeds = np.stack([reads[:, s:s + L] for s in starts], axis=1)
+        if strand:
+            seeds = np.where(seeds[..., ::-1] < 4, 3 - seeds[..., ::-1], seeds[..., ::-1]).astype(np.uint8)
+        flat = np.ascontiguousarray(seeds.reshape(-1))
+        offs = (np.arange(R * spr + 1) * L).astype(np.uint32)
+        t0 = time.perf_counter()
+        ranges = Rf.match_batch(ridx, flat, offs)
+        t_ref += time.perf_counter() - t0
+        sizes = np.where(ranges[:, 1] >= ranges[:, 0], ranges[:, 1].astype(np.int64) + 1 - ranges[:, 0], 0)
+        total = int(sizes.sum())
+        if total == 0:
+            continue
+        sid = np.repeat(np.arange(R * spr, dtype=np.int64), sizes)
+        first = np.repeat(ranges[:, 0].astype(np.int64), sizes)
+        local = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+        t0 = time.perf_counter()
+        pos = Rf.locate_batch(ridx, (first + local).astype(np.uint32)).astype(np.int64)
+        t_ref += time.perf_counter() - t0
+        rid = sid // spr
+        p = (sid - rid * spr) * S_int
+        if strand:
+            p = M - p - L
+        cands.append((rid << 34) | (strand << 33) | (pos - p + 1024))
+    best_score = np.full(R, SCORE_MIN, dtype=np.int32)
+    best_pos = np.full(R, -1, dtype=np.int64)
+    best_rc = np.zeros(R, dtype=np.uint8)
+    if not cands:
+        return best_score, best_pos, best_rc, 0
+    keys = np.unique(np.concatenate(cands))
+    C = len(keys)
+    rid = keys >> 34
+    rc = (keys >> 33) & 1
+    diag = (keys & ((1 << 33) - 1)) - 1024
+    g_pos = np.maximum(diag, 0)
+    half = band // 2
+    wb = np.where(g_pos > half, g_pos - half, 0)
+    we = np.minimum(wb + band + M, genome_len)
+    # strings one symbol per byte, as the reference's vector_view<const uint8*> strings
+    pats = reads[rid]
+    rcm = rc.astype(bool)
+    pats[rcm] = np.where(pats[rcm][:, ::-1] < 4, 3 - pats[rcm][:, ::-1], pats[rcm][:, ::-1])
+    tl = (we - wb).astype(np.int64)
+    toff = np.zeros(C + 1, dtype=np.uint32); toff[1:] = np.cumsum(tl)
+    tidx = np.repeat(wb, tl) + (np.arange(int(toff[-1]), dtype=np.int64) - np.repeat(toff[:-1].astype(np.int64), tl))
+    txts = ((genome2[tidx >> 4] >> (30 - 2 * (tidx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
+    poff = (np.arange(C + 1) * M).astype(np.uint32)
+    t0 = time.perf_counter()
+    scores, sinks = Rf.banded_gotoh_batch(band, aln_type, scheme, np.ascontiguousarray(pats.reshape(-1)), poff, txts, toff)
+    t_ref += time.perf_counter() - t0
+    pos = wb.astype(np.int64) + sinks[:, 0].astype(np.int64)
+    packed = (np.maximum(scores.astype(np.int64) + (1 << 20), 0) << 34) | (rc.astype(np.int64) << 33) | pos
+    top = np.full(R, -1, dtype=np.int64)
+    np.maximum.at(top, rid, packed)
+    has = top >= 0
+    sv = top >> 34
+    best_score = np.where(has & (sv > 0), sv - (1 << 20), best_score).astype(np.int32)
+    best_pos = np.where(has, top & ((1 << 33) - 1), best_pos)
+    best_rc = np.where(has, (top >> 33) & 1, best_rc).astype(np.uint8)
+    if timing is not None:
+        timing["ref_seconds"] = t_ref
+    return best_score, best_pos, best_rc, C
+
+
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
                         aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False):
     """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates)."""

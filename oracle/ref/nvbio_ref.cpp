@@ -36,6 +36,9 @@
 #include <vector>
 #include <cstring>
 #include <cstdint>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace nvbio;
 
@@ -244,6 +247,31 @@ void* ref_fm_create(const uint8_t* text_bytes, uint32_t n)
     return idx;
 }
 
+// Adopt an index built elsewhere (e.g. on the GPU by nvbio_fm_index_build) in the reference's
+// production layout, so that the reference's own host code can be run -- and timed -- on it.
+void* ref_fm_adopt(uint32_t n, uint32_t primary, const uint32_t* L2, const uint32_t* bwt_occ, uint64_t bwt_occ_words,
+                   const uint32_t* ssa, uint64_t ssa_words)
+{
+    RefIndex* idx = new RefIndex;
+    idx->n = n; idx->primary = primary;
+    for (int c = 0; c < 5; ++c) idx->L2[c] = L2[c];
+    idx->bwt_occ.assign( bwt_occ, bwt_occ + bwt_occ_words );
+    idx->ssa.assign( ssa, ssa + ssa_words );
+    idx->occ.resize( bwt_occ_words / 2 );
+    idx->count_table.resize( 256 );
+    gen_bwt_count_table( &idx->count_table[0] );
+    return idx;
+}
+
+int ref_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 void ref_fm_destroy(void* h) { delete (RefIndex*)h; }
 
 uint32_t ref_fm_primary(void* h) { return ((RefIndex*)h)->primary; }
@@ -376,6 +404,23 @@ void ref_banded_gotoh_batch(uint32_t band, int type, int match, int mm, int gap_
     {
         ref_banded_gotoh( band, type, match, mm, gap_open, gap_ext,
             pats + pat_off[i], pat_off[i+1] - pat_off[i],
+            txts + txt_off[i], txt_off[i+1] - txt_off[i],
+            min_score, scores + i, sinks + 2*i );
+    }
+}
+
+// general-scheme batch: the host path of BatchedBandedAlignmentScore<BAND,stream,HostThreadScheduler>
+// (an OpenMP parallel for over banded_alignment_score, nvbio/alignment/batched_banded_inl.h:113-121)
+void ref_banded_gotoh_ex_batch(uint32_t band, int type, const int32_t* sc,
+                               const uint8_t* pats, const uint8_t* quals, const uint32_t* pat_off,
+                               const uint8_t* txts, const uint32_t* txt_off, uint32_t n,
+                               int32_t min_score, int32_t* scores, uint32_t* sinks)
+{
+    #pragma omp parallel for
+    for (int64 i = 0; i < int64(n); ++i)
+    {
+        ref_banded_gotoh_ex( band, type, sc,
+            pats + pat_off[i], quals ? quals + pat_off[i] : NULL, pat_off[i+1] - pat_off[i],
             txts + txt_off[i], txt_off[i+1] - txt_off[i],
             min_score, scores + i, sinks + 2*i );
     }
