@@ -269,7 +269,7 @@ def main():
     #   the development container; the .so travels with the snapshot) -- match() / locate() /
     #   banded_alignment_score<31> under OpenMP, run on the index the GPU built;
     # kind "port": the oracle's C restatement, when oracle/_ref is not there.
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         from oracle import cpu_pipeline
         O = oracle.Oracle()

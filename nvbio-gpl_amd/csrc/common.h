@@ -85,51 +85,4 @@ struct SymbolReader<8>
     __device__ __forceinline__ uint32_t get(uint32_t i) { return bytes[i]; }
 };
 
-// Sequential reader with a one-word look-ahead: the DP kernels walk a read / a text window one symbol
-// per row, so the next word is requested when the current one is first used (8 or 16 rows before it
-// is needed) and its HBM/L2 latency overlaps the row arithmetic instead of stalling the wave.
-// [lo, hi] are the first and last symbol indices that may be touched: the look-ahead never reads a
-// word outside them.
-template <int BITS>
-struct SeqSymbolReader
-{
-    static constexpr uint32_t LOG = (BITS == 2) ? 4 : 3;
-    const uint32_t* words;
-    uint32_t        cur_idx, lim_w;       // current word, last word in the walking direction
-    uint32_t        cur, nxt;
-    bool            back;
-    __device__ __forceinline__ uint32_t ahead(const uint32_t w) const
-    {
-        // the neighbour of w in the walking direction, never past the last word that may be touched
-        return back ? (w > lim_w ? w - 1u : lim_w) : (w < lim_w ? w + 1u : lim_w);
-    }
-    // first: first symbol read; last: last symbol that may be read (first >= last when walking backwards)
-    __device__ __forceinline__ void init(const void* p, const uint32_t first, const uint32_t last, const bool backward)
-    {
-        words = (const uint32_t*)p; back = backward;
-        lim_w = last >> LOG;
-        cur_idx = first >> LOG;
-        cur = words[cur_idx];
-        nxt = words[ahead( cur_idx )];
-    }
-    __device__ __forceinline__ uint32_t get(const uint32_t i)
-    {
-        const uint32_t w = i >> LOG;
-        if (w != cur_idx)
-        {
-            // sequential by construction: w is the neighbour of cur_idx in the walking direction
-            cur = nxt; cur_idx = w;
-            nxt = words[ahead( w )];
-        }
-        return (cur >> ((32u - BITS) - BITS * (i & ((1u << LOG) - 1u)))) & ((1u << BITS) - 1u);
-    }
-};
-template <>
-struct SeqSymbolReader<8>
-{
-    const uint8_t* bytes;
-    __device__ __forceinline__ void init(const void* p, uint32_t, uint32_t, bool) { bytes = (const uint8_t*)p; }
-    __device__ __forceinline__ uint32_t get(const uint32_t i) { return bytes[i]; }
-};
-
 } // namespace nvbio_amd

@@ -64,3 +64,28 @@ def test_gotoh_fuzz(orc, ref):
             ms = oracle.SCORE_MIN if it % 3 else int(rng.integers(-50, 200))
             for blk in range(2):
                 assert ref.full_gotoh(typ, blk, sc, pat, txt, quals, ms) == orc.full_gotoh(typ, blk, sc, pat, txt, quals, ms)
+
+
+def test_whole_path_oracle_equals_reference_code(orc, ref):
+    """the CPU composition used as bench.py's baseline: the oracle's functions and the reference's own
+    host templates (on an adopted index) give the same best alignment for every read"""
+    from oracle import cpu_pipeline
+    rng = np.random.default_rng(3)
+    G = 300000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    text[1000:1500] = text[200000:200500]
+    hidx = orc.build_index(text)
+    ridx = ref.adopt_index(oracle.HostIndex(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa))
+    R, M = 2000, 150
+    starts = rng.integers(0, G - M, R)
+    starts[:40] = rng.integers(1000, 1300, 40)
+    reads = np.stack([text[s:s + M] for s in starts]).copy()
+    reads[rng.random(reads.shape) < 0.02] = 2
+    rc = rng.random(R) < 0.5
+    reads[rc] = 3 - reads[rc][:, ::-1]
+    a = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads)
+    b = cpu_pipeline.seed_and_extend_ref(ref, orc, ridx, orc.pack2(text), G, reads)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert a[3] == b[3]
+    ref.destroy(ridx)
