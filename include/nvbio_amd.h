@@ -113,6 +113,18 @@ nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, in
                                   const nvbio_fm_build_options* options /* NULL = defaults */,
                                   void* stream, nvbio_fm_index_t* out);
 
+/* Load an index from the reference's on-disk files (written by nvBWT, nvBWT/nvBWT.cu:303-342; read by
+ * io::FMIndexDataHost::load, nvbio/io/fmindex/fmindex_impl.cu:111-252,333-...):
+ *   <bwt_path>  uint32 primary; uint32 cumulative symbol counts[4] (last = n); packed 2-bit BWT words
+ *   <sa_path>   uint32 primary; uint32 counts[4]; uint32 SA_INT; uint32 n; ssa[1..]   (optional, may be NULL)
+ * The occurrence table is rebuilt and interleaved on the GPU (the reference does it on the host,
+ * fmindex_impl.cu:254-331).  All arrays are owned by the handle. */
+nvbio_status nvbio_fm_index_load(const char* bwt_path, const char* sa_path, int device, uint32_t kmer_len,
+                                 void* stream, nvbio_fm_index_t* out);
+/* Write the index in those formats (the role of nvBWT for indices built by nvbio_fm_index_build);
+ * sa_path may be NULL.  The reference's reader accepts .sa files with SA_INT = 16 only. */
+nvbio_status nvbio_fm_index_save(nvbio_fm_index_t index, const char* bwt_path, const char* sa_path, void* stream);
+
 nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index);
 nvbio_status nvbio_fm_index_get_view(nvbio_fm_index_t index, nvbio_fm_index_view* view);
 /* copy the index arrays into caller buffers in HBM (either may be NULL); sizes from get_view */

@@ -202,6 +202,20 @@ class FMIndex:
                                           ctypes.byref(opts), _stream_ptr(device), ctypes.byref(h)))
         return cls(h, device, keep=(t,))
 
+    @classmethod
+    def load(cls, bwt_path, sa_path=None, kmer_len=0, device="cuda:0"):
+        """load the reference's .bwt / .sa files (io::FMIndexDataHost::load, fmindex_impl.cu:333-...)"""
+        h = ctypes.c_void_p()
+        _check(lib().nvbio_fm_index_load(bwt_path.encode(), sa_path.encode() if sa_path else None,
+                                         cls._dev_index(device), ctypes.c_uint32(kmer_len), _stream_ptr(device),
+                                         ctypes.byref(h)))
+        return cls(h, device)
+
+    def save(self, bwt_path, sa_path=None):
+        """write the index in the reference's .bwt / .sa formats (the role of nvBWT)"""
+        _check(lib().nvbio_fm_index_save(self._h, bwt_path.encode(), sa_path.encode() if sa_path else None,
+                                         _stream_ptr(self.device)))
+
     def close(self):
         if self._h is not None:
             _torch().cuda.synchronize(self.device)

@@ -23,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 #include <vector>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace nvbio_amd {
 
@@ -520,10 +521,156 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     return fm_index_adopt( &view, device, kmer_len, true, s, out, isa, text_copy );
 }
 
+// BWT words (plain, 16 symbols per word) <-> the BWT half of the interleaved 32-byte records
+__global__ void __launch_bounds__(256)
+interleave_bwt_kernel(const uint32_t* __restrict__ bwt, const uint32_t n_words, const uint32_t n_words_padded, uint32_t* __restrict__ bwt_occ)
+{
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words_padded; w += gridDim.x * blockDim.x)
+        bwt_occ[(size_t)(w >> 2) * 8u + (w & 3u)] = w < n_words ? bwt[w] : 0u;
+}
+__global__ void __launch_bounds__(256)
+deinterleave_bwt_kernel(const uint32_t* __restrict__ bwt_occ, const uint32_t n_words, uint32_t* __restrict__ bwt)
+{
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += gridDim.x * blockDim.x)
+        bwt[w] = bwt_occ[(size_t)(w >> 2) * 8u + (w & 3u)];
+}
+
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose( f ); } };
+
+static nvbio_status load_impl(const char* bwt_path, const char* sa_path, const int device, const uint32_t kmer_len,
+                              hipStream_t s, nvbio_fm_index_t* out)
+{
+    Scratch scratch;
+    // ---- .bwt: primary, cumulative counts (the last is the length), packed words (fmindex_impl.cu:111-170) ----
+    FileCloser bf = { fopen( bwt_path, "rb" ) };
+    if (!bf.f) { set_error( "unable to open bwt \"%s\"", bwt_path ); return NVBIO_ERR_INVALID; }
+    uint32_t hdr[5];
+    if (fread( hdr, sizeof(uint32_t), 5, bf.f ) != 5) { set_error( "failed reading bwt header \"%s\"", bwt_path ); return NVBIO_ERR_INVALID; }
+    const uint32_t primary = hdr[0], n = hdr[4];
+    if (n == 0 || primary > n) { set_error( "bad bwt header in \"%s\" (length %u, primary %u)", bwt_path, n, primary ); return NVBIO_ERR_INVALID; }
+    const uint32_t n_words = (n + 15u) / 16u;
+    const uint32_t words   = (n_words + 3u) & ~3u;
+    const uint32_t n_blocks = words / 4u;
+    std::vector<uint32_t> h_bwt( words, 0u );
+    const size_t got = fread( h_bwt.data(), sizeof(uint32_t), words, bf.f );
+    if (((got + 3u) & ~(size_t)3u) != words) { set_error( "failed reading bwt \"%s\" (%zu of %u words)", bwt_path, got, n_words ); return NVBIO_ERR_INVALID; }
+    // clear whatever follows the last symbol (the reference's builder leaves a stale (n+1)-th symbol there)
+    if (n & 15u) h_bwt[n_words - 1u] &= ~0u << (32u - 2u * (n & 15u));
+    for (uint32_t w = n_words; w < words; ++w) h_bwt[w] = 0u;
+
+    NVB_ALLOC( d_bwt, uint32_t, words );
+    NVB_ALLOC( bwt_occ, uint32_t, (size_t)words * 2u );
+    NVB_HIP( hipMemcpyAsync( d_bwt, h_bwt.data(), (size_t)words * sizeof(uint32_t), hipMemcpyHostToDevice, s ) );
+    hipLaunchKernelGGL( interleave_bwt_kernel, dim3( grid_for( words ) ), dim3(256), 0, s, (const uint32_t*)d_bwt, n_words, words, bwt_occ );
+
+    // ---- occurrence table (K = 64) on the GPU: per-record counts, exclusive scan, interleave (fmindex_impl.cu:254-331) ----
+    NVB_ALLOC( cnt, uint4, (size_t)n_blocks + 1u );
+    NVB_ALLOC( occ, uint4, (size_t)n_blocks + 1u );
+    hipLaunchKernelGGL( block_counts_kernel, dim3( grid_for( n_blocks ) ), dim3(256), 0, s, (const uint32_t*)bwt_occ, n, n_blocks, cnt );
+    NVB_HIP( hipMemsetAsync( cnt + n_blocks, 0, sizeof(uint4), s ) );
+    {
+        size_t temp_bytes = 0;
+        NVB_HIP( rocprim::exclusive_scan( nullptr, temp_bytes, cnt, occ, make_uint4( 0, 0, 0, 0 ), (size_t)n_blocks + 1u, AddU4(), s ) );
+        NVB_ALLOC( temp, uint8_t, temp_bytes );
+        NVB_HIP( rocprim::exclusive_scan( temp, temp_bytes, cnt, occ, make_uint4( 0, 0, 0, 0 ), (size_t)n_blocks + 1u, AddU4(), s ) );
+        NVB_HIP( hipStreamSynchronize( s ) );
+        scratch.release( temp );
+    }
+    hipLaunchKernelGGL( write_occ_kernel, dim3( grid_for( n_blocks ) ), dim3(256), 0, s, (const uint4*)occ, n_blocks, bwt_occ );
+    uint4 totals;
+    NVB_HIP( hipMemcpyAsync( &totals, occ + n_blocks, sizeof(uint4), hipMemcpyDeviceToHost, s ) );
+    NVB_HIP( hipStreamSynchronize( s ) );
+
+    nvbio_fm_index_view view;
+    view.length = n; view.primary = primary;
+    view.L2[0] = 0; view.L2[1] = totals.x; view.L2[2] = view.L2[1] + totals.y; view.L2[3] = view.L2[2] + totals.z; view.L2[4] = view.L2[3] + totals.w;
+    if (view.L2[4] != n) { set_error( "bwt \"%s\": symbol counts do not add up to the length", bwt_path ); return NVBIO_ERR_INVALID; }
+    view.bwt_occ_dev = bwt_occ; view.bwt_occ_words = (uint64_t)words * 2u;
+    view.ssa_dev = nullptr; view.ssa_words = 0; view.sa_int = 16;
+
+    // ---- .sa: primary, counts, SA_INT, length, ssa[1..] (fmindex_impl.cu:172-252) ----
+    uint32_t* ssa = nullptr;
+    if (sa_path)
+    {
+        FileCloser sf = { fopen( sa_path, "rb" ) };
+        if (!sf.f) { set_error( "unable to open sa \"%s\"", sa_path ); return NVBIO_ERR_INVALID; }
+        uint32_t sh[7];
+        if (fread( sh, sizeof(uint32_t), 7, sf.f ) != 7) { set_error( "failed reading sa header \"%s\"", sa_path ); return NVBIO_ERR_INVALID; }
+        if (sh[0] != primary || sh[6] != n) { set_error( "SA file mismatch \"%s\" (primary %u/%u, length %u/%u)", sa_path, sh[0], primary, sh[6], n ); return NVBIO_ERR_INVALID; }
+        const uint32_t K = sh[5];
+        if (K == 0 || K > 64 || (K & (K - 1u))) { set_error( "unsupported SA interval %u in \"%s\"", K, sa_path ); return NVBIO_ERR_UNSUPPORTED; }
+        const uint64_t sa_size = (uint64_t)n / K + 1u;
+        std::vector<uint32_t> h_ssa( sa_size );
+        h_ssa[0] = 0xFFFFFFFFu;
+        if (sa_size > 1 && fread( &h_ssa[1], sizeof(uint32_t), sa_size - 1u, sf.f ) != sa_size - 1u) { set_error( "failed reading sa \"%s\"", sa_path ); return NVBIO_ERR_INVALID; }
+        NVB_ALLOC( d_ssa, uint32_t, sa_size );
+        NVB_HIP( hipMemcpyAsync( d_ssa, h_ssa.data(), sa_size * sizeof(uint32_t), hipMemcpyHostToDevice, s ) );
+        NVB_HIP( hipStreamSynchronize( s ) );
+        ssa = d_ssa;
+        view.ssa_dev = ssa; view.ssa_words = sa_size; view.sa_int = K;
+    }
+    scratch.forget( bwt_occ ); if (ssa) scratch.forget( ssa );
+    return fm_index_adopt( &view, device, kmer_len, true, s, out, nullptr, nullptr );
+}
+
+static nvbio_status save_impl(const nvbio_fm_index_view& v, const char* bwt_path, const char* sa_path, hipStream_t s)
+{
+    Scratch scratch;
+    const uint32_t n = v.length, n_words = (n + 15u) / 16u;
+    NVB_ALLOC( d_bwt, uint32_t, n_words );
+    hipLaunchKernelGGL( deinterleave_bwt_kernel, dim3( grid_for( n_words ) ), dim3(256), 0, s, v.bwt_occ_dev, n_words, d_bwt );
+    std::vector<uint32_t> h_bwt( n_words );
+    NVB_HIP( hipMemcpyAsync( h_bwt.data(), d_bwt, (size_t)n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, s ) );
+    NVB_HIP( hipStreamSynchronize( s ) );
+    const uint32_t hdr[5] = { v.primary, v.L2[1], v.L2[2], v.L2[3], v.L2[4] };
+    {
+        FileCloser bf = { fopen( bwt_path, "wb" ) };
+        if (!bf.f) { set_error( "unable to create \"%s\"", bwt_path ); return NVBIO_ERR_INVALID; }
+        if (fwrite( hdr, sizeof(uint32_t), 5, bf.f ) != 5 || fwrite( h_bwt.data(), sizeof(uint32_t), n_words, bf.f ) != n_words)
+        { set_error( "failed writing \"%s\"", bwt_path ); return NVBIO_ERR_INVALID; }
+    }
+    if (sa_path)
+    {
+        if (!v.ssa_dev) { set_error( "index has no sampled suffix array to save" ); return NVBIO_ERR_INVALID; }
+        std::vector<uint32_t> h_ssa( v.ssa_words );
+        NVB_HIP( hipMemcpyAsync( h_ssa.data(), v.ssa_dev, v.ssa_words * sizeof(uint32_t), hipMemcpyDeviceToHost, s ) );
+        NVB_HIP( hipStreamSynchronize( s ) );
+        FileCloser sf = { fopen( sa_path, "wb" ) };
+        if (!sf.f) { set_error( "unable to create \"%s\"", sa_path ); return NVBIO_ERR_INVALID; }
+        const uint32_t sh[7] = { v.primary, v.L2[1], v.L2[2], v.L2[3], v.L2[4], v.sa_int ? v.sa_int : 16u, n };
+        if (fwrite( sh, sizeof(uint32_t), 7, sf.f ) != 7 ||
+            (v.ssa_words > 1 && fwrite( &h_ssa[1], sizeof(uint32_t), v.ssa_words - 1u, sf.f ) != v.ssa_words - 1u))
+        { set_error( "failed writing \"%s\"", sa_path ); return NVBIO_ERR_INVALID; }
+    }
+    return NVBIO_OK;
+}
+
 } // anonymous namespace
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_fm_index_load(const char* bwt_path, const char* sa_path, int device, uint32_t kmer_len,
+                                            void* stream, nvbio_fm_index_t* out)
+{
+    NVB_REQUIRE( bwt_path && out, "bwt_path/out is NULL" );
+    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    return load_impl( bwt_path, sa_path, device, kmer_len, (hipStream_t)stream, out );
+}
+
+extern "C" nvbio_status nvbio_fm_index_save(nvbio_fm_index_t index, const char* bwt_path, const char* sa_path, void* stream)
+{
+    NVB_REQUIRE( index && bwt_path, "index/bwt_path is NULL" );
+    nvbio_fm_index_view v;
+    NVB_CHECK( nvbio_fm_index_get_view( index, &v ) );
+    int dev = 0;
+    if (hipGetDevice( &dev ) != hipSuccess) dev = 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes( &attr, v.bwt_occ_dev ) == hipSuccess) dev = attr.device;
+    DeviceGuard g( dev ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    return save_impl( v, bwt_path, sa_path, (hipStream_t)stream );
+}
 
 extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
                                              const nvbio_fm_build_options* options, void* stream, nvbio_fm_index_t* out)

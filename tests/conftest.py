@@ -20,6 +20,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """the native pieces must exist before any test runs: build them if a fresh checkout has none
+    (hipcc cross-compiles gfx950 without a GPU; on the GPU box the prebuilt files travel with the tree)"""
+    import __graft_entry__ as ge
+    lib = os.path.join(ROOT, "nvbio-gpl_amd", "lib", "libnvbio_amd.so")
+    orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc_so)):
+        ge.build()
+
+
 @pytest.fixture(scope="session")
 def orc():
     import oracle

@@ -157,3 +157,47 @@ def test_sa_isa_verification_shortcut_is_exact(amd, orc, k):
     fmi.close()
     with pytest.raises(amd.NvbioError):
         amd.FMIndex.build(orc.pack2(text), n, sa_int=16, verify=True)
+
+
+def test_reference_index_files_roundtrip(amd, orc, tmp_path):
+    """.bwt / .sa in the reference's on-disk format (fmindex_impl.cu:111-252; writers nvBWT.cu:303-342):
+    files written independently from the oracle's index load into the oracle's arrays, and an index
+    built on the GPU survives save -> load"""
+    rng = np.random.default_rng(41)
+    for n in (100003, 64, 65, 4097):
+        text = rng.integers(0, 4, n, dtype=np.uint8)
+        hidx = orc.build_index(text)
+        # independent writer, straight from the format description
+        words = (n + 15) // 16
+        bwt_words = hidx.bwt_occ.reshape(-1, 8)[:, :4].reshape(-1)[:words]
+        bwt_file, sa_file = str(tmp_path / ("g%d.bwt" % n)), str(tmp_path / ("g%d.sa" % n))
+        with open(bwt_file, "wb") as f:
+            np.array([hidx.primary, hidx.L2[1], hidx.L2[2], hidx.L2[3], hidx.L2[4]], dtype=np.uint32).tofile(f)
+            bwt_words.astype(np.uint32).tofile(f)
+        with open(sa_file, "wb") as f:
+            np.array([hidx.primary, hidx.L2[1], hidx.L2[2], hidx.L2[3], hidx.L2[4], 16, n], dtype=np.uint32).tofile(f)
+            hidx.ssa[1:].astype(np.uint32).tofile(f)
+        fmi = amd.FMIndex.load(bwt_file, sa_file, kmer_len=4)
+        v = fmi.view()
+        assert (v.length, v.primary, v.sa_int) == (n, hidx.primary, 16)
+        assert [v.L2[i] for i in range(5)] == list(hidx.L2)
+        b, s = fmi.arrays()
+        assert np.array_equal(amd.u32(b), hidx.bwt_occ) and np.array_equal(amd.u32(s), hidx.ssa)
+        rows = rng.integers(0, n + 1, 2000).astype(np.uint32)
+        assert np.array_equal(amd.u32(fmi.locate(rows)), orc.locate_batch(hidx, rows))
+        fmi.close()
+        # GPU build -> save -> byte-identical files -> load
+        built = amd.FMIndex.build(orc.pack2(text), n, sa_int=16)
+        b2, s2 = str(tmp_path / "b.bwt"), str(tmp_path / "b.sa")
+        built.save(b2, s2)
+        assert open(b2, "rb").read() == open(bwt_file, "rb").read()
+        assert open(s2, "rb").read() == open(sa_file, "rb").read()
+        built.close()
+        # a match-only index (no .sa)
+        m = amd.FMIndex.load(bwt_file)
+        assert m.view().ssa_words == 0
+        with pytest.raises(amd.NvbioError):
+            m.locate(rows)
+        m.close()
+    with pytest.raises(amd.NvbioError):
+        amd.FMIndex.load(str(tmp_path / "missing.bwt"))
