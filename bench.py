@@ -232,7 +232,7 @@ def main():
         except Exception:
             traffic = None
     cells = float(nc) * params.band * M
-    extend_ms = stage_ms.get("extend", 0.0)
+    extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0)
 
     result = {
         "metric": "aligned reads/sec (150 bp single-end, 3 Gbp ref); GCUPS of the banded extend pass in `extend`",

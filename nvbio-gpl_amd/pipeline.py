@@ -88,7 +88,28 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
                          seed_interval=S_int)
 
-    cands = []
+    read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    aligner = GotohAligner(params.aln_type, params.scheme)
+
+    def extend(keys, tag):
+        """candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106) and
+        the banded Gotoh of every one of them; returns (read ids, selection keys)"""
+        e = tick("windows" + tag)
+        rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len)
+        tock(e)
+        e = tick("extend" + tag)
+        batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, read_id=rid,
+                               flags=flags, device=dev, max_read_len=M)
+        scores, sinks = BatchedBandedAlignmentScore(params.band, aligner).enact(batch)
+        tock(e)
+        e = tick("pack" + tag)
+        rc = (keys >> 33) & 1
+        pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
+        sel = pack_best_key(torch, scores, rc, pos)
+        tock(e)
+        return rid.to(torch.int64), sel
+
+    results, n_cand = [], 0
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
         #    (FMIndexFilter::rank = match + scan; the two halves are called separately so that the
@@ -111,40 +132,27 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
         #    removes nearly all duplicates without a sort; a survivor only costs a repeated extension)
         e = tick("diagonals")
         keys = torch.unique_consecutive(hits_to_diagonals(hits, spr, S_int, L, M, strand))
-        cands.append(keys)
         tock(e)
+        n_cand += keys.numel()
+        # (running this strand's VALU-bound extension on a second stream beside the other strand's
+        # memory-bound seed pass was measured: the two kernels serialise, 42-44 ms vs 36 ms per step)
+        results.append(extend(keys, "_rc" if strand else "_fw"))
 
     best_score = torch.full((R,), SCORE_MIN, dtype=torch.int32, device=dev)
     best_pos = torch.full((R,), -1, dtype=torch.int64, device=dev)
     best_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
-    if not cands:
+    if not results:
         return best_score, best_pos, best_rc, 0
 
-    # 5. candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106)
-    e = tick("windows")
-    keys = torch.cat(cands) if len(cands) > 1 else cands[0]
-    C = keys.numel()
-    rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len)
-    read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
-    tock(e)
-
-    # 6. banded Gotoh of every candidate window
-    e = tick("extend")
-    batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, read_id=rid, flags=flags,
-                           device=dev, max_read_len=M)
-    scores, sinks = BatchedBandedAlignmentScore(params.band, GotohAligner(params.aln_type, params.scheme)).enact(batch)
-    tock(e)
-
-    # 7. best candidate per read
+    # 5. best candidate per read
     e = tick("reduce")
-    rc = (keys >> 33) & 1
-    pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
     top = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    top.scatter_reduce_(0, rid.to(torch.int64), pack_best_key(torch, scores, rc, pos), "amax", include_self=True)
+    for rid, sel in results:
+        top.scatter_reduce_(0, rid, sel, "amax", include_self=True)
     has = top >= 0
     sv = top >> 34
     best_score = torch.where(has & (sv > 0), (sv - SCORE_BIAS).to(torch.int32), best_score)
     best_pos = torch.where(has, top & ((1 << 33) - 1), best_pos)
     best_rc = torch.where(has, ((top >> 33) & 1).to(torch.uint8), best_rc)
     tock(e)
-    return best_score, best_pos, best_rc, int(C)
+    return best_score, best_pos, best_rc, int(n_cand)
