@@ -4,8 +4,9 @@
 Workload (config.workload = "nvbowtie-se-150bp-3gbp", BASELINE.json configs[2]): per GPU, one
 step = one pass of the seed-and-extend path over a batch of 10 M synthetic 150 bp reads against
 a 3 Gbp synthetic reference: 2 x 9 exact 22-mer seeds per read through the FM-index (match +
-scan), expand + locate of every hit, candidate loci by diagonal, band-31 local Gotoh of every
-candidate window, best alignment per read.  Inputs (index, genome, reads) are resident in HBM
+scan), expand + locate of every hit, candidate loci by diagonal, band-31 Gotoh of every
+candidate window (nvBowtie's default end-to-end mode: SEMI_GLOBAL, match 0, mismatch -6 at constant
+q >= 40, gaps -8/-3; --mode local for its local mode), best alignment per read.  Inputs (index, genome, reads) are resident in HBM
 when the timed region starts.  value = reads/s over all ranks (weak scaling: every rank maps its
 own 10 M-read shard against its own replica of the index; one RCCL gather of the per-read best
 (score, position) to rank 0 closes each step).
@@ -117,6 +118,8 @@ def main():
     ap.add_argument("--kmer", type=int, default=16, help="k of the k-mer SA-range table (0 disables)")
     ap.add_argument("--sa-int", type=int, default=1, help="SA sampling interval of the index built for the run")
     ap.add_argument("--verify", action="store_true", help="build the index with the SA/ISA/text verification shortcut (needs --sa-int 1)")
+    ap.add_argument("--mode", choices=("e2e", "local"), default="e2e",
+                    help="nvBowtie scoring mode of the extension: end-to-end (default, SURVEY 8d config 3) or local")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,7 +163,9 @@ def main():
     torch.cuda.synchronize()
     log("%d reads x %d bp per rank generated in %.2fs" % (R, M, time.time() - t2))
     batch = pipeline.ReadBatch(reads4, R, M)
-    params = pipeline.SeedExtendParams()
+    params = pipeline.SeedExtendParams.end_to_end() if args.mode == "e2e" else pipeline.SeedExtendParams()
+    sv = params.scheme.c
+    scheme_t = tuple(int(getattr(sv, f)) for f, _ in sv._fields_)
     min_score = params.min_score_for(M)
 
     def step(timers=None):
@@ -245,7 +250,8 @@ def main():
         "config": {"workload": "nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150) else "custom",
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
-                   "alignment": "local Gotoh (2, -2..-6, -8, -3)", "kmer_table": args.kmer, "sa_int": args.sa_int, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
+                   "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
+                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "sa_int": args.sa_int, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
@@ -258,7 +264,7 @@ def main():
                      "without_kmer_table": {"ms_per_launch": no_table_ms,
                                             "achieved": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9,
                                             "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        "extend": {"kernel": "banded_gotoh_local31_pk_kernel<4,2> (two alignments per lane, int16 packed)",
+        "extend": {"kernel": "banded_gotoh_band31_pk_kernel<%s,4> (two alignments per lane, int16 packed)" % ("SEMI_GLOBAL" if args.mode == "e2e" else "LOCAL"),
                    "bound": "valu (integer; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
@@ -288,13 +294,15 @@ def main():
 
             def run(reads_np):
                 tm = {}
-                out = cpu_pipeline.seed_and_extend_ref(Rf, O, hidx, g_host, n, reads_np, timing=tm)
+                out = cpu_pipeline.seed_and_extend_ref(Rf, O, hidx, g_host, n, reads_np, timing=tm, aln_type=params.aln_type,
+                                                       scheme=oracle.Scheme(*scheme_t))
                 return out, tm["ref_seconds"]
             cores = Rf.num_threads()
         else:
             def run(reads_np):
                 c0 = time.perf_counter()
-                out = cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, reads_np, genome_is_packed=True)
+                out = cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, reads_np, genome_is_packed=True,
+                                                       aln_type=params.aln_type, scheme=oracle.Scheme(*scheme_t))
                 return out, time.perf_counter() - c0
             cores = O.num_threads()
         probe = reads_sym[:20000].cpu().numpy()
@@ -308,7 +316,7 @@ def main():
         result["cpu_baseline"] = {
             "value": Rs / cdt, "unit": "reads/s", "cores": cores, "kind": "reference" if use_ref else "port",
             "sample": "first %d reads of rank 0's batch; whole path (2x9 exact 22-mer seeds, locate of every hit, band-31 "
-                      "local Gotoh of every candidate) through %s, OpenMP over work items; %.1f s"
+                      "Gotoh of every candidate, same mode) through %s, OpenMP over work items; %.1f s"
                       % (Rs, "the reference's own host templates (oracle/_ref)" if use_ref else "the oracle's C restatement", cdt),
             "results_equal_gpu": same}
         log("cpu baseline (%s): %d reads in %.1fs on %d threads (equal to GPU results: %s)"

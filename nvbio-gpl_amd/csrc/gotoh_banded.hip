@@ -197,9 +197,9 @@ __device__ __forceinline__ uint32_t clamp_u32(const int64_t v, const uint32_t lo
 // issues the loads for the next chunk: one wave-uniform wait point per 8 rows with an 8-row
 // (~5,000 instruction) head start, and no per-row branches.  Reads are packed RBITS (2 or 4) per
 // symbol, the text 2 bits per symbol.
-template <int RBITS>
-__global__ void __launch_bounds__(128)
-banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+template <int TYPE, int RBITS>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
+banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
 {
     constexpr int BAND = 31;
     constexpr uint32_t RMASK = (1u << RBITS) - 1u;
@@ -212,7 +212,7 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
     const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
     const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
 
-    uint32_t first[2], M[2], tb[2], N[2], rows_u[2];
+    uint32_t first[2], M[2], tb[2], N[2], rows_all[2];
     bool     rev[2], comp[2], valid[2];
     #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -228,10 +228,9 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
         comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
         tb[u]   = b.win_begin[jj];
         N[u]    = b.win_end[jj] - tb[u];
-        // rows this half really computes: none when the text is shorter than the pattern (nothing reported)
-        rows_u[u] = (valid[u] && N[u] >= M[u]) ? M[u] : 0u;
+        // rows this alignment really computes: none when the text is shorter than the pattern (nothing reported)
+        rows_all[u] = (valid[u] && N[u] >= M[u]) ? M[u] : 0u;
     }
-    const uint32_t rows = rows_u[0] > rows_u[1] ? rows_u[0] : rows_u[1];
 
     // word ranges a stream may touch (loads are clamped into them; symbols outside are never used)
     uint32_t r_lo[2], r_hi[2], t_lo[2], t_hi[2];
@@ -244,63 +243,15 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
         t_hi[u] = (tb[u] + (N[u] ? N[u] - 1u : 0u)) >> 4;
     }
 
-    // storage position (symbol index) where the read chunk of rows [r0, r0+8) starts, and the nibble
-    // step inside it: forward reads start at first+r0 and walk up; reversed reads cover
-    // [first+M-1-r0-7, first+M-1-r0] and walk down from its top
+    // storage position (symbol index) where the read chunk of rows [r0, r0+8) starts: forward reads start
+    // at first+r0 and walk up; reversed reads cover [first+M-1-r0-7, first+M-1-r0] and walk down from its top
     auto read_chunk_start = [&](const int u, const uint32_t r0) -> int64_t {
         return rev[u] ? (int64_t)first[u] + (int64_t)M[u] - 1 - (int64_t)r0 - 7 : (int64_t)first[u] + r0;
     };
 
-    // ---- text cache: columns 0..29 of row 0, big-endian (column j at bits [62-2j, 63-2j]) ------------
-    uint64_t cache[2];
-    #pragma unroll
-    for (int u = 0; u < 2; ++u)
-    {
-        const uint32_t w  = tb[u] >> 4;
-        const uint32_t w0 = twords[clamp_u32( w,      t_lo[u], t_hi[u] )];
-        const uint32_t w1 = twords[clamp_u32( w + 1u, t_lo[u], t_hi[u] )];
-        const uint32_t w2 = twords[clamp_u32( w + 2u, t_lo[u], t_hi[u] )];
-        const uint32_t bit = (tb[u] & 15u) * 2u;
-        const uint64_t hi = ((uint64_t)funnel32( w0, w1, bit ) << 32) | funnel32( w1, w2, bit );
-        uint64_t c = hi & ~0xFull;                                   // 30 symbols = top 60 bits
-        // symbols at or past the text end read as 3 (the 255 sentinel through a 2-bit cache)
-        if (N[u] < 30u) c |= (~0ull >> (2u * N[u])) & ~0xFull;
-        cache[u] = c;
-    }
-
-    // ---- stream words for chunk 0 (loaded now, consumed at the top of the loop) ----------------------
-    uint32_t ra[2], rb[2], ta[2], tbw[2];
-    uint32_t qa[2] = { 0, 0 }, qb[2] = { 0, 0 }, qc[2] = { 0, 0 };  // quality bytes of the chunk: 3 words cover 8 unaligned bytes
     const uint32_t qadj = (uint32_t)((uintptr_t)b.quals & 3u);      // the quality stream need not be 4-byte aligned
     const uint32_t* __restrict__ qwords = (const uint32_t*)((uintptr_t)b.quals - qadj);
     const bool has_quals = (b.quals != nullptr);
-    auto issue_loads = [&](const uint32_t r0) {
-        if (has_quals)
-        {
-            #pragma unroll
-            for (int u = 0; u < 2; ++u)
-            {
-                const int64_t qw  = (read_chunk_start( u, r0 ) + qadj) >> 2;        // byte position / 4
-                const uint32_t lo = (first[u] + qadj) >> 2, hi = (first[u] + qadj + (M[u] ? M[u] - 1u : 0u)) >> 2;
-                qa[u] = qwords[clamp_u32( qw,     lo, hi )];
-                qb[u] = qwords[clamp_u32( qw + 1, lo, hi )];
-                qc[u] = qwords[clamp_u32( qw + 2, lo, hi )];
-            }
-        }
-        #pragma unroll
-        for (int u = 0; u < 2; ++u)
-        {
-            const int64_t  rbit = read_chunk_start( u, r0 ) * RBITS;
-            const int64_t  rw   = rbit >> 5;                          // arithmetic shift: floor for negatives
-            ra[u]  = rwords[clamp_u32( rw,     r_lo[u], r_hi[u] )];
-            rb[u]  = rwords[clamp_u32( rw + 1, r_lo[u], r_hi[u] )];
-            const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);  // text symbol entering column 30 at row r0
-            const int64_t  tw   = (int64_t)(tpos >> 4);
-            ta[u]  = twords[clamp_u32( tw,     t_lo[u], t_hi[u] )];
-            tbw[u] = twords[clamp_u32( tw + 1, t_lo[u], t_hi[u] )];
-        }
-    };
-    issue_loads( 0 );
 
     const v2s GO = pk( sc.pat_go, sc.pat_go ), GE = pk( sc.pat_ge, sc.pat_ge );
     const int gm = sc.pat_go > sc.pat_ge ? sc.pat_go : sc.pat_ge;
@@ -308,104 +259,201 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
     const v2s INF = pk( -16384, -16384 ), ZERO = pk( 0, 0 ), K32 = pk( 32, 32 );
     const int V = sc.match;
 
-    v2s H[BAND], F[BAND];
-    #pragma unroll
-    for (int j = 0; j < BAND; ++j) { H[j] = ZERO; F[j] = INF; }
-
     int32_t  best[2]   = { NVBIO_SCORE_MIN, NVBIO_SCORE_MIN };
     uint32_t best_x[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, best_y[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu };
 
-    for (uint32_t r0 = 0; r0 < rows; r0 += 8u)
+    // GLOBAL / SEMI_GLOBAL report from the band after an alignment's LAST row (:624-645).  To keep that out
+    // of the row loop, a lane whose two alignments have different lengths runs them one after the other
+    // (two passes, one half active each); equal lengths -- the normal case for a read batch -- take one pass.
+    // LOCAL reports every cell as it goes and always takes one pass.
+    const bool want0 = valid[0] && N[0] >= M[0], want1 = valid[1] && N[1] >= M[1];
+    const bool split = (TYPE != NVBIO_LOCAL) && want0 && want1 && M[0] != M[1];
+
+    for (int pass = 0; pass < (split ? 2 : 1); ++pass)
     {
-        // ---- assemble this chunk from the words loaded a chunk ago, then request the next chunk ----
-        uint32_t rchunk[2], tchunk[2]; int rsh[2], rstep[2];
-        uint64_t qchunk[2] = { 0, 0 }; int qsh[2], qstep[2];
+        uint32_t rows_u[2];
+        rows_u[0] = (split && pass != 0) ? 0u : rows_all[0];
+        rows_u[1] = (split && pass != 1) ? 0u : rows_all[1];
+        const uint32_t rows = rows_u[0] > rows_u[1] ? rows_u[0] : rows_u[1];
+
+        // ---- text cache: columns 0..29 of row 0, big-endian (column j at bits [62-2j, 63-2j]) ------------
+        uint64_t cache[2];
         #pragma unroll
         for (int u = 0; u < 2; ++u)
         {
+            const uint32_t w  = tb[u] >> 4;
+            const uint32_t w0 = twords[clamp_u32( w,      t_lo[u], t_hi[u] )];
+            const uint32_t w1 = twords[clamp_u32( w + 1u, t_lo[u], t_hi[u] )];
+            const uint32_t w2 = twords[clamp_u32( w + 2u, t_lo[u], t_hi[u] )];
+            const uint32_t bit = (tb[u] & 15u) * 2u;
+            const uint64_t hi = ((uint64_t)funnel32( w0, w1, bit ) << 32) | funnel32( w1, w2, bit );
+            uint64_t c = hi & ~0xFull;                               // 30 symbols = top 60 bits
+            // symbols at or past the text end read as 3 (the 255 sentinel through a 2-bit cache)
+            if (N[u] < 30u) c |= (~0ull >> (2u * N[u])) & ~0xFull;
+            cache[u] = c;
+        }
+
+        // ---- stream words for chunk 0 (loaded now, consumed at the top of the loop) ----------------------
+        uint32_t ra[2], rb[2], ta[2], tbw[2];
+        uint32_t qa[2] = { 0, 0 }, qb[2] = { 0, 0 }, qc[2] = { 0, 0 };  // quality bytes: 3 words cover 8 unaligned bytes
+        auto issue_loads = [&](const uint32_t r0) {
             if (has_quals)
             {
-                // 8 quality bytes of the chunk, byte k of the chunk at bits [8k, 8k+7] (memory order)
-                const uint32_t bs = ((uint32_t)((read_chunk_start( u, r0 ) + qadj) & 3)) * 8u;
-                const uint32_t lo = bs ? ((qa[u] >> bs) | (qb[u] << (32u - bs))) : qa[u];
-                const uint32_t hi = bs ? ((qb[u] >> bs) | (qc[u] << (32u - bs))) : qb[u];
-                qchunk[u] = ((uint64_t)hi << 32) | lo;
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const int64_t qw  = (read_chunk_start( u, r0 ) + qadj) >> 2;        // byte position / 4
+                    const uint32_t lo = (first[u] + qadj) >> 2, hi = (first[u] + qadj + (M[u] ? M[u] - 1u : 0u)) >> 2;
+                    qa[u] = qwords[clamp_u32( qw,     lo, hi )];
+                    qb[u] = qwords[clamp_u32( qw + 1, lo, hi )];
+                    qc[u] = qwords[clamp_u32( qw + 2, lo, hi )];
+                }
             }
-            qsh[u] = rev[u] ? 56 : 0; qstep[u] = rev[u] ? -8 : 8;
-            const int64_t rbit = read_chunk_start( u, r0 ) * RBITS;
-            rchunk[u] = funnel32( ra[u], rb[u], (uint32_t)(rbit & 31) );
-            rsh[u]    = rev[u] ? (32 - RBITS) - 7 * RBITS : (32 - RBITS);   // row 0 of the chunk: last / first symbol
-            rstep[u]  = rev[u] ? RBITS : -RBITS;
-            const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);
-            tchunk[u] = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
-        }
-        if (r0 + 8u < rows) issue_loads( r0 + 8u );
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const int64_t  rbit = read_chunk_start( u, r0 ) * RBITS;
+                const int64_t  rw   = rbit >> 5;                          // arithmetic shift: floor for negatives
+                ra[u]  = rwords[clamp_u32( rw,     r_lo[u], r_hi[u] )];
+                rb[u]  = rwords[clamp_u32( rw + 1, r_lo[u], r_hi[u] )];
+                const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);  // text symbol entering column 30 at row r0
+                const int64_t  tw   = (int64_t)(tpos >> 4);
+                ta[u]  = twords[clamp_u32( tw,     t_lo[u], t_hi[u] )];
+                tbw[u] = twords[clamp_u32( tw + 1, t_lo[u], t_hi[u] )];
+            }
+        };
+        issue_loads( 0 );
 
-        const uint32_t r_end = (r0 + 8u < rows) ? 8u : rows - r0;
-        for (uint32_t t = 0; t < r_end; ++t)
+        v2s H[BAND], F[BAND];
+        #pragma unroll
+        for (int j = 0; j < BAND; ++j)
         {
-            const uint32_t i = r0 + t;
-            // the row's pattern symbols / mismatch scores and the text symbols entering column 30
-            uint32_t q[2], gn[2]; int S[2];
+            const int h0 = (TYPE == NVBIO_GLOBAL && j > 0) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;      // init_row_zero (:37-68)
+            H[j] = pk( h0, h0 ); F[j] = INF;
+        }
+
+        for (uint32_t r0 = 0; r0 < rows; r0 += 8u)
+        {
+            // ---- assemble this chunk from the words loaded a chunk ago, then request the next chunk ----
+            uint32_t rchunk[2], tchunk[2]; int rsh[2], rstep[2];
+            uint64_t qchunk[2] = { 0, 0 }; int qsh[2], qstep[2];
             #pragma unroll
             for (int u = 0; u < 2; ++u)
             {
-                uint32_t qq = (rchunk[u] >> rsh[u]) & RMASK; rsh[u] += rstep[u];
-                if (comp[u] && qq < 4u) qq = 3u - qq;
-                q[u] = (i < rows_u[u]) ? qq : 255u;
-                uint32_t ql = (uint32_t)(qchunk[u] >> qsh[u]) & 0xFFu; qsh[u] += qstep[u];
-                if (i >= rows_u[u]) ql = 0;
-                S[u] = s_mm[ql < 63u ? ql : 63u];
-                gn[u] = (i + (uint32_t)(BAND - 1) < N[u]) ? (tchunk[u] >> 30) : 255u;
-                tchunk[u] <<= 2;
+                if (has_quals)
+                {
+                    // 8 quality bytes of the chunk, byte k of the chunk at bits [8k, 8k+7] (memory order)
+                    const uint32_t bs = ((uint32_t)((read_chunk_start( u, r0 ) + qadj) & 3)) * 8u;
+                    const uint32_t lo = bs ? ((qa[u] >> bs) | (qb[u] << (32u - bs))) : qa[u];
+                    const uint32_t hi = bs ? ((qb[u] >> bs) | (qc[u] << (32u - bs))) : qb[u];
+                    qchunk[u] = ((uint64_t)hi << 32) | lo;
+                }
+                qsh[u] = rev[u] ? 56 : 0; qstep[u] = rev[u] ? -8 : 8;
+                const int64_t rbit = read_chunk_start( u, r0 ) * RBITS;
+                rchunk[u] = funnel32( ra[u], rb[u], (uint32_t)(rbit & 31) );
+                rsh[u]    = rev[u] ? (32 - RBITS) - 7 * RBITS : (32 - RBITS);   // row 0 of the chunk: last / first symbol
+                rstep[u]  = rev[u] ? RBITS : -RBITS;
+                const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);
+                tchunk[u] = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
             }
+            if (r0 + 8u < rows) issue_loads( r0 + 8u );
 
-            // match flags of the 30 cached columns: alignment 0 at bit 63-2j, alignment 1 at bit 62-2j... built as
-            // e(u) at the LOW bit of each 2-bit slot, then alignment 1 moved to the high bit
-            uint64_t e[2];
+            const uint32_t r_end = (r0 + 8u < rows) ? 8u : rows - r0;
+            for (uint32_t t = 0; t < r_end; ++t)
+            {
+                const uint32_t i = r0 + t;
+                // the row's pattern symbols / mismatch scores and the text symbols entering column 30
+                uint32_t q[2], gn[2]; int S[2];
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    uint32_t qq = (rchunk[u] >> rsh[u]) & RMASK; rsh[u] += rstep[u];
+                    if (comp[u] && qq < 4u) qq = 3u - qq;
+                    q[u] = (i < rows_u[u]) ? qq : 255u;
+                    uint32_t ql = (uint32_t)(qchunk[u] >> qsh[u]) & 0xFFu; qsh[u] += qstep[u];
+                    if (i >= rows_u[u]) ql = 0;
+                    S[u] = s_mm[ql < 63u ? ql : 63u];
+                    gn[u] = (i + (uint32_t)(BAND - 1) < N[u]) ? (tchunk[u] >> 30) : 255u;
+                    tchunk[u] <<= 2;
+                }
+
+                // match flags of the 30 cached columns, e(u) at the LOW bit of each 2-bit slot, then alignment 1
+                // moved to the high bit: column j at bits 62-2j (alignment 0) and 63-2j (alignment 1)
+                uint64_t e[2];
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    e[u] = 0;
+                    if (q[u] < 4u) { const uint64_t x = cache[u] ^ ((uint64_t)q[u] * 0x5555555555555555ull); e[u] = ~(x | (x >> 1)) & 0x5555555555555555ull; }
+                }
+                const uint64_t EQ = e[0] | (e[1] << 1);
+
+                const v2s SS = pk( S[0], S[1] );
+                const v2s DV = pk( V - S[0], V - S[1] );
+
+                v2s E = ZERO;
+                v2s key = pk( -1, -1 );
+                #pragma unroll
+                for (int j = 0; j < BAND; ++j)
+                {
+                    const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
+                    F[j] = f;
+
+                    uint32_t eq01;
+                    if (j == BAND - 1) eq01 = (gn[0] == q[0] ? 1u : 0u) | (gn[1] == q[1] ? 0x10000u : 0u);
+                    else               eq01 = (uint32_t)((EQ >> (62 - 2 * j)) & 1ull) | ((uint32_t)((EQ >> (63 - 2 * j)) & 1ull) << 16);
+                    const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
+
+                    // everything that does not depend on E first: t = max(f, d [, 0]); then h = max(t, E) and the
+                    // E recurrence E' = max(t + GO, E + max(GO,GE)) (== max(h + GO, E + GE)): two dependent ops per cell
+                    v2s tt = (j == BAND - 1) ? d : pk_max( f, d );
+                    if (TYPE == NVBIO_LOCAL) tt = pk_max( tt, ZERO );
+                    const v2s h = (j == 0) ? tt : pk_max( tt, E );
+                    if (TYPE == NVBIO_LOCAL) key = pk_max( key, h * K32 + pk( j, j ) );
+                    H[j] = h;
+                    E = (j == 0) ? tt + GO : pk_max( tt + GO, E + GM );
+                }
+
+                // shift the caches by one column and append the new symbols
+                #pragma unroll
+                for (int u = 0; u < 2; ++u) cache[u] = ((cache[u] << 2) & ~0xFull) | ((uint64_t)(gn[u] & 3u) << 4);
+
+                if (TYPE == NVBIO_LOCAL)
+                {
+                    // BestSink: row-major reports, the LAST maximum wins
+                    const int k0 = key.x, k1 = key.y;
+                    if (i < rows_u[0] && (k0 >> 5) >= best[0]) { best[0] = k0 >> 5; best_x[0] = i + (uint32_t)(k0 & 31) + 1u; best_y[0] = i + 1u; }
+                    if (i < rows_u[1] && (k1 >> 5) >= best[1]) { best[1] = k1 >> 5; best_x[1] = i + (uint32_t)(k1 & 31) + 1u; best_y[1] = i + 1u; }
+                }
+            }
+        }
+
+        // ---- end-of-alignment reports (:624-645); every active half ended at row `rows` (or has no rows) ----
+        if (TYPE != NVBIO_LOCAL)
+        {
             #pragma unroll
             for (int u = 0; u < 2; ++u)
             {
-                e[u] = 0;
-                if (q[u] < 4u) { const uint64_t x = cache[u] ^ ((uint64_t)q[u] * 0x5555555555555555ull); e[u] = ~(x | (x >> 1)) & 0x5555555555555555ull; }
+                const bool active = (u ? want1 : want0) && (!split || u == pass);
+                if (!active) continue;
+                if (TYPE == NVBIO_GLOBAL)
+                {
+                    const int v = u ? (int)H[BAND - 1].y : (int)H[BAND - 1].x;
+                    if (best[u] <= v) { best[u] = v; best_x[u] = M[u] + BAND - 1; best_y[u] = M[u]; }
+                }
+                else
+                {
+                    const uint32_t mb = M[u] + (uint32_t)(BAND - 1);
+                    const uint32_t m  = (mb < N[u] ? mb : N[u]) - (M[u] - 1u);
+                    #pragma unroll
+                    for (int j = 0; j < BAND; ++j)
+                        if (j == 0 || (uint32_t)j < m)
+                        {
+                            const int v = u ? (int)H[j].y : (int)H[j].x;
+                            if (best[u] <= v) { best[u] = v; best_x[u] = M[u] + j; best_y[u] = M[u]; }
+                        }
+                }
             }
-            const uint64_t EQ = e[0] | (e[1] << 1);                  // column j: bits 62-2j (alignment 0), 63-2j (alignment 1)
-
-            const v2s SS = pk( S[0], S[1] );
-            const v2s DV = pk( V - S[0], V - S[1] );
-
-            v2s E = ZERO;
-            v2s key = pk( -1, -1 );
-            #pragma unroll
-            for (int j = 0; j < BAND; ++j)
-            {
-                const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
-                F[j] = f;
-
-                uint32_t eq01;
-                if (j == BAND - 1) eq01 = (gn[0] == q[0] ? 1u : 0u) | (gn[1] == q[1] ? 0x10000u : 0u);
-                else               eq01 = (uint32_t)((EQ >> (62 - 2 * j)) & 1ull) | ((uint32_t)((EQ >> (63 - 2 * j)) & 1ull) << 16);
-                const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
-
-                // everything that does not depend on E first: t = max(f, d, 0); then h = max(t, E) and the
-                // E recurrence E' = max(t + GO, E + max(GO,GE)) (== max(h + GO, E + GE)): two dependent ops per cell
-                v2s tt;
-                if (j == BAND - 1) tt = pk_max( d, ZERO );
-                else               tt = pk_max( pk_max( f, d ), ZERO );
-                const v2s h = (j == 0) ? tt : pk_max( tt, E );
-                key = pk_max( key, h * K32 + pk( j, j ) );
-                H[j] = h;
-                E = (j == 0) ? tt + GO : pk_max( tt + GO, E + GM );
-            }
-
-            // shift the caches by one column and append the new symbols
-            #pragma unroll
-            for (int u = 0; u < 2; ++u) cache[u] = ((cache[u] << 2) & ~0xFull) | ((uint64_t)(gn[u] & 3u) << 4);
-
-            // BestSink: row-major reports, the LAST maximum wins
-            const int k0 = key.x, k1 = key.y;
-            if (i < rows_u[0] && (k0 >> 5) >= best[0]) { best[0] = k0 >> 5; best_x[0] = i + (uint32_t)(k0 & 31) + 1u; best_y[0] = i + 1u; }
-            if (i < rows_u[1] && (k1 >> 5) >= best[1]) { best[1] = k1 >> 5; best_x[1] = i + (uint32_t)(k1 & 31) + 1u; best_y[1] = i + 1u; }
         }
     }
     #pragma unroll
@@ -413,32 +461,39 @@ banded_gotoh_local31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __
         if (valid[u]) { scores[2u * pair + u] = best[u]; sinks[2u * pair + u] = make_uint2( best_x[u], best_y[u] ); }
 }
 
-// the packed kernel is exact iff every LOCAL score fits 10 bits and penalties are small
-static bool packed_local_ok(const SchemeDev& sc, const uint32_t max_read_len)
+// the packed kernel is exact iff no intermediate value can leave the int16 range or meet the -16384 stand-in
+// for the reference's infimum: LOCAL additionally packs (score << 5 | column), so scores must fit 10 bits
+static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_read_len)
 {
     if (max_read_len == 0) return false;
-    if (sc.match < 0 || (uint64_t)sc.match * max_read_len > 1000u) return false;
     const int lim = 4096;
     if (sc.mm_min < 0 || sc.mm_max < 0 || sc.mm_min > lim || sc.mm_max > lim) return false;
     if (sc.pat_go > 0 || sc.pat_ge > 0 || sc.pat_go < -lim || sc.pat_ge < -lim) return false;
-    return true;
+    if (sc.match < 0) return false;
+    if (type == NVBIO_LOCAL) return (uint64_t)sc.match * max_read_len <= 1000u;
+    if (sc.txt_go > 0 || sc.txt_ge > 0 || sc.txt_go < -lim || sc.txt_ge < -lim) return false;
+    // |score| <= (rows + band) * (largest single step) must stay far from -16384
+    int64_t step = sc.match;
+    const int c[] = { sc.mm_min, sc.mm_max, -sc.pat_go, -sc.pat_ge, -sc.txt_go, -sc.txt_ge };
+    for (int v : c) if (v > step) step = v;
+    return ((int64_t)max_read_len + 32) * step <= 8000;
 }
 
-template <int RB>
+template <int TYPE, int RB>
 static void launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
     const uint32_t pairs = (b.n + 1u) / 2u;
-    hipLaunchKernelGGL( (banded_gotoh_local31_pk_kernel<RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
+    hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
 }
 
 template <int BAND, int TYPE>
 static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
                                 int32_t* scores, uint2* sinks, hipStream_t s)
 {
-    if (BAND == 31 && TYPE == NVBIO_LOCAL && packed_local_ok( sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
+    if (BAND == 31 && packed_ok( TYPE, sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
     {
-        if      (rbits == 4 && tbits == 2) { launch_pk<4>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
-        else if (rbits == 2 && tbits == 2) { launch_pk<2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        if      (rbits == 4 && tbits == 2) { launch_pk<TYPE,4>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        else if (rbits == 2 && tbits == 2) { launch_pk<TYPE,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
     }
     const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
 #define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks )

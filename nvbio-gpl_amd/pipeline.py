@@ -15,7 +15,7 @@ import math
 
 import numpy as np
 
-from . import (FM_COMPLEMENT, FM_SCAN_FORWARD, LOCAL, READ_COMPLEMENT, READ_REVERSE, SCORE_MIN, AlignmentBatch,
+from . import (FM_COMPLEMENT, FM_SCAN_FORWARD, LOCAL, READ_COMPLEMENT, READ_REVERSE, SCORE_MIN, SEMI_GLOBAL, AlignmentBatch,
                BatchedBandedAlignmentScore, FMIndexFilter, GotohAligner, GotohScheme, PackedStringSet)
 
 
@@ -31,12 +31,24 @@ class SeedExtendParams:
         self.min_score = min_score                  # None -> nvBowtie local(): int(0 + 10*ln(len)) (scoring.h:117-129)
         self.max_seed_hits = max_seed_hits          # None: every SA row of every seed range is extended (fmmap)
 
+    @classmethod
+    def end_to_end(cls, constant_quality=True, **kw):
+        """nvBowtie's default (end-to-end) mode: GotohAligner<SEMI_GLOBAL> (scoring.h:212) with the default
+        SmithWatermanScoringScheme (scoring_inl.h:99-114): match 0, mismatch 2..6 by quality, gaps 5+3 / 3.
+        constant_quality: reads carry no qualities and every base counts as q >= 40 (mismatch -6)."""
+        scheme = GotohScheme(0, 6, 6, -8, -3, -8, -3) if constant_quality else GotohScheme(0, 2, 6, -8, -3, -8, -3)
+        p = cls(aln_type=SEMI_GLOBAL, scheme=scheme, **kw)
+        p.e2e = True
+        return p
+
     def interval_for(self, read_len):
         return self.seed_interval or int(1 + 1.15 * math.sqrt(read_len))
 
     def min_score_for(self, read_len):
         if self.min_score is not None:
             return self.min_score
+        if getattr(self, "e2e", False):                # linear -0.6 - 0.6 L (scoring_inl.h:99-114, MinScoreFunc scoring.h:117-129)
+            return int(np.float32(-0.6) + np.float32(-0.6) * np.float32(read_len))
         return int(np.float32(0.0) + np.float32(10.0) * np.float32(math.log(np.float32(read_len))))
 
 

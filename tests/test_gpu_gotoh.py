@@ -112,7 +112,8 @@ def test_banded_edge_cases(amd, orc):
     assert sc.numel() == 0
 
 
-def test_packed_local31_kernel_equals_int32_and_oracle(amd, orc):
+@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL", "GLOBAL"])
+def test_packed_band31_kernel_equals_int32_and_oracle(amd, orc, typ):
     """the 16-bit two-alignments-per-lane kernel (picked when max_read_len is given and every score
     fits) against the oracle: odd batch sizes, ragged lengths, pairs of different length, short
     texts (N < M on one half of a pair), reversed/complemented reads, qualities, clipped windows"""
@@ -140,22 +141,28 @@ def test_packed_local31_kernel_equals_int32_and_oracle(amd, orc):
     we = np.minimum(np.maximum(we, wb + 30), G).astype(np.uint32)
     sel = np.nonzero((we - wb) >= 30)[0]
     assert (we[sel] - wb[sel] < lens[rid[sel]]).any()           # some N < M jobs are in
-    for sv in ((2, 2, 6, -8, -3, -8, -3), (1, 3, 3, -11, -4, -11, -4), (3, 0, 9, -5, -5, -2, -1)):
+    typ = getattr(oracle, typ)
+    # nvBowtie local() / a constant-mismatch scheme / asymmetric gaps; for the end-to-end types also nvBowtie's
+    # e2e defaults (match 0, scoring_inl.h:49-70) with the quality ramp and with the constant -6
+    schemes = [(2, 2, 6, -8, -3, -8, -3), (1, 3, 3, -11, -4, -11, -4), (3, 0, 9, -5, -5, -2, -1)]
+    if typ != oracle.LOCAL:
+        schemes += [(0, 2, 6, -8, -3, -8, -3), (0, 6, 6, -8, -3, -8, -3)]
+    for sv in schemes:
         for use_q in (True, False):
             kw = dict(quals=quals if use_q else None, read_id=rid[sel], flags=flags[sel])
-            wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.LOCAL, oracle.Scheme(*sv), orc.pack4(flat), roffs,
+            wsc, wsk = orc.banded_gotoh_packed_batch(31, typ, oracle.Scheme(*sv), orc.pack4(flat), roffs,
                                                      orc.pack2(text), wb[sel], we[sel], **kw)
             for hint in (150, 0):                               # packed kernel / int32 kernel
                 batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel],
                                            max_read_len=hint, **kw)
-                sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.LOCAL, _scheme(amd, sv)), batch)
+                sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, _scheme(amd, sv)), batch)
                 assert np.array_equal(sc.cpu().numpy(), wsc), (sv, use_q, hint)
                 assert np.array_equal(amd.u32(sk), wsk), (sv, use_q, hint)
     # a scheme whose scores do not fit 10 bits must fall back to the int32 kernel and still be exact
-    sv = (9, 2, 6, -8, -3, -8, -3)
+    sv = (9, 2, 60, -8, -3, -8, -3)
     batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel], max_read_len=150,
                                read_id=rid[sel], flags=flags[sel])
-    sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.LOCAL, _scheme(amd, sv)), batch)
-    wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.LOCAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text),
+    sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, _scheme(amd, sv)), batch)
+    wsc, wsk = orc.banded_gotoh_packed_batch(31, typ, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text),
                                              wb[sel], we[sel], read_id=rid[sel], flags=flags[sel])
     assert np.array_equal(sc.cpu().numpy(), wsc) and np.array_equal(amd.u32(sk), wsk)

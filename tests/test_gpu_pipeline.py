@@ -13,7 +13,8 @@ from util import mutate_reads
 pytestmark = pytest.mark.gpu
 
 
-def test_pipeline_equals_cpu_path(amd, orc):
+@pytest.mark.parametrize("mode", ["local", "e2e"])
+def test_pipeline_equals_cpu_path(amd, orc, mode):
     import torch
     pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
     rng = np.random.default_rng(21)
@@ -33,16 +34,23 @@ def test_pipeline_equals_cpu_path(amd, orc):
     reads[rcm] = 3 - reads[rcm][:, ::-1]
     reads[rng.random(reads.shape) < 0.001] = 4
     reads[-20:] = rng.integers(0, 4, (20, M))            # unalignable reads
-    want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads)
+    if mode == "local":
+        params = pipeline.SeedExtendParams()
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads)
+    else:                                                 # nvBowtie default mode, constant quality
+        params = pipeline.SeedExtendParams.end_to_end()
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
+                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3))
+        assert params.min_score_for(150) == -90
     rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
     bs, bp, brc, nc = pipeline.seed_and_extend(fmi, torch.from_numpy(genome2.view(np.int32)).cuda(), G, rb,
-                                               pipeline.SeedExtendParams())
+                                               params)
     assert want[3] <= nc <= want[3] * 1.10           # adjacent-duplicate removal may keep a few repeats
     assert np.array_equal(bs.cpu().numpy(), want[0])
     assert np.array_equal(bp.cpu().numpy(), want[1])
     assert np.array_equal(brc.cpu().numpy(), want[2])
     # properties that also hold at full size: reads come back to their locus on the right strand
-    ok = (bs.cpu().numpy()[:-20] >= 10 * np.log(150)).mean()
+    ok = (bs.cpu().numpy()[:-20] >= params.min_score_for(150)).mean()
     assert ok > 0.99
     near = np.abs(bp.cpu().numpy()[70:-20] - (starts[70:-20] + M)) <= 40
     assert near.mean() > 0.98
