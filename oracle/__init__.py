@@ -37,6 +37,30 @@ def _c32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
 
 
+def cigar_from_ops(ops, clip_before, clip_after):
+    """nvBowtie's Backtracker (alignment_utils.h:115-157) over a recorded op string: run-length io::Cigar
+    elements (type | len << 2) in backtracking order, soft clips only when non-zero"""
+    out = []
+    if clip_before:
+        out.append(3 | (clip_before << 2))
+    prev = 255
+    for op in ops:
+        op = int(op)
+        if op == prev:
+            out[-1] += 4
+        else:
+            out.append(op | (1 << 2)); prev = op
+    if clip_after:
+        out.append(3 | (clip_after << 2))
+    return np.array(out, dtype=np.uint16)
+
+
+def cigar_string(cigar, reverse=False):
+    """'147M2D3M'-style rendering of io::Cigar elements (backtracking order unless reverse)"""
+    els = list(cigar)[::-1] if reverse else list(cigar)
+    return "".join("%d%s" % (int(c) >> 2, "MIDS"[int(c) & 3]) for c in els)
+
+
 def build(force=False):
     """compile liboracle.so (and _ref/libnvbio_ref.so when /root/reference exists)"""
     so = os.path.join(_HERE, "liboracle.so")
@@ -234,6 +258,37 @@ class Oracle:
                                        ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def banded_gotoh_traceback(self, band, typ, scheme, pat, txt, quals=None, cap=4096):
+        """-> (traced, score, source, sink, cigar uint16[], ops uint8[]) in backtracking order"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        cig = np.zeros(cap, dtype=np.uint16); ops = np.zeros(cap, dtype=np.uint8)
+        cl = ctypes.c_uint32(); no = ctypes.c_uint32()
+        ok = self.lib.orc_banded_gotoh_traceback(
+            ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(pat, _u8p), _p(quals, _u8p),
+            ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(src, _u32p),
+            _p(sk, _u32p), cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap), ctypes.byref(cl),
+            _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no))
+        assert cl.value <= cap and no.value <= cap
+        return ok, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), cig[:cl.value].copy(), ops[:no.value].copy()
+
+    def banded_gotoh_traceback_packed_batch(self, band, typ, scheme, reads4, read_offsets, genome2, win_begin, win_end,
+                                            cigar_stride, read_id=None, flags=None, quals=None):
+        reads4, read_offsets, genome2 = _c32(reads4), _c32(read_offsets), _c32(genome2)
+        win_begin, win_end, read_id = _c32(win_begin), _c32(win_end), _c32(read_id)
+        flags, quals = _c8(flags), _c8(quals)
+        n = len(win_begin)
+        scores = np.zeros(n, dtype=np.int32)
+        sources = np.zeros((n, 2), dtype=np.uint32); sinks = np.zeros((n, 2), dtype=np.uint32)
+        cigars = np.zeros((n, cigar_stride), dtype=np.uint16); lens = np.zeros(n, dtype=np.uint32)
+        self.lib.orc_banded_gotoh_traceback_packed_batch(
+            ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(reads4, _u32p),
+            _p(read_offsets, _u32p), _p(quals, _u8p), _p(read_id, _u32p), _p(flags, _u8p), _p(genome2, _u32p),
+            _p(win_begin, _u32p), _p(win_end, _u32p), ctypes.c_uint32(n), _p(scores, _i32p), _p(sources, _u32p),
+            _p(sinks, _u32p), cigars.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cigar_stride), _p(lens, _u32p))
+        return scores, sources, sinks, cigars, lens
+
     def full_gotoh(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN):
         pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
         sc = ctypes.c_int32()
@@ -392,6 +447,29 @@ class Reference:
                                               ctypes.c_uint32(len(txt)), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc),
                                               _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_gotoh_traceback(self, band, typ, scheme, pat, txt, quals=None, cap=4096):
+        """the reference's banded_alignment_traceback<BAND,1024,16> with a recording backtracer
+        -> (n_clip_calls, score, source, sink, ops uint8[] in backtracking order, (clip_before, clip_after)).
+        The reference re-reads text[window_begin .. window_begin+BAND-2] unconditionally when it recomputes a
+        checkpointed block (gotoh_banded_inl.h:432-433), i.e. past the end of a clipped text; the text is
+        handed over followed by the same 255 sentinel its score pass substitutes there (:569), which keeps the
+        two passes consistent (in nvBowtie those reads land in the genome after the window)."""
+        n_txt = len(txt)
+        pat, quals = _c8(pat), _c8(quals)
+        txt = np.ascontiguousarray(np.concatenate([np.asarray(txt, dtype=np.uint8), np.full(64, 255, dtype=np.uint8)]))
+        arr = scheme.as_array()
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        ops = np.zeros(cap, dtype=np.uint8); clips = np.zeros(2, dtype=np.uint32)
+        no = ctypes.c_uint32()
+        r = self.lib.ref_banded_gotoh_traceback_ex(
+            ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p), _p(quals, _u8p),
+            ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(n_txt), ctypes.c_int32(SCORE_MIN),
+            ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p), _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no),
+            _p(clips, _u32p))
+        assert no.value <= cap
+        return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
 
     def full_gotoh(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN):
         pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)

@@ -426,16 +426,13 @@ static inline void sink_report(best_sink* s, int32_t score, uint32_t x, uint32_t
  * ------------------------------------------------------------------------------------------ */
 #define ORC_MAX_BAND 64
 
-int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,
-                     const uint8_t* pat, const uint8_t* quals, uint32_t M,
-                     const uint8_t* txt, uint32_t N,
-                     int32_t* score, uint32_t sink_out[2])
+/* the banded DP; dirs (optional, M*B bytes) receives every cell's direction vector
+ * hdir | edir | fdir as GotohSubmatrixContext::new_cell stores it (gotoh_banded_inl.h:316-330) */
+static int banded_core(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                       const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                       const uint8_t* txt, uint32_t N, best_sink* sink_p, uint8_t* dirs)
 {
-    best_sink sink; sink_init( &sink );
-    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
-    if (B < 2 || B > ORC_MAX_BAND) return -1;
-    if (N < M) return 0;                                                    /* :422-423 */
-
+    best_sink sink = *sink_p;
     /* Reference_cache<BAND> (alignment_base_inl.h:66-90): bands 3,5,7,15 cache whole uint32
      * symbols, every other band (31 in production) a 2-bit packed stream, so a cached symbol is
      * re-read modulo 4 (the out-of-range sentinel 255 becomes 3) */
@@ -459,33 +456,48 @@ int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,
         H[j] = (type == ORC_GLOBAL) ? sc->txt_gap_open + (int32_t)(j-1)*sc->txt_gap_ext : 0;
     for (uint32_t j = 0; j < B; ++j) F[j] = infimum;
 
+    /* direction vectors (alignment.h:326-336) */
+    enum { D_SUB = 0, D_INS = 1, D_DEL = 2, D_SINK = 3, D_INS_EXT = 4, D_DEL_EXT = 8 };
+
     for (uint32_t i = 0; i < M; ++i)
     {
         const uint8_t  q  = pat[i];
         const uint8_t  qq = quals ? quals[i] : 0;
         const int32_t  V  = sc->match;
         const int32_t  S  = orc_mismatch( sc, qq );
+        uint8_t edir = D_SUB;
 
         /* j == 0 (:474-505) */
         {
-            F[0] = imax( F[1] + G_e, H[1] + G_o );
+            const int32_t ftop = F[1] + G_e, htop = H[1] + G_o;
+            F[0] = imax( ftop, htop );
+            const uint8_t fdir = ftop > htop ? D_DEL_EXT : D_SUB;
             const uint32_t g  = cache[0];
             const int32_t  d  = H[0] + ((g == q) ? V : S);
             int32_t        hi = imax( F[0], d );
-            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i+1, i+1 ); }
+            uint8_t      hdir = F[0] > d ? D_INS : D_SUB;
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); if (hi == 0) hdir = D_SINK; sink_report( &sink, hi, i+1, i+1 ); }
             H[0] = hi;
+            if (dirs) dirs[(size_t)i*B] = hdir | D_SUB | fdir;
         }
         int32_t E = H[0] + G_o;                                             /* :507 */
 
         for (uint32_t j = 1; j + 1 < B; ++j)                                /* :509-566 */
         {
-            F[j] = imax( F[j+1] + G_e, H[j+1] + G_o );
+            const int32_t ftop = F[j+1] + G_e, htop = H[j+1] + G_o;
+            F[j] = imax( ftop, htop );
+            const uint8_t fdir = ftop > htop ? D_DEL_EXT : D_SUB;
             const uint32_t g = cache[j]; cache[j-1] = g;
             const int32_t  d  = H[j] + ((g == q) ? V : S);
-            int32_t        hi = imax( imax( F[j], E ), d );
-            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i+j+1, i+1 ); }
+            const int32_t  top = F[j], left = E;
+            int32_t        hi = imax( imax( top, left ), d );
+            uint8_t      hdir = top > left ? (top > d ? D_INS : D_SUB) : (left > d ? D_DEL : D_SUB);
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); if (hi == 0) hdir = D_SINK; sink_report( &sink, hi, i+j+1, i+1 ); }
             H[j] = hi;
-            E = imax( hi + G_o, E + G_e );
+            if (dirs) dirs[(size_t)i*B + j] = hdir | edir | fdir;
+            const int32_t eleft = E + G_e, ediag = hi + G_o;                /* :562-565 */
+            edir = eleft > ediag ? D_INS_EXT : D_SUB;
+            E = imax( ediag, eleft );
         }
 
         /* new text character (:569-570) */
@@ -497,8 +509,10 @@ int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,
             F[B-1] = infimum;
             const int32_t d  = H[B-1] + ((g == q) ? V : S);
             int32_t       hi = imax( E, d );
-            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i+B, i+1 ); }
+            uint8_t     hdir = E > d ? D_DEL : D_SUB;
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); if (hi == 0) hdir = D_SINK; sink_report( &sink, hi, i+B, i+1 ); }
             H[B-1] = hi;
+            if (dirs) dirs[(size_t)i*B + B-1] = hdir | edir | D_SUB;
         }
     }
 
@@ -511,7 +525,85 @@ int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,
         for (uint32_t j = 1; j < B; ++j)
             if (j < m) sink_report( &sink, H[j], M + j, M );
     }
+    *sink_p = sink;
+    return 1;
+}
+
+int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                     const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                     const uint8_t* txt, uint32_t N,
+                     int32_t* score, uint32_t sink_out[2])
+{
+    best_sink sink; sink_init( &sink );
     *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    if (B < 2 || B > ORC_MAX_BAND) return -1;
+    if (N < M) return 0;                                                    /* :422-423 */
+    banded_core( B, type, sc, pat, quals, M, txt, N, &sink, 0 );
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    return 1;
+}
+
+/* banded traceback: banded_alignment_traceback (nvbio/alignment/banded_inl.h:354-417) = score pass,
+ * clip(pattern_len - sink.y), the walk of priv::banded_alignment_traceback
+ * (gotoh/gotoh_banded_inl.h:872-948) over the direction vectors, clip(source.y) -- delivered to
+ * nvBowtie's run-length Backtracker (nvBowtie/bowtie2/cuda/alignment_utils.h:115-157): io::Cigar
+ * elements (type in bits 0-1, length in bits 2-15; nvbio/io/alignments.h:48-66) in BACKTRACKING
+ * order.  The reference recomputes the direction vectors from int16 checkpoints every 16 rows; that
+ * equals the single pass here as long as every score stays inside int16 (checked by the caller's
+ * sizes; -32736 is the checkpoint clamp, :216-222).  ops (optional): the raw op per step.
+ * Returns 1 if an alignment was traced, 0 if nothing was reported (no clip, no ops). */
+int orc_banded_gotoh_traceback(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                               const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                               const uint8_t* txt, uint32_t N,
+                               int32_t* score, uint32_t source[2], uint32_t sink_out[2],
+                               uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len,
+                               uint8_t* ops, uint32_t ops_cap, uint32_t* n_ops)
+{
+    best_sink best; sink_init( &best );
+    *score = best.score; sink_out[0] = sink_out[1] = source[0] = source[1] = 0xFFFFFFFFu;
+    *cigar_len = 0; if (n_ops) *n_ops = 0;
+    if (B < 2 || B > ORC_MAX_BAND) return -1;
+    uint8_t* dirs = (uint8_t*)malloc( (size_t)(M ? M : 1) * B );
+    if (N >= M) banded_core( B, type, sc, pat, quals, M, txt, N, &best, dirs );
+    *score = best.score;
+    if (best.x == 0xFFFFFFFFu || best.y == 0xFFFFFFFFu) { free( dirs ); return 0; }   /* banded_inl.h:376-379 */
+    sink_out[0] = best.x; sink_out[1] = best.y;
+
+    uint32_t clen = 0, nops = 0; int prev = 255;
+#define CIG_PUSH(type_, len_) do { if (clen < cigar_cap) cigar[clen] = (uint16_t)((type_) | ((len_) << 2)); ++clen; } while (0)
+#define OP_PUSH(op_) do { if (ops && nops < ops_cap) ops[nops] = (uint8_t)(op_); ++nops; \
+                          if (prev == (int)(op_)) { if (clen - 1 < cigar_cap) cigar[clen-1] += 4; } else { CIG_PUSH( op_, 1u ); prev = (int)(op_); } } while (0)
+    if (M - best.y) CIG_PUSH( 3u, M - best.y );                             /* clip the end (:382) */
+
+    int32_t entry = (int32_t)(best.x - best.y);                             /* :884-885 */
+    int32_t row   = (int32_t)best.y - 1;
+    int state = 0;                                                          /* HSTATE 0, ESTATE 1, FSTATE 2 */
+    uint32_t sx, sy; int found = 0;
+    while (row >= 0)
+    {
+        const uint8_t op = dirs[(size_t)row*B + entry];
+        const uint8_t h_op = op & 3u;
+        if (type == ORC_LOCAL && state == 0 && h_op == 3u)                  /* :898-906 */
+        {
+            sy = (uint32_t)row + 1u; sx = (uint32_t)entry + sy; found = 1;
+            break;
+        }
+        if (state == 1)      { if ((op & 4u) == 0) state = 0; --entry; OP_PUSH( 2u ); }              /* E: DELETION */
+        else if (state == 2) { if ((op & 8u) == 0) state = 0; ++entry; --row; OP_PUSH( 1u ); }       /* F: INSERTION */
+        else
+        {
+            if (h_op == 2u) state = 1;
+            else if (h_op == 1u) state = 2;
+            else { --row; OP_PUSH( 0u ); }
+        }
+    }
+    if (!found) { sy = 0; sx = (uint32_t)entry; }                            /* :945-947 with checkpoint 0 */
+    if (sy) CIG_PUSH( 3u, sy );                                             /* clip the beginning (:413) */
+#undef OP_PUSH
+#undef CIG_PUSH
+    source[0] = sx; source[1] = sy;
+    *cigar_len = clen; if (n_ops) *n_ops = nops;
+    free( dirs );
     return 1;
 }
 
@@ -751,6 +843,43 @@ void orc_banded_gotoh_packed_batch(uint32_t band, int type, const orc_gotoh_sche
             }
             for (uint32_t k = 0; k < tl; ++k) t[k] = orc_get2( genome2, (uint64_t)tb + k );
             orc_banded_gotoh( band, type, s, p, quals ? pq : 0, len, t, tl, scores + i, sinks + 2*i );
+        }
+        free( p ); free( pq ); free( t );
+    }
+}
+
+void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_gotoh_scheme* s,
+                                   const uint32_t* reads4, const uint32_t* read_offsets, const uint8_t* quals,
+                                   const uint32_t* read_id, const uint8_t* flags,
+                                   const uint32_t* genome2, const uint32_t* win_begin, const uint32_t* win_end,
+                                   uint32_t n, int32_t* scores, uint32_t* sources, uint32_t* sinks,
+                                   uint16_t* cigars, uint32_t cigar_stride, uint32_t* cigar_lens)
+{
+    #pragma omp parallel
+    {
+        uint32_t cap_p = 512, cap_t = 1024;
+        uint8_t* p  = (uint8_t*)malloc( cap_p );
+        uint8_t* pq = (uint8_t*)malloc( cap_p );
+        uint8_t* t  = (uint8_t*)malloc( cap_t );
+        #pragma omp for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n; ++i)
+        {
+            const uint32_t rid   = read_id ? read_id[i] : (uint32_t)i;
+            const uint32_t first = read_offsets[rid], len = read_offsets[rid+1] - first;
+            const uint32_t tb = win_begin[i], tl = win_end[i] - tb;
+            if (len > cap_p) { cap_p = 2*len; p = (uint8_t*)realloc( p, cap_p ); pq = (uint8_t*)realloc( pq, cap_p ); }
+            if (tl  > cap_t) { cap_t = 2*tl;  t = (uint8_t*)realloc( t, cap_t ); }
+            const int rev = flags ? (flags[i] & 1) : 0, comp = flags ? (flags[i] & 2) : 0;
+            for (uint32_t k = 0; k < len; ++k)
+            {
+                const uint32_t idx = rev ? first + len - 1u - k : first + k;
+                const uint8_t  c   = orc_get4( reads4, idx );
+                p[k]  = comp ? (c < 4 ? 3 - c : c) : c;
+                pq[k] = quals ? quals[idx] : 0;
+            }
+            for (uint32_t k = 0; k < tl; ++k) t[k] = orc_get2( genome2, (uint64_t)tb + k );
+            orc_banded_gotoh_traceback( band, type, s, p, quals ? pq : 0, len, t, tl, scores + i, sources + 2*i, sinks + 2*i,
+                                        cigars + (size_t)i*cigar_stride, cigar_stride, cigar_lens + i, 0, 0, 0 );
         }
         free( p ); free( pq ); free( t );
     }

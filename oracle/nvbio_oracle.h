@@ -126,6 +126,28 @@ int orc_banded_gotoh(uint32_t band, int type, const orc_gotoh_scheme* s,
                      const uint8_t* txt, uint32_t N,
                      int32_t* score, uint32_t sink[2]);
 
+/* banded Gotoh traceback: aln::banded_alignment_traceback (nvbio/alignment/banded_inl.h:354-417,
+ * gotoh/gotoh_banded_inl.h:872-948) delivered to nvBowtie's run-length Backtracker
+ * (nvBowtie/bowtie2/cuda/alignment_utils.h:115-157).  cigar: io::Cigar elements (type bits 0-1:
+ * 0 M, 1 I, 2 D, 3 soft clip; length bits 2-15) in BACKTRACKING order: [clip(M - sink.y)] ops
+ * [clip(source.y)].  ops (optional): one byte per step in the same order.  Returns 1 if an
+ * alignment was traced, 0 if nothing was reported (source = sink = (-1,-1), no cigar). */
+int orc_banded_gotoh_traceback(uint32_t band, int type, const orc_gotoh_scheme* s,
+                               const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                               const uint8_t* txt, uint32_t N,
+                               int32_t* score, uint32_t source[2], uint32_t sink[2],
+                               uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len,
+                               uint8_t* ops, uint32_t ops_cap, uint32_t* n_ops);
+
+/* the same over nvBowtie-shaped packed inputs (see orc_banded_gotoh_packed_batch); cigars has
+ * cigar_stride elements per alignment */
+void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_gotoh_scheme* s,
+                                   const uint32_t* reads4, const uint32_t* read_offsets, const uint8_t* quals,
+                                   const uint32_t* read_id, const uint8_t* flags,
+                                   const uint32_t* genome2, const uint32_t* win_begin, const uint32_t* win_end,
+                                   uint32_t n, int32_t* scores, uint32_t* sources, uint32_t* sinks,
+                                   uint16_t* cigars, uint32_t cigar_stride, uint32_t* cigar_lens);
+
 /* full-matrix Gotoh, 8-column stripes with an int16 (short2) boundary column
  * (gotoh_inl.h:444-841 pattern blocking, :847-1256 text blocking; alignment_score_dispatch :1283-1330).
  * blocking: 0 = PatternBlockingTag (alignment_score default), 1 = TextBlockingTag (sw-benchmark).

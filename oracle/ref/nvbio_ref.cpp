@@ -155,6 +155,63 @@ int banded_band(uint32 band, int type, const scheme_type& scheme,
     return -1;
 }
 
+// A Backtracer model (concept: nvbio/alignment/alignment.h:130-140) that records exactly what the
+// reference's traceback hands it: the ops in backtracking order and the two clip() calls.
+struct RecordingBacktracer
+{
+    uint8* ops; uint32 cap; uint32 n; uint32 clips[2]; uint32 n_clips;
+    void clip(const uint32 l) { if (n_clips < 2) clips[n_clips] = l; ++n_clips; }
+    void push(const uint8 op) { if (n < cap) ops[n] = op; ++n; }
+};
+
+// aln::banded_alignment_traceback<BAND,MAX_PATTERN_LEN,CHECKPOINTS> (nvbio/alignment/banded_inl.h:440-483 ->
+// :354-417 -> gotoh/gotoh_banded_inl.h:730-950); CHECKPOINTS = 16 as nvBowtie (BANDED_DP_CHECKPOINTS, defs.h:95)
+template <uint32 BAND, aln::AlignmentType TYPE, typename scheme_type, typename qual_type>
+int banded_tb_run(const scheme_type& scheme,
+                  const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                  int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    typedef vector_view<const uint8*> string_type;
+    const aln::Alignment<int32> a = aln::banded_alignment_traceback<BAND,1024u,16u>(
+        aln::make_gotoh_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        quals,
+        string_type( N, txt ),
+        min_score,
+        bt );
+    *score = a.score; source[0] = a.source.x; source[1] = a.source.y; sink[0] = a.sink.x; sink[1] = a.sink.y;
+    return (int)bt.n_clips;
+}
+
+template <uint32 BAND, typename scheme_type, typename qual_type>
+int banded_tb_type(int type, const scheme_type& scheme,
+                   const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                   int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    switch (type)
+    {
+    case 0: return banded_tb_run<BAND,aln::GLOBAL>     ( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 1: return banded_tb_run<BAND,aln::LOCAL>      ( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 2: return banded_tb_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    }
+    return -1;
+}
+
+template <typename scheme_type, typename qual_type>
+int banded_tb_band(uint32 band, int type, const scheme_type& scheme,
+                   const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                   int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    switch (band)
+    {
+    case 3:  return banded_tb_type<3> ( type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 7:  return banded_tb_type<7> ( type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 15: return banded_tb_type<15>( type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 31: return banded_tb_type<31>( type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    }
+    return -1;
+}
+
 template <aln::AlignmentType TYPE, typename algorithm_tag, typename scheme_type, typename qual_type>
 int full_run(const scheme_type& scheme,
              const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
@@ -364,6 +421,26 @@ int ref_banded_gotoh_ex(uint32_t band, int type, const int32_t* sc,
     return quals ?
         banded_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
         banded_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+// banded traceback through the reference (M <= 1024).  ops: one byte per op in BACKTRACKING order
+// (0 SUBSTITUTION, 1 INSERTION, 2 DELETION -- aln::DirectionVector, alignment.h:326-330); *n_ops is the
+// number of ops produced (ops beyond cap are dropped); clips[0] = clip before the ops (pattern_len - sink.y),
+// clips[1] = clip after them (source.y).  Returns the number of clip() calls (0: not aligned, nothing reported).
+int ref_banded_gotoh_traceback_ex(uint32_t band, int type, const int32_t* sc,
+                                  const uint8_t* pat, const uint8_t* quals, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                                  int32_t* score, uint32_t* source, uint32_t* sink,
+                                  uint8_t* ops, uint32_t cap, uint32_t* n_ops, uint32_t* clips)
+{
+    if (M > 1024u) return -1;
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    RecordingBacktracer bt; bt.ops = ops; bt.cap = cap; bt.n = 0; bt.n_clips = 0; bt.clips[0] = bt.clips[1] = 0;
+    const int r = quals ?
+        banded_tb_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt ) :
+        banded_tb_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, source, sink, bt );
+    *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
+    return r;
 }
 
 int ref_full_gotoh_ex(int type, int blocking, const int32_t* sc,

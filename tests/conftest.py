@@ -57,6 +57,11 @@ def dp_golden():
 
 
 @pytest.fixture(scope="session")
+def tb_golden():
+    return np.load(os.path.join(GOLDEN, "tb_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def amd():
     """the product package (HIP kernels behind the C-ABI); GPU tests only"""
     import __graft_entry__ as ge

@@ -15,6 +15,8 @@ Fixtures:
                   random pairs (substitutions, indels, N's, qualities, clipped windows, N < M),
                   each scored by the reference with banded Gotoh (bands 3/7/15/31 x 3 types) and
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
+  tb_golden.npz   the same pairs traced back by the reference (banded_alignment_traceback, bands
+                  3/7/15/31 x 3 types): score, source, sink and the run-length CIGAR.
 """
 import os
 import sys
@@ -192,9 +194,49 @@ def make_dp(R):
     print("dp_golden.npz: %d pairs" % n)
 
 
+def make_tb(R):
+    """tb_golden.npz: the reference's banded_alignment_traceback<BAND,1024,16> on every pair of
+    dp_golden.npz (bands 3/7/15/31 x 3 types, scheme = case % S; the known-answer pairs under the
+    schemes of alignment_test.cu:743-828): Alignment {score, source, sink} and the ops / clips the
+    Backtracer received, folded into nvBowtie's run-length io::Cigar elements (backtracking order)."""
+    g = np.load(os.path.join(HERE, "dp_golden.npz"))
+    n = len(g["pat_off"]) - 1
+    bands = [int(b) for b in g["bands"]]
+    S = len(g["schemes"])
+    nk = int(g["n_known"])
+    aln = np.zeros((n, len(bands), 3, 6), dtype=np.int64)       # traced, score, source.x, source.y, sink.x, sink.y
+    cig_off = np.zeros((n, len(bands), 3, 2), dtype=np.int64)   # [begin, end) into cigars
+    cigars = []
+    pos = 0
+    for i in range(n):
+        pat = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+        txt = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+        q = g["quals"][g["pat_off"][i]:g["pat_off"][i + 1]] if g["has_quals"][i] else None
+        sv = g["known_schemes"][i] if i < nk else g["schemes"][i % S]
+        sc = oracle.Scheme(*[int(x) for x in sv])
+        for bi, b in enumerate(bands):
+            for typ in range(3):
+                if len(txt) < b - 1:        # the reference reads text[0..BAND-2] unconditionally: undefined, not pinned
+                    aln[i, bi, typ, 0] = -1
+                    cig_off[i, bi, typ] = (pos, pos)
+                    continue
+                r, s_, src, snk, ops, clips = R.banded_gotoh_traceback(b, typ, sc, pat, txt, q)
+                traced = 1 if r == 2 else 0
+                assert r in (0, 2)
+                c = oracle.cigar_from_ops(ops, *clips) if traced else np.zeros(0, dtype=np.uint16)
+                aln[i, bi, typ] = (traced, s_, np.int64(np.int32(np.uint32(src[0]))), np.int64(np.int32(np.uint32(src[1]))),
+                                   np.int64(np.int32(np.uint32(snk[0]))), np.int64(np.int32(np.uint32(snk[1]))))
+                cig_off[i, bi, typ] = (pos, pos + len(c)); pos += len(c)
+                cigars.append(c)
+    np.savez_compressed(os.path.join(HERE, "tb_golden.npz"), aln=aln, cig_off=cig_off,
+                        cigars=np.concatenate(cigars).astype(np.uint16), bands=np.array(bands))
+    print("tb_golden.npz: %d pairs, %d cigar elements" % (n, pos))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
     R = oracle.Reference()
     make_fm(R)
     make_dp(R)
+    make_tb(R)

@@ -160,6 +160,46 @@ def test_banded_gotoh_golden(orc, dp_golden):
                 assert (ok, s, sk[0], sk[1]) == tuple(int(v) for v in want), (i, b, typ)
 
 
+def _tb_scheme(g, i):
+    S = len(g["schemes"])
+    v = g["known_schemes"][i] if i < int(g["n_known"]) else g["schemes"][i % S]
+    return oracle.Scheme(*[int(x) for x in v])
+
+
+def test_banded_traceback_golden(orc, dp_golden, tb_golden):
+    """score, source, sink and run-length CIGAR of the reference's banded_alignment_traceback"""
+    g, t = dp_golden, tb_golden
+    n = len(g["pat_off"]) - 1
+    u = lambda v: int(np.uint32(np.int64(v) & 0xFFFFFFFF))
+    checked = 0
+    for i in range(n):
+        sc = _tb_scheme(g, i)
+        p, x, q = _case(g, i)
+        for bi, b in enumerate(t["bands"]):
+            for typ in range(3):
+                want = t["aln"][i, bi, typ]
+                if want[0] < 0:
+                    continue
+                ok, s, src, snk, cig, ops = orc.banded_gotoh_traceback(int(b), typ, sc, p, x, q)
+                assert (ok, s) == (int(want[0]), int(want[1])), (i, b, typ)
+                assert src == (u(want[2]), u(want[3])) and snk == (u(want[4]), u(want[5])), (i, b, typ)
+                lo, hi = t["cig_off"][i, bi, typ]
+                assert np.array_equal(cig, t["cigars"][lo:hi]), (i, b, typ, oracle.cigar_string(cig))
+                if ok:      # the CIGAR spans the pattern and the source/sink text interval
+                    ln = cig >> 2; ty = cig & 3
+                    assert int(ln[(ty == 0) | (ty == 1) | (ty == 3)].sum()) == len(p)
+                    assert int(ln[(ty == 0) | (ty == 2)].sum()) == snk[0] - src[0]
+                checked += 1
+    assert checked > 4000
+    # the reference's functional tests (alignment_test.cu:743-746,779-785)
+    p, x, _ = _case(g, 0)
+    r = orc.banded_gotoh_traceback(7, oracle.SEMI_GLOBAL, oracle.Scheme.simple(2, -1, -1, -1), p, x)
+    assert oracle.cigar_string(r[4]) == "4M1D3M"
+    p, x, _ = _case(g, 1)
+    r = orc.banded_gotoh_traceback(31, oracle.SEMI_GLOBAL, oracle.Scheme.simple(0, -5, -8, -3), p, x)
+    assert oracle.cigar_string(r[4]) == "147M2D3M" and r[1] == -11 and r[2] == (13, 0) and r[3] == (165, 150)
+
+
 def test_full_gotoh_golden(orc, dp_golden):
     g = dp_golden
     S = len(g["schemes"])

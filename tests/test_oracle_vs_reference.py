@@ -61,6 +61,12 @@ def test_gotoh_fuzz(orc, ref):
         sc = SCHEMES[it % len(SCHEMES)]
         for typ in range(3):
             assert ref.banded_gotoh(band, typ, sc, pat, txt, quals) == orc.banded_gotoh(band, typ, sc, pat, txt, quals)
+            # traceback: Alignment {score, source, sink}, the op string and the clips (banded_inl.h:354-417)
+            r, rs, rsrc, rsnk, rops, rclips = ref.banded_gotoh_traceback(band, typ, sc, pat, txt, quals)
+            ok, s, src, snk, cig, ops = orc.banded_gotoh_traceback(band, typ, sc, pat, txt, quals)
+            assert (ok, s, src, snk) == (1 if r == 2 else 0, rs, rsrc, rsnk), (it, typ)
+            assert np.array_equal(ops, rops), (it, typ)
+            assert np.array_equal(cig, oracle.cigar_from_ops(rops, *rclips) if r == 2 else np.zeros(0, dtype=np.uint16)), (it, typ)
             ms = oracle.SCORE_MIN if it % 3 else int(rng.integers(-50, 200))
             for blk in range(2):
                 assert ref.full_gotoh(typ, blk, sc, pat, txt, quals, ms) == orc.full_gotoh(typ, blk, sc, pat, txt, quals, ms)
