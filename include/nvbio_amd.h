@@ -290,6 +290,32 @@ nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbio_alignment
                                       const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
                                       int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
 
+/* Banded Gotoh traceback: aln::banded_alignment_traceback<band,CHECKPOINTS> / BatchedBandedAlignmentTraceback
+ * (nvbio/alignment/banded_inl.h:354-483, gotoh/gotoh_banded_inl.h:730-950; nvBowtie banded_traceback_best,
+ * traceback_inl.h:191-247) with nvBowtie's run-length Backtracker as the backtracer
+ * (nvBowtie/bowtie2/cuda/alignment_utils.h:115-157).  Per job i:
+ *   scores_dev[i], sinks_dev[i]   as nvbio_banded_gotoh_score;
+ *   sources_dev[i]                Alignment::source: (text, pattern) cell where the alignment starts;
+ *   cigars_dev[i*cigar_stride..]  io::Cigar elements (uint16: type in bits 0-1 -- 0 substitution/match,
+ *                                 1 insertion, 2 deletion, 3 soft clip -- length in bits 2-15; nvbio/io/alignments.h:48-66)
+ *                                 in BACKTRACKING order, exactly the sequence the Backtracker receives:
+ *                                 [clip(pattern_len - sink.y)] ops... [clip(source.y)];
+ *   cigar_lens_dev[i]             number of elements produced (elements beyond cigar_stride are dropped, the
+ *                                 count is not); 0 with source = sink = (-1,-1) when nothing was reported;
+ *                                 0xFFFFFFFF when the pattern is longer than batch->max_read_len (job skipped).
+ * batch->max_read_len is REQUIRED here (the stream's max_pattern_length(): it sizes the scratch).
+ * The reference recomputes the direction vectors from int16 checkpoints; this call returns
+ * NVBIO_ERR_UNSUPPORTED for (scheme, max_read_len) combinations whose scores could leave that range, where the
+ * reference's own result is truncation-dependent.
+ * temp_dev / temp_bytes: optional caller scratch (nvbio_banded_gotoh_traceback_temp_bytes); if NULL the library
+ * allocates stream-ordered scratch and processes the batch in as many launches as 16 GiB allow. */
+nvbio_status nvbio_banded_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t band, uint64_t* bytes);
+nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
+                                          const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                          int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                          uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                          void* temp_dev, uint64_t temp_bytes, void* stream);
+
 /* full-matrix Gotoh: aln::alignment_score / BatchedAlignmentScore (nvbio/alignment/gotoh/gotoh_inl.h:444-1256,
  * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default
  * PatternBlockingTag; min_scores_dev (optional) enables the reference's stripe early exit.

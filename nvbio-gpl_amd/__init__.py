@@ -451,6 +451,45 @@ def batch_banded_alignment_score(band_len, aligner, batch):
     return BatchedBandedAlignmentScore(band_len, aligner).enact(batch)
 
 
+class BatchedBandedAlignmentTraceback:
+    """aln::BatchedBandedAlignmentTraceback<BAND_LEN,CHECKPOINTS,stream> (nvbio/alignment/batched.h,
+    batched_banded_inl.h) with nvBowtie's run-length Backtracker (alignment_utils.h:115-157) as the stream's
+    backtracer: per job the Alignment {score, source, sink} and its io::Cigar elements in backtracking order"""
+
+    def __init__(self, band_len, aligner):
+        self.band_len, self.aligner = int(band_len), aligner
+
+    def min_temp_storage(self, batch):
+        out = ctypes.c_uint64(0)
+        bs = batch.c_struct()
+        _check(lib().nvbio_banded_gotoh_traceback_temp_bytes(ctypes.byref(bs), ctypes.c_uint32(self.band_len), ctypes.byref(out)))
+        return int(out.value)
+
+    def enact(self, batch, cigar_stride=64, temp=None):
+        torch = _torch()
+        n, dev = batch.n, batch.device
+        scores = torch.empty(n, dtype=torch.int32, device=dev)
+        sources = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        cigars = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev)
+        lens = torch.empty(n, dtype=torch.int32, device=dev)
+        bs = batch.c_struct()
+        _check(lib().nvbio_banded_gotoh_traceback(
+            FMIndex._dev_index(dev), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
+            ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs), _ptr(scores), _ptr(sources), _ptr(sinks), _ptr(cigars),
+            ctypes.c_uint32(cigar_stride), _ptr(lens), _ptr(temp),
+            ctypes.c_uint64(0 if temp is None else temp.numel() * temp.element_size()), _stream_ptr(dev)))
+        return scores, sources, sinks, cigars, lens
+
+
+def cigar_string(cigar_row, length, forward=True):
+    """render one alignment's io::Cigar elements ('3M2D147M'); forward=True reverses the backtracking order"""
+    els = [int(c) & 0xFFFF for c in cigar_row[:length]]
+    if forward:
+        els = els[::-1]
+    return "".join("%d%s" % (c >> 2, "MIDS"[c & 3]) for c in els)
+
+
 class BatchedAlignmentScore:
     """aln::BatchedAlignmentScore<stream, scheduler> (full-matrix DP; batched.h:274, batched_inl.h:221-592)"""
 

@@ -1,0 +1,389 @@
+// gotoh_traceback.hip -- batched banded Gotoh traceback (score + CIGAR) for gfx950.
+//
+// Reference behaviour reproduced (file:line relative to the reference tree):
+//   banded_alignment_traceback (driver: score pass, clip, walk, clip)   nvbio/alignment/banded_inl.h:354-417
+//   direction vectors per cell (hdir | edir | fdir)                     nvbio/alignment/gotoh/gotoh_banded_inl.h:461-602, :316-330
+//   priv::banded_alignment_traceback (the H/E/F state walk)             gotoh_banded_inl.h:872-948
+//   DirectionVector / State encodings                                   nvbio/alignment/alignment.h:326-346
+//   nvBowtie's run-length Backtracker and io::Cigar                     nvBowtie/bowtie2/cuda/alignment_utils.h:115-157, nvbio/io/alignments.h:48-66
+//   batched driver                                                      nvbio/alignment/batched_banded_inl.h (BatchedBandedAlignmentTraceback)
+//
+// MI355X design.  The reference keeps one int16 checkpoint of the band every 16 rows and recomputes
+// each 16-row block of direction vectors on the way back (twice the DP, plus a per-thread
+// submatrix in local memory) because a K40 has 12 GB.  With 288 GB of HBM the direction vectors of
+// the WHOLE band are simply written out during the one forward pass: a row of a band-31 DP is
+// 31 x 4 bits = one 16-byte vector per lane, stored row-major / job-interleaved so that a wave
+// writes 4 x 256 contiguous bytes per row (2.4 KB per 150 bp alignment; the launch is chunked to
+// the scratch the caller grants).  The walk back then reads at most one row vector per step,
+// again coalesced across the wave, and run-length encodes straight into the caller's CIGAR array.
+// The two are identical as long as every score fits the reference's int16 checkpoints, which the
+// host checks from the scheme and the batch's max_read_len (else NVBIO_ERR_UNSUPPORTED).
+#include "gotoh_common.h"
+
+namespace nvbio_amd {
+
+namespace {
+
+enum : uint32_t { D_SUB = 0u, D_INS = 1u, D_DEL = 2u, D_SINK = 3u, D_INS_EXT = 4u, D_DEL_EXT = 8u };
+
+template <int BAND, int TYPE, int RBITS, int TBITS>
+__global__ void __launch_bounds__(128)
+banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin, const uint32_t jobs,
+                              uint32_t* __restrict__ dirs,
+                              int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
+                              uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens)
+{
+    constexpr int WORDS = (BAND + 7) / 8;                        // 32-bit words of direction nibbles per row
+
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // slot inside this launch
+    if (t >= jobs) return;
+    const uint32_t job = job_begin + t;
+
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+
+    int32_t  best   = NVBIO_SCORE_MIN;
+    uint32_t best_x = 0xFFFFFFFFu, best_y = 0xFFFFFFFFu;
+
+    if (M > b.max_read_len)                                      // would overrun the direction-vector scratch: skip, flagged
+    {
+        scores[job] = best; sinks[job] = sources[job] = make_uint2( best_x, best_y );
+        cigar_lens[job] = 0xFFFFFFFFu;
+        return;
+    }
+
+    if (N >= M)                                                  // else nothing is reported (gotoh_banded_inl.h:422-423)
+    {
+        constexpr bool PACKED = !(BAND == 3 || BAND == 5 || BAND == 7 || BAND == 15);
+
+        SymbolReader<TBITS> trd( b.text );
+        SymbolReader<RBITS> prd( b.reads );
+
+        uint64_t cache_bits = 0;                                 // PACKED: symbol j at bits [2j,2j+1]
+        uint32_t cache_raw[PACKED ? 1 : BAND - 1];
+        #pragma unroll
+        for (int j = 0; j < BAND - 1; ++j)
+        {
+            const uint32_t g = ((uint32_t)j < N) ? trd.get( tb + j ) : 255u;
+            if (PACKED) cache_bits |= (uint64_t)(g & 3u) << (2 * j);
+            else        cache_raw[j] = g;
+        }
+
+        const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+        const int32_t infimum = -32768 - max2( max2( G_o, G_e ), max2( sc.txt_go, sc.txt_ge ) );
+        const int32_t V = sc.match;
+
+        int32_t H[BAND], F[BAND];
+        H[0] = 0;
+        #pragma unroll
+        for (int j = 1; j < BAND; ++j) H[j] = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;
+        #pragma unroll
+        for (int j = 0; j < BAND; ++j) F[j] = infimum;
+
+        for (uint32_t i = 0; i < M; ++i)
+        {
+            const uint32_t pidx = rev ? first + M - 1u - i : first + i;
+            uint32_t q = prd.get( pidx );
+            if (comp && q < 4u) q = 3u - q;
+            const uint32_t qq = b.quals ? b.quals[pidx] : 0u;
+            const int32_t  S  = s_mm[qq < 63u ? qq : 63u];
+
+            const uint32_t g_new = (i + (uint32_t)(BAND - 1) < N) ? trd.get( tb + i + (BAND - 1) ) : 255u;
+
+            uint64_t eq_bits = 0;
+            if (PACKED && q < 4u)
+            {
+                const uint64_t x = cache_bits ^ ((uint64_t)q * 0x5555555555555555ull);
+                eq_bits = ~(x | (x >> 1)) & 0x5555555555555555ull;
+            }
+
+            uint32_t dw[WORDS];
+            #pragma unroll
+            for (int w = 0; w < WORDS; ++w) dw[w] = 0;
+
+            int32_t  E = 0;
+            uint32_t edir = D_SUB;
+            int32_t  row_key = -1;
+            #pragma unroll
+            for (int j = 0; j < BAND; ++j)
+            {
+                // F and its direction (:476-480,513-517; column BAND-1: :575-576)
+                int32_t f = infimum; uint32_t fdir = D_SUB;
+                if (j < BAND - 1)
+                {
+                    const int32_t ftop = F[j + 1] + G_e, htop = H[j + 1] + G_o;
+                    f = max2( ftop, htop );
+                    fdir = ftop > htop ? D_DEL_EXT : D_SUB;
+                }
+                F[j] = f;
+
+                bool eq;
+                if (j == BAND - 1)   eq = (g_new == q);
+                else if (PACKED)     eq = ((eq_bits >> (2 * j)) & 1ull) != 0;
+                else                 eq = (cache_raw[j] == q);
+                const int32_t d = H[j] + (eq ? V : S);
+
+                int32_t h; uint32_t hdir;
+                if (j == 0)             { h = max2( f, d ); hdir = f > d ? D_INS : D_SUB; }                   // :486-503
+                else if (j == BAND - 1) { h = max2( E, d ); hdir = E > d ? D_DEL : D_SUB; }                   // :579-601
+                else
+                {
+                    h = max3( f, E, d );                                                                      // :534-557
+                    hdir = f > E ? (f > d ? D_INS : D_SUB) : (E > d ? D_DEL : D_SUB);
+                }
+                if (TYPE == NVBIO_LOCAL)
+                {
+                    h = max2( h, 0 );
+                    if (h == 0) hdir = D_SINK;
+                    row_key = max2( row_key, (h << 5) | j );
+                }
+                H[j] = h;
+                dw[j >> 3] |= (hdir | edir | fdir) << (4 * (j & 7));
+
+                // E for the next column and its direction (:507,560-565)
+                if (j == 0) { E = h + G_o; edir = D_SUB; }
+                else
+                {
+                    const int32_t eleft = E + G_e, ediag = h + G_o;
+                    edir = eleft > ediag ? D_INS_EXT : D_SUB;
+                    E = max2( ediag, eleft );
+                }
+            }
+            #pragma unroll
+            for (int w = 0; w < WORDS; ++w) dirs[((size_t)i * WORDS + w) * jobs + t] = dw[w];
+
+            if (PACKED) cache_bits = (cache_bits >> 2) | ((uint64_t)(g_new & 3u) << (2 * (BAND - 2)));
+            else
+            {
+                #pragma unroll
+                for (int j = 0; j < BAND - 2; ++j) cache_raw[j] = cache_raw[j + 1];
+                cache_raw[BAND - 2] = g_new;
+            }
+
+            if (TYPE == NVBIO_LOCAL)
+            {
+                const int32_t h = row_key >> 5;
+                if (h >= best) { best = h; best_x = i + (uint32_t)(row_key & 31) + 1u; best_y = i + 1u; }
+            }
+        }
+
+        if (TYPE == NVBIO_GLOBAL)                                // :629-630
+        {
+            if (best <= H[BAND - 1]) { best = H[BAND - 1]; best_x = M + BAND - 1; best_y = M; }
+        }
+        else if (TYPE == NVBIO_SEMI_GLOBAL)                      // :631-643
+        {
+            const uint32_t mb = M + (uint32_t)(BAND - 1);
+            const uint32_t m  = (mb < N ? mb : N) - (M - 1u);
+            #pragma unroll
+            for (int j = 0; j < BAND; ++j)
+                if (j == 0 || (uint32_t)j < m)
+                    if (best <= H[j]) { best = H[j]; best_x = M + j; best_y = M; }
+        }
+    }
+
+    scores[job] = best;
+    sinks[job]  = make_uint2( best_x, best_y );
+    if (best_x == 0xFFFFFFFFu || best_y == 0xFFFFFFFFu)         // banded_inl.h:376-379: nothing to trace
+    {
+        sources[job]    = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu );
+        cigar_lens[job] = 0;
+        return;
+    }
+
+    // ---- the walk back (gotoh_banded_inl.h:884-947), run-length encoded as nvBowtie's Backtracker does ----
+    uint16_t* cig = cigars + (size_t)job * cigar_stride;
+    uint32_t  clen = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) {
+        if (clen < cigar_stride) cig[clen] = (uint16_t)(type | (len << 2));
+        ++clen;
+    };
+    if (M - best_y) emit( 3u, M - best_y );                      // clip the end of the pattern (banded_inl.h:382)
+
+    int32_t  entry = (int32_t)(best_x - best_y);
+    int32_t  row   = (int32_t)best_y - 1;
+    uint32_t state = 0;                                          // HSTATE 0, ESTATE 1, FSTATE 2
+    uint32_t prev = 255u, run = 0;
+    uint32_t src_x = 0, src_y = 0;
+    bool     found = false;
+
+    int32_t  loaded_row = -1;
+    uint32_t rw[WORDS];
+    #pragma unroll
+    for (int w = 0; w < WORDS; ++w) rw[w] = 0;
+
+    while (row >= 0)
+    {
+        if (row != loaded_row)
+        {
+            #pragma unroll
+            for (int w = 0; w < WORDS; ++w) rw[w] = dirs[((size_t)row * WORDS + w) * jobs + t];
+            loaded_row = row;
+        }
+        uint32_t word = rw[0];
+        #pragma unroll
+        for (int w = 1; w < WORDS; ++w) if ((entry >> 3) == w) word = rw[w];
+        const uint32_t op   = (word >> (4 * (entry & 7))) & 15u;
+        const uint32_t h_op = op & 3u;
+
+        if (TYPE == NVBIO_LOCAL && state == 0u && h_op == D_SINK)
+        {
+            src_y = (uint32_t)row + 1u; src_x = (uint32_t)entry + src_y; found = true;
+            break;
+        }
+        uint32_t push = 255u;
+        if (state == 1u)      { if ((op & D_INS_EXT) == 0u) state = 0u; --entry; push = D_DEL; }
+        else if (state == 2u) { if ((op & D_DEL_EXT) == 0u) state = 0u; ++entry; --row; push = D_INS; }
+        else
+        {
+            if (h_op == D_DEL)      state = 1u;
+            else if (h_op == D_INS) state = 2u;
+            else { --row; push = D_SUB; }
+        }
+        if (push != 255u)
+        {
+            if (push == prev) ++run;
+            else { if (run) emit( prev, run ); prev = push; run = 1u; }
+        }
+    }
+    if (run) emit( prev, run );
+    if (!found) { src_y = 0u; src_x = (uint32_t)entry; }
+    if (src_y) emit( 3u, src_y );                                // clip the beginning (banded_inl.h:413)
+
+    sources[job]    = make_uint2( src_x, src_y );
+    cigar_lens[job] = clen;
+}
+
+template <int BAND, int TYPE>
+nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
+                         uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
+                         uint32_t* lens, hipStream_t s)
+{
+    const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens )
+    if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
+    else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
+    else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
+    else if (rbits == 8 && tbits == 8) NVB_GO(8, 8);
+    else if (rbits == 4 && tbits == 8) NVB_GO(4, 8);
+    else if (rbits == 2 && tbits == 8) NVB_GO(2, 8);
+    else { set_error( "unsupported read_bits/text_bits %u/%u", rbits, tbits ); return NVBIO_ERR_INVALID; }
+#undef NVB_GO
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+template <int BAND>
+nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
+                         uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
+                         uint32_t* lens, hipStream_t s)
+{
+    switch (type)
+    {
+    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    }
+    set_error( "invalid alignment type %d", type );
+    return NVBIO_ERR_INVALID;
+}
+
+inline uint64_t row_bytes(const uint32_t band) { return (uint64_t)((band + 7u) / 8u) * sizeof(uint32_t); }
+
+} // anonymous namespace
+} // namespace nvbio_amd
+
+using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_banded_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch, uint32_t band, uint64_t* bytes)
+{
+    NVB_REQUIRE( batch && bytes, "batch/bytes is NULL" );
+    NVB_REQUIRE( band == 3 || band == 7 || band == 15 || band == 31, "band must be 3, 7, 15 or 31" );
+    NVB_REQUIRE( batch->n == 0 || batch->max_read_len > 0, "batch.max_read_len must bound the pattern lengths" );
+    *bytes = (uint64_t)batch->n * batch->max_read_len * row_bytes( band );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
+                                                     const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                                     int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                     uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                     void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( band == 3 || band == 7 || band == 15 || band == 31, "band must be 3, 7, 15 or 31" );
+    NVB_REQUIRE( scores_dev && sources_dev && sinks_dev && cigar_lens_dev, "NULL output pointer" );
+    NVB_REQUIRE( cigars_dev != nullptr || cigar_stride == 0, "cigars_dev is NULL" );
+    NVB_REQUIRE( b.max_read_len > 0, "batch.max_read_len must bound the pattern lengths (it sizes the direction-vector scratch)" );
+
+    // the reference re-derives the direction vectors from int16 checkpoints (clamped at -32736,
+    // gotoh_banded_inl.h:216-222); the single pass here equals that iff no score can leave that range
+    {
+        int64_t step = scheme->match < 0 ? -(int64_t)scheme->match : scheme->match;
+        const int64_t c[] = { scheme->mm_min, scheme->mm_max, -(int64_t)scheme->pat_gap_open, -(int64_t)scheme->pat_gap_ext,
+                              -(int64_t)scheme->txt_gap_open, -(int64_t)scheme->txt_gap_ext };
+        for (int64_t v : c) { if (v < 0) v = -v; if (v > step) step = v; }
+        if (((int64_t)b.max_read_len + band + 1) * step > 30000)
+        {
+            set_error( "banded traceback: scores of %u-symbol reads under this scheme can overflow the reference's int16 checkpoints", b.max_read_len );
+            return NVBIO_ERR_UNSUPPORTED;
+        }
+    }
+
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
+                     scheme->txt_gap_open, scheme->txt_gap_ext };
+
+    const uint64_t per_job = (uint64_t)b.max_read_len * row_bytes( band );
+    void*     owned = nullptr;
+    uint32_t* dirs  = (uint32_t*)temp_dev;
+    uint64_t  cap_jobs;
+    if (dirs)
+    {
+        cap_jobs = temp_bytes / per_job;
+        NVB_REQUIRE( cap_jobs >= 64 || cap_jobs >= b.n, "temp_bytes too small (see nvbio_banded_gotoh_traceback_temp_bytes)" );
+    }
+    else
+    {
+        cap_jobs = b.n;
+        const uint64_t budget = 16ull << 30;                     // at most 16 GiB of scratch per launch
+        if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
+        if (cap_jobs < 64) cap_jobs = 64;
+        if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
+        {
+            set_error( "banded traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
+            return NVBIO_ERR_NOMEM;
+        }
+        dirs = (uint32_t*)owned;
+    }
+    nvbio_status st = NVBIO_OK;
+    for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
+    {
+        const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
+#define NVB_BAND(B) st = launch_type<B>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, dirs, scores_dev, \
+                                         (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s )
+        switch (band)
+        {
+        case 3:  NVB_BAND(3);  break;
+        case 7:  NVB_BAND(7);  break;
+        case 15: NVB_BAND(15); break;
+        default: NVB_BAND(31); break;
+        }
+#undef NVB_BAND
+    }
+    if (owned) (void)hipFreeAsync( owned, s );
+    return st;
+}

@@ -1,0 +1,142 @@
+"""GPU parity: batched banded Gotoh traceback (score, source, sink, run-length CIGAR) through the C-ABI
+vs the reference's golden vectors (tests/golden/tb_golden.npz) and the oracle on nvBowtie-shaped batches."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _scheme(amd, v):
+    return amd.GotohScheme(*[int(x) for x in v])
+
+
+def _i64(t):
+    return t.cpu().numpy().astype(np.int64)
+
+
+def test_traceback_golden(amd, dp_golden, tb_golden):
+    g, t = dp_golden, tb_golden
+    S = len(g["schemes"])
+    nk = int(g["n_known"])
+    n = len(g["pat_off"]) - 1
+    max_len = int(np.diff(g["pat_off"]).max())
+    groups = {}
+    for i in range(n):
+        key = ("k", i) if i < nk else ("s", i % S, int(g["has_quals"][i]))
+        groups.setdefault(key, []).append(i)
+    checked = 0
+    STRIDE = 96
+    for key, cases in groups.items():
+        cases = np.array(cases, dtype=np.uint32)
+        sv = g["known_schemes"][cases[0]] if key[0] == "k" else g["schemes"][key[1]]
+        hq = bool(g["has_quals"][cases[0]])
+        batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1],
+                                   quals=g["quals"] if hq else None, read_id=cases, max_read_len=max_len)
+        for bi, band in enumerate(t["bands"]):
+            for typ in range(3):
+                al = amd.make_gotoh_aligner(typ, _scheme(amd, sv))
+                sc, src, snk, cig, ln = amd.BatchedBandedAlignmentTraceback(int(band), al).enact(batch, cigar_stride=STRIDE)
+                sc, src, snk, ln = _i64(sc), _i64(src), _i64(snk), _i64(ln)
+                cig = cig.cpu().numpy().view(np.uint16)
+                for k, i in enumerate(cases):
+                    want = t["aln"][i, bi, typ]
+                    if want[0] < 0:
+                        continue                                   # the reference reads past a < BAND-1 text: not pinned
+                    lo, hi = t["cig_off"][i, bi, typ]
+                    assert sc[k] == want[1], (i, band, typ)
+                    assert tuple(src[k]) == (want[2], want[3]) and tuple(snk[k]) == (want[4], want[5]), (i, band, typ)
+                    assert ln[k] == hi - lo, (i, band, typ)
+                    m = min(int(ln[k]), STRIDE)                 # elements beyond the stride are dropped, the count is not
+                    assert np.array_equal(cig[k, :m], t["cigars"][lo:lo + m]), (i, band, typ)
+                    checked += 1
+    assert checked > 4000
+    # the reference's functional tests (alignment_test.cu:743-746,779-785): 4M1D3M and 147M2D3M in backtracking order
+    for k, band, sv, want in ((0, 7, (2, 1, 1, -1, -1, -1, -1), "4M1D3M"), (1, 31, (0, 5, 5, -8, -3, -8, -3), "147M2D3M")):
+        c = np.array([k], dtype=np.uint32)
+        batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][c], g["txt_off"][c + 1], read_id=c,
+                                   max_read_len=max_len)
+        out = amd.BatchedBandedAlignmentTraceback(band, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv))).enact(batch)
+        assert amd.cigar_string(out[3][0].cpu().numpy(), int(out[4][0]), forward=False) == want
+
+
+@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
+def test_traceback_packed_batch_vs_oracle(amd, orc, typ):
+    """nvBowtie-shaped: 4-bit reads with reversed / complemented flags and qualities against 2-bit genome
+    windows (clipped at both genome ends, some shorter than the read), ragged read lengths, chunked scratch"""
+    import torch
+    typ = getattr(oracle, typ)
+    rng = np.random.default_rng(5)
+    G = 300000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R = 3000
+    lens = rng.integers(30, 151, R); lens[::2] = 150
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(0, G - 200, R)
+    reads = []
+    for s, l in zip(starts, lens):
+        r = text[s:s + l].copy()
+        mut = rng.random(l) < 0.02
+        r[mut] = rng.integers(0, 4, int(mut.sum()))
+        if rng.random() < 0.4:                                    # an indel of 1-3 bp
+            k = int(rng.integers(5, l - 5)); gsz = int(rng.integers(1, 4))
+            r = np.concatenate([r[:k], r[k + gsz:], rng.integers(0, 4, gsz, dtype=np.uint8)]) if rng.random() < 0.5 \
+                else np.concatenate([r[:k], rng.integers(0, 4, gsz, dtype=np.uint8), r[k:l - gsz]])
+        reads.append(r)
+    flat = np.concatenate(reads)
+    flat[rng.integers(0, len(flat), 100)] = 4
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    J = 9001
+    rid = rng.integers(0, R, J).astype(np.uint32)
+    flags = np.zeros(J, dtype=np.uint8); flags[J // 2:] = rng.integers(0, 4, J - J // 2)
+    g_pos = starts[rid].astype(np.int64) + rng.integers(-4, 5, J)
+    g_pos[::50] = rng.integers(0, 10, len(g_pos[::50]))
+    g_pos[1::50] = G - rng.integers(20, 170, len(g_pos[1::50]))
+    g_pos = np.clip(g_pos, 0, G - 1)
+    wb = np.where(g_pos > 15, g_pos - 15, 0).astype(np.uint32)
+    we = np.minimum(wb + 31 + lens[rid], G).astype(np.uint32)
+    sel = np.nonzero((we - wb) >= 30)[0]
+    stride = 48
+    for sv in ((2, 2, 6, -8, -3, -8, -3), (0, 6, 6, -8, -3, -8, -3), (1, 3, 3, -11, -4, -6, -2)):
+        for use_q in (True, False):
+            kw = dict(quals=quals if use_q else None, read_id=rid[sel], flags=flags[sel])
+            want = orc.banded_gotoh_traceback_packed_batch(31, typ, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text),
+                                                           wb[sel], we[sel], stride, **kw)
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb[sel], we[sel], max_read_len=150, **kw)
+            op = amd.BatchedBandedAlignmentTraceback(31, amd.make_gotoh_aligner(typ, _scheme(amd, sv)))
+            need = op.min_temp_storage(batch)
+            assert need == len(sel) * 150 * 16
+            # caller scratch for a third of the jobs: the batch is processed in several launches
+            temp = torch.empty(need // 3 + 16, dtype=torch.uint8, device="cuda:0")
+            for tmp in (None, temp):
+                sc, src, snk, cig, ln = op.enact(batch, cigar_stride=stride, temp=tmp)
+                assert np.array_equal(sc.cpu().numpy(), want[0]), (sv, use_q)
+                assert np.array_equal(amd.u32(src), want[1]) and np.array_equal(amd.u32(snk), want[2]), (sv, use_q)
+                assert np.array_equal(amd.u32(ln), want[4]), (sv, use_q)
+                assert np.array_equal(cig.cpu().numpy().view(np.uint16), want[3]), (sv, use_q)
+            # the scores and sinks are those of the scoring kernel
+            s2, k2 = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, _scheme(amd, sv)), batch)
+            assert np.array_equal(s2.cpu().numpy(), want[0]) and np.array_equal(amd.u32(k2), want[2])
+    assert (want[4] > 3).any() and (want[4] == 0).any()           # gapped alignments and untraceable jobs are both in
+
+
+def test_traceback_argument_errors(amd, orc):
+    txt = np.zeros(256, dtype=np.uint8)
+    pats = np.zeros(80, dtype=np.uint8)
+    roffs = np.array([0, 40, 80], dtype=np.uint32)
+    wb = np.array([0, 0], dtype=np.uint32); we = np.array([71, 64], dtype=np.uint32)
+    al = amd.make_gotoh_aligner(oracle.LOCAL, amd.SimpleGotohScheme(2, -1, -2, -1))
+    with pytest.raises(amd.NvbioError):                            # max_read_len is required
+        amd.BatchedBandedAlignmentTraceback(31, al).enact(amd.AlignmentBatch(pats, 8, roffs, txt, 8, wb, we))
+    with pytest.raises(amd.NvbioError):                            # unsupported band
+        amd.BatchedBandedAlignmentTraceback(9, al).enact(amd.AlignmentBatch(pats, 8, roffs, txt, 8, wb, we, max_read_len=40))
+    with pytest.raises(amd.NvbioError):                            # scores could overflow the int16 checkpoints
+        amd.BatchedBandedAlignmentTraceback(31, amd.make_gotoh_aligner(oracle.LOCAL, amd.SimpleGotohScheme(900, -1, -2, -1))).enact(
+            amd.AlignmentBatch(pats, 8, roffs, txt, 8, wb, we, max_read_len=40))
+    # a pattern longer than max_read_len is skipped and flagged, the other job is traced: 40 matches
+    out = amd.BatchedBandedAlignmentTraceback(31, al).enact(
+        amd.AlignmentBatch(pats, 8, np.array([0, 30, 80], dtype=np.uint32), txt, 8, wb, np.array([61, 90], dtype=np.uint32), max_read_len=30))
+    ln = amd.u32(out[4])
+    assert ln[1] == 0xFFFFFFFF and ln[0] == 1 and int(out[0][0]) == 60
+    assert amd.cigar_string(out[3][0].cpu().numpy(), 1) == "30M"
