@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -200,6 +201,28 @@ def main():
     frac_aligned = float(aligned.float().mean())
     frac_correct = float((aligned & near & (brc.bool() == truth_rc)).float().mean())
 
+    # ---- traceback of every read's best alignment (not part of the timed step) ----
+    tb_ms, tb_info = None, None
+    if not args.no_traceback:
+        _, _, _, _, bwb = pipeline.seed_and_extend(fmi, genome, n, batch, params, None, return_windows=True)
+        tms = []
+        for _ in range(3):
+            tt = {}
+            ids, tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=16, timers=tt, best_pos=bp)
+            torch.cuda.synchronize()
+            tms.append(event_ms(tt["traceback"])[0])
+        tb_ms = float(np.median(tms))
+        lens_i = tln.to(torch.int64) & 0xFFFFFFFF
+        tb_info = {"kernels": "ungapped_traceback_kernel<31,%s,4,2> (diagonal check, settles ungapped reads) + banded_gotoh_traceback_kernel "
+                              "(the rest: one DP pass writing 16 B of direction vectors per row, walk back to a run-length CIGAR)%s"
+                              % ("SEMI_GLOBAL" if args.mode == "e2e" else "LOCAL",
+                                 "; score and sink handed over from the scoring pass" if args.mode == "e2e" else "; scoring pass re-run inside"),
+                   "reads": int(ids.numel()), "ms": tb_ms, "reads_per_s": ids.numel() / (tb_ms * 1e-3),
+                   "gapped_fraction": float((lens_i > 1).float().mean()),
+                   "scores_equal_scoring_pass": bool(torch.equal(tsc, bs[ids])),
+                   "mean_cigar_elements": float(lens_i.float().mean()), "max_cigar_elements": int(lens_i.max())}
+        del bwb, ids, tsc, tpos, tsrc, tsnk, tcig, tln
+
     # ---- stage times and the roofline of the dominant HBM kernel (the seed pass match kernel) --
     stage_ms = {k: float(np.mean(event_ms(v))) for k, v in timers.items()}
     spr = (M - params.seed_len) // params.interval_for(M) + 1
@@ -268,6 +291,7 @@ def main():
                    "bound": "valu (integer; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
+        "traceback": tb_info,
     }
 
     # ---- CPU baseline on a bounded sample of the same reads, all host cores ------------------------

@@ -307,14 +307,20 @@ nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbio_alignment
  * The reference recomputes the direction vectors from int16 checkpoints; this call returns
  * NVBIO_ERR_UNSUPPORTED for (scheme, max_read_len) combinations whose scores could leave that range, where the
  * reference's own result is truncation-dependent.
+ * flags: NVBIO_TRACEBACK_SINKS_GIVEN -- scores_dev / sinks_dev already hold what nvbio_banded_gotoh_score returns
+ * for this very batch (nvBowtie traces alignments it has scored, traceback_inl.h:103-113); the scoring pass is skipped.
+ * Implementation note: jobs whose optimum is reached by the diagonal through the sink alone are traced without a
+ * DP (the reference's tie rule makes their traceback all substitutions); the others run the DP once, writing
+ * their direction vectors to scratch.  Results do not depend on which route a job takes.
  * temp_dev / temp_bytes: optional caller scratch (nvbio_banded_gotoh_traceback_temp_bytes); if NULL the library
  * allocates stream-ordered scratch and processes the batch in as many launches as 16 GiB allow. */
+enum { NVBIO_TRACEBACK_SINKS_GIVEN = 1 };
 nvbio_status nvbio_banded_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t band, uint64_t* bytes);
 nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
                                           const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
                                           int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
                                           uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
-                                          void* temp_dev, uint64_t temp_bytes, void* stream);
+                                          uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
 
 /* full-matrix Gotoh: aln::alignment_score / BatchedAlignmentScore (nvbio/alignment/gotoh/gotoh_inl.h:444-1256,
  * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default

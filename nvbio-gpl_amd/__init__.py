@@ -29,6 +29,7 @@ GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
 FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY = 1, 2, 4, 8
 READ_REVERSE, READ_COMPLEMENT = 1, 2
+TRACEBACK_SINKS_GIVEN = 1
 
 _STATUS = {0: "OK", 1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "UNSUPPORTED", 5: "NO_DEVICE"}
 
@@ -465,19 +466,23 @@ class BatchedBandedAlignmentTraceback:
         _check(lib().nvbio_banded_gotoh_traceback_temp_bytes(ctypes.byref(bs), ctypes.c_uint32(self.band_len), ctypes.byref(out)))
         return int(out.value)
 
-    def enact(self, batch, cigar_stride=64, temp=None):
+    def enact(self, batch, cigar_stride=64, temp=None, scores=None, sinks=None):
+        """scores / sinks: optional results of BatchedBandedAlignmentScore for the same batch (the scoring pass is
+        then skipped, NVBIO_TRACEBACK_SINKS_GIVEN)"""
         torch = _torch()
         n, dev = batch.n, batch.device
-        scores = torch.empty(n, dtype=torch.int32, device=dev)
+        given = scores is not None and sinks is not None
+        if not given:
+            scores = torch.empty(n, dtype=torch.int32, device=dev)
+            sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
         sources = torch.empty((n, 2), dtype=torch.int32, device=dev)
-        sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
         cigars = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev)
         lens = torch.empty(n, dtype=torch.int32, device=dev)
         bs = batch.c_struct()
         _check(lib().nvbio_banded_gotoh_traceback(
             FMIndex._dev_index(dev), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
             ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs), _ptr(scores), _ptr(sources), _ptr(sinks), _ptr(cigars),
-            ctypes.c_uint32(cigar_stride), _ptr(lens), _ptr(temp),
+            ctypes.c_uint32(cigar_stride), _ptr(lens), ctypes.c_uint32(TRACEBACK_SINKS_GIVEN if given else 0), _ptr(temp),
             ctypes.c_uint64(0 if temp is None else temp.numel() * temp.element_size()), _stream_ptr(dev)))
         return scores, sources, sinks, cigars, lens
 

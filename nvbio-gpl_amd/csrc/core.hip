@@ -43,6 +43,20 @@ nvbio_status use_device(int device)
         set_error( "hipSetDevice(%d) failed", device );
         return NVBIO_ERR_HIP;
     }
+    // Scratch (boundary columns, direction vectors, scan temporaries) comes from the device's stream-ordered
+    // pool.  By default the pool hands freed blocks back to the driver at every synchronisation, which makes
+    // each call pay for mapping gigabytes again (measured: 1.4 s per 16 GiB); let it keep up to 24 GiB.
+    static bool pool_ready[64] = { false };
+    if (device < 64 && !pool_ready[device])
+    {
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool( &pool, device ) == hipSuccess)
+        {
+            uint64_t keep = 24ull << 30;
+            (void)hipMemPoolSetAttribute( pool, hipMemPoolAttrReleaseThreshold, &keep );
+        }
+        pool_ready[device] = true;
+    }
     return NVBIO_OK;
 }
 

@@ -19,6 +19,8 @@
 // The two are identical as long as every score fits the reference's int16 checkpoints, which the
 // host checks from the scheme and the batch's max_read_len (else NVBIO_ERR_UNSUPPORTED).
 #include "gotoh_common.h"
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace nvbio_amd {
 
@@ -29,6 +31,7 @@ enum : uint32_t { D_SUB = 0u, D_INS = 1u, D_DEL = 2u, D_SINK = 3u, D_INS_EXT = 4
 template <int BAND, int TYPE, int RBITS, int TBITS>
 __global__ void __launch_bounds__(128)
 banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin, const uint32_t jobs,
+                              const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
                               uint32_t* __restrict__ dirs,
                               int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
                               uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens)
@@ -41,7 +44,10 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // slot inside this launch
     if (t >= jobs) return;
-    const uint32_t job = job_begin + t;
+    // with a job list (the jobs the ungapped pass could not settle) slot t of this launch is entry
+    // job_begin + t of the list, and the list's length lives on the device
+    if (job_list && job_begin + t >= *job_count) return;
+    const uint32_t job = job_list ? job_list[job_begin + t] : job_begin + t;
 
     const uint32_t rid   = b.read_id ? b.read_id[job] : job;
     const uint32_t first = b.read_offsets[rid];
@@ -264,13 +270,129 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
     cigar_lens[job] = clen;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ungapped shortcut.  Let S* and the sink come from the scoring pass, and let Q_k be the score of
+// the k diagonal steps that end in the sink.  If the diagonal alone reaches S* (LOCAL: some Q_k = S*;
+// otherwise H_0[entry] + Q_sink.y = S*), every cell on it holds exactly its prefix score -- more
+// would beat the optimum, less would not reach it -- so at each of them the diagonal move ties for
+// the maximum, and the reference's direction rule resolves ties to SUBSTITUTION (strict `>` at
+// gotoh_banded_inl.h:553-556); a LOCAL walk stops at the first cell whose score is 0, i.e. at the
+// smallest k with Q_k = S*.  The traceback of such a job is therefore k substitutions along the
+// diagonal, known without running the DP; only the other jobs (need_dp = 1) go through it.
+// Symbols compare exactly as in the DP: beyond the text end the sentinel 255, which a band-31
+// (2-bit cached) column < 30 sees as 3 (alignment_base_inl.h:66-90).
+// ---------------------------------------------------------------------------------------------
+template <int BAND, int TYPE, int RBITS, int TBITS>
+__global__ void __launch_bounds__(256)
+ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                          uint2* __restrict__ sources, uint16_t* __restrict__ cigars, const uint32_t cigar_stride,
+                          uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp)
+{
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    const uint2    sink  = sinks[job];
+    const int32_t  best  = scores[job];
+
+    need_dp[job] = 0;
+    if (M > b.max_read_len) { sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0xFFFFFFFFu; return; }
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu)
+    {
+        sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0;
+        return;
+    }
+
+    constexpr bool PACKED = !(BAND == 3 || BAND == 5 || BAND == 7 || BAND == 15);
+    const uint32_t entry = sink.x - sink.y;
+    const int32_t  H0 = (TYPE == NVBIO_GLOBAL && entry > 0u) ? sc.txt_go + (int32_t)(entry - 1u) * sc.txt_ge : 0;
+
+    SymbolReader<TBITS> trd( b.text );
+    SymbolReader<RBITS> prd( b.reads );
+
+    int32_t  Q = 0;
+    uint32_t k = 0;
+    bool found = (TYPE == NVBIO_LOCAL) && (best == 0);
+    for (int32_t row = (int32_t)sink.y - 1; row >= 0 && !found; --row)
+    {
+        const uint32_t pidx = rev ? first + M - 1u - (uint32_t)row : first + (uint32_t)row;
+        uint32_t q = prd.get( pidx );
+        if (comp && q < 4u) q = 3u - q;
+        const uint32_t qq = b.quals ? b.quals[pidx] : 0u;
+        const uint32_t ti = (uint32_t)row + entry;
+        const uint32_t g  = ti < N ? trd.get( tb + ti ) : 255u;
+        const bool eq = (entry == (uint32_t)(BAND - 1) || !PACKED) ? (g == q) : (q < 4u && (g & 3u) == q);
+        Q += eq ? sc.match : s_mm[qq < 63u ? qq : 63u];
+        ++k;
+        if (TYPE == NVBIO_LOCAL && Q == best) found = true;
+    }
+    if (TYPE != NVBIO_LOCAL) found = (H0 + Q == best);
+    if (!found) { need_dp[job] = 1; return; }
+
+    uint16_t* cig = cigars + (size_t)job * cigar_stride;
+    uint32_t  clen = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) {
+        if (clen < cigar_stride) cig[clen] = (uint16_t)(type | (len << 2));
+        ++clen;
+    };
+    if (M - sink.y) emit( 3u, M - sink.y );
+    if (k)          emit( D_SUB, k );
+    if (sink.y - k) emit( 3u, sink.y - k );
+    sources[job]    = make_uint2( sink.x - k, sink.y - k );
+    cigar_lens[job] = clen;
+}
+
+template <int BAND, int TYPE>
+nvbio_status launch_ungapped(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, const int32_t* scores, const uint2* sinks,
+                             uint2* sources, uint16_t* cigars, uint32_t stride, uint32_t* lens, uint8_t* need_dp, hipStream_t s)
+{
+    const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (ungapped_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks, sources, cigars, stride, lens, need_dp )
+    if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
+    else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
+    else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
+    else if (rbits == 8 && tbits == 8) NVB_GO(8, 8);
+    else if (rbits == 4 && tbits == 8) NVB_GO(4, 8);
+    else if (rbits == 2 && tbits == 8) NVB_GO(2, 8);
+    else { set_error( "unsupported read_bits/text_bits %u/%u", rbits, tbits ); return NVBIO_ERR_INVALID; }
+#undef NVB_GO
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+template <int BAND>
+nvbio_status launch_ungapped_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, const int32_t* scores,
+                                  const uint2* sinks, uint2* sources, uint16_t* cigars, uint32_t stride, uint32_t* lens, uint8_t* need_dp,
+                                  hipStream_t s)
+{
+    switch (type)
+    {
+    case NVBIO_GLOBAL:      return launch_ungapped<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
+    case NVBIO_LOCAL:       return launch_ungapped<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
+    case NVBIO_SEMI_GLOBAL: return launch_ungapped<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
+    }
+    set_error( "invalid alignment type %d", type );
+    return NVBIO_ERR_INVALID;
+}
+
 template <int BAND, int TYPE>
 nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
-                         uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
+                         const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
                          uint32_t* lens, hipStream_t s)
 {
     const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
-#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens )
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -285,14 +407,14 @@ nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits,
 
 template <int BAND>
 nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
-                         uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
+                         const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
                          uint32_t* lens, hipStream_t s)
 {
     switch (type)
     {
-    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
-    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
-    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
     }
     set_error( "invalid alignment type %d", type );
     return NVBIO_ERR_INVALID;
@@ -318,7 +440,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
                                                      const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
                                                      int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
                                                      uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
-                                                     void* temp_dev, uint64_t temp_bytes, void* stream)
+                                                     uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
 {
     NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
     BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
@@ -347,6 +469,49 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
                      scheme->txt_gap_open, scheme->txt_gap_ext };
 
+    // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
+    const bool shortcut = !getenv( "NVBIO_AMD_NO_UNGAPPED_TRACEBACK" );
+    uint8_t*  need_dp   = nullptr;      // [n] flags
+    uint32_t* job_list  = nullptr;      // [n] compacted job ids
+    uint32_t* job_count = nullptr;      // [1]
+    void*     sel_temp  = nullptr;
+    void*     aux       = nullptr;
+    if (shortcut)
+    {
+        if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
+            NVB_CHECK( nvbio_banded_gotoh_score( device, band, type, scheme, batch, scores_dev, sinks_dev, stream ) );
+        size_t sel_bytes = 0;
+        hipcub::CountingInputIterator<uint32_t> ids( 0u );
+        NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
+        const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
+        const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        {
+            set_error( "banded traceback: out of device memory for the job list" );
+            return NVBIO_ERR_NOMEM;
+        }
+        need_dp   = (uint8_t*)aux;
+        job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
+        job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
+        sel_temp  = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        nvbio_status st1;
+#define NVB_BAND(B) st1 = launch_ungapped_type<B>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (const uint2*)sinks_dev, \
+                                                   (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp, s )
+        switch (band)
+        {
+        case 3:  NVB_BAND(3);  break;
+        case 7:  NVB_BAND(7);  break;
+        case 15: NVB_BAND(15); break;
+        default: NVB_BAND(31); break;
+        }
+#undef NVB_BAND
+        if (st1 != NVBIO_OK) { (void)hipFreeAsync( aux, s ); return st1; }
+        // ---- 3. the jobs that do need the DP, compacted (their number stays on the device) ----
+        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    }
+
+    // ---- 4. the DP with direction vectors + walk back, over the job list (or every job) ----
     const uint64_t per_job = (uint64_t)b.max_read_len * row_bytes( band );
     void*     owned = nullptr;
     uint32_t* dirs  = (uint32_t*)temp_dev;
@@ -354,16 +519,25 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     if (dirs)
     {
         cap_jobs = temp_bytes / per_job;
-        NVB_REQUIRE( cap_jobs >= 64 || cap_jobs >= b.n, "temp_bytes too small (see nvbio_banded_gotoh_traceback_temp_bytes)" );
+        if (!(cap_jobs >= 64 || cap_jobs >= b.n))
+        {
+            if (aux) (void)hipFreeAsync( aux, s );
+            set_error( "invalid argument: temp_bytes too small (see nvbio_banded_gotoh_traceback_temp_bytes)" );
+            return NVBIO_ERR_INVALID;
+        }
     }
     else
     {
-        cap_jobs = b.n;
+        // with the shortcut only the gapped alignments reach the DP (a minority of a read batch): size the
+        // scratch for a quarter of the jobs per launch -- launches over an exhausted job list exit at once
+        cap_jobs = shortcut ? ((uint64_t)b.n + 3u) / 4u : b.n;
+        if (cap_jobs < 65536u) cap_jobs = b.n < 65536u ? b.n : 65536u;
         const uint64_t budget = 16ull << 30;                     // at most 16 GiB of scratch per launch
         if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
         if (cap_jobs < 64) cap_jobs = 64;
         if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
+            if (aux) (void)hipFreeAsync( aux, s );
             set_error( "banded traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
         }
@@ -373,7 +547,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
     {
         const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
-#define NVB_BAND(B) st = launch_type<B>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, dirs, scores_dev, \
+#define NVB_BAND(B) st = launch_type<B>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, job_list, job_count, dirs, scores_dev, \
                                          (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s )
         switch (band)
         {
@@ -385,5 +559,6 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 #undef NVB_BAND
     }
     if (owned) (void)hipFreeAsync( owned, s );
+    if (aux)   (void)hipFreeAsync( aux, s );
     return st;
 }

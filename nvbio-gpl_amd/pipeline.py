@@ -70,9 +70,11 @@ def pack_best_key(torch, scores, rc, pos):
     return (s << 34) | (rc.to(torch.int64) << 33) | pos.to(torch.int64)
 
 
-def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
+def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return_windows=False):
     """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end, or -1),
-    best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events."""
+    best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events.
+    return_windows: also return best_wb[int64 R], the window begin of each read's best candidate (-1 if
+    none; the largest one if several candidates tie on the whole selection key) -- what traceback_best needs."""
     import torch
     from . import diagonals_to_windows, hits_to_diagonals
     dev = fmi.device
@@ -119,7 +121,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
         pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
         sel = pack_best_key(torch, scores, rc, pos)
         tock(e)
-        return rid.to(torch.int64), sel
+        return rid.to(torch.int64), sel, (wb if return_windows else None)
 
     results, n_cand = [], 0
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
@@ -154,12 +156,14 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     best_pos = torch.full((R,), -1, dtype=torch.int64, device=dev)
     best_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
     if not results:
+        if return_windows:
+            return best_score, best_pos, best_rc, 0, torch.full((R,), -1, dtype=torch.int64, device=dev)
         return best_score, best_pos, best_rc, 0
 
     # 5. best candidate per read
     e = tick("reduce")
     top = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    for rid, sel in results:
+    for rid, sel, _ in results:
         top.scatter_reduce_(0, rid, sel, "amax", include_self=True)
     has = top >= 0
     sv = top >> 34
@@ -167,4 +171,50 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None):
     best_pos = torch.where(has, top & ((1 << 33) - 1), best_pos)
     best_rc = torch.where(has, ((top >> 33) & 1).to(torch.uint8), best_rc)
     tock(e)
+    if return_windows:
+        best_wb = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        for rid, sel, wb in results:
+            win = sel == top[rid]
+            best_wb.scatter_reduce_(0, rid[win], (wb.to(torch.int64) & 0xFFFFFFFF)[win], "amax", include_self=True)
+        return best_score, best_pos, best_rc, int(n_cand), best_wb
     return best_score, best_pos, best_rc, int(n_cand)
+
+
+def traceback_best(genome2, genome_len, reads, params, best_score, best_rc, best_wb, cigar_stride=32, timers=None,
+                   best_pos=None):
+    """nvBowtie's banded_traceback_best (traceback_inl.h:191-247) for the pipeline's best alignment per read:
+    re-align every aligned read inside its best candidate's window with the traceback kernel.
+    Returns (read ids [A], scores, align_pos [A] int64 = text position where the alignment starts,
+    sources, sinks, cigars [A, cigar_stride] (io::Cigar elements, backtracking order), cigar_lens)."""
+    import torch
+    from . import BatchedBandedAlignmentTraceback
+    dev = best_score.device
+    R, M = reads.n, reads.read_len
+    ids = torch.nonzero(best_wb >= 0).view(-1)
+    wb = best_wb[ids]
+    we = torch.clamp(wb + params.band + M, max=genome_len)
+    flags = (best_rc[ids].to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8)
+    read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+
+    def i32(t):
+        return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32)
+
+    batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, i32(wb), i32(we), quals=reads.quals,
+                           read_id=ids.to(torch.int32), flags=flags, device=dev, max_read_len=M)
+    ev = None
+    if timers is not None:
+        a, ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        timers.setdefault("traceback", []).append((a, ev))
+        a.record()
+    known = {}
+    if best_pos is not None and params.aln_type != LOCAL:
+        # the scoring pass already ran on exactly these windows: hand its score and sink over (an end-to-end
+        # alignment ends in the last pattern row, so the sink is (end position - window begin, read length))
+        sx = (best_pos[ids] - wb).to(torch.int32)
+        known = dict(scores=best_score[ids].contiguous(), sinks=torch.stack([sx, torch.full_like(sx, M)], dim=1).contiguous())
+    sc, src, snk, cig, ln = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme)).enact(
+        batch, cigar_stride=cigar_stride, **known)
+    if ev is not None:
+        ev.record()
+    pos = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+    return ids, sc, pos, src, snk, cig, ln

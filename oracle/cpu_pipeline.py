@@ -107,8 +107,10 @@ def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, se
 
 
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
-                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False):
-    """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates)."""
+                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0):
+    """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates); with
+    traceback_stride > 0 also a dict with the traceback of every aligned read's best candidate (the one with
+    the largest window begin among candidates tying on the selection key)."""
     scheme = scheme or Scheme(2, 2, 6, -8, -3, -8, -3)
     R, M = reads.shape
     L = seed_len
@@ -164,4 +166,16 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
     best_score = np.where(has & (sv > 0), sv - (1 << 20), best_score).astype(np.int32)
     best_pos = np.where(has, top & ((1 << 33) - 1), best_pos)
     best_rc = np.where(has, (top >> 33) & 1, best_rc).astype(np.uint8)
+    if traceback_stride:
+        best_wb = np.full(R, -1, dtype=np.int64)
+        win = packed == top[rid]
+        np.maximum.at(best_wb, rid[win], wb[win].astype(np.int64))
+        ids = np.nonzero(best_wb >= 0)[0]
+        twb = best_wb[ids]
+        twe = np.minimum(twb + band + M, genome_len)
+        sc, src, snk, cig, ln = O.banded_gotoh_traceback_packed_batch(
+            band, aln_type, scheme, reads4, roffs, genome2, twb.astype(np.uint32), twe.astype(np.uint32), traceback_stride,
+            read_id=ids.astype(np.uint32), flags=(best_rc[ids] * 3).astype(np.uint8), quals=quals)
+        tb = dict(ids=ids, scores=sc, pos=twb + src[:, 0].astype(np.int64), sources=src, sinks=snk, cigars=cig, lens=ln)
+        return best_score, best_pos, best_rc, len(keys), tb
     return best_score, best_pos, best_rc, len(keys)

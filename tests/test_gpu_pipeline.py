@@ -36,15 +36,15 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     reads[-20:] = rng.integers(0, 4, (20, M))            # unalignable reads
     if mode == "local":
         params = pipeline.SeedExtendParams()
-        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads)
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, traceback_stride=24)
     else:                                                 # nvBowtie default mode, constant quality
         params = pipeline.SeedExtendParams.end_to_end()
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
-                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3))
+                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3), traceback_stride=24)
         assert params.min_score_for(150) == -90
     rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
-    bs, bp, brc, nc = pipeline.seed_and_extend(fmi, torch.from_numpy(genome2.view(np.int32)).cuda(), G, rb,
-                                               params)
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    bs, bp, brc, nc, bwb = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, return_windows=True)
     assert want[3] <= nc <= want[3] * 1.10           # adjacent-duplicate removal may keep a few repeats
     assert np.array_equal(bs.cpu().numpy(), want[0])
     assert np.array_equal(bp.cpu().numpy(), want[1])
@@ -55,4 +55,18 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     near = np.abs(bp.cpu().numpy()[70:-20] - (starts[70:-20] + M)) <= 40
     assert near.mean() > 0.98
     assert (brc.cpu().numpy()[70:-20][near] == rcm[70:-20][near]).all()
+    # traceback of every aligned read's best candidate: CIGARs equal the CPU path's
+    ids, tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best(g_dev, G, rb, params, bs, brc, bwb, cigar_stride=24, best_pos=bp)
+    tb = want[4]
+    assert np.array_equal(ids.cpu().numpy(), tb["ids"])
+    assert np.array_equal(tsc.cpu().numpy(), tb["scores"]) and np.array_equal(tsc.cpu().numpy(), bs.cpu().numpy()[tb["ids"]])
+    assert np.array_equal(tpos.cpu().numpy(), tb["pos"])
+    assert np.array_equal(amd.u32(tsrc), tb["sources"]) and np.array_equal(amd.u32(tsnk), tb["sinks"])
+    assert np.array_equal(amd.u32(tln), tb["lens"]) and np.array_equal(tcig.cpu().numpy().view(np.uint16), tb["cigars"])
+    assert int(tb["lens"].max()) <= 24
+    # the traced alignment ends where the scoring pass said it would
+    assert np.array_equal(bwb.cpu().numpy()[tb["ids"]] + tb["sinks"][:, 0].astype(np.int64), bp.cpu().numpy()[tb["ids"]])
+    # reads with one indel carry exactly one gap element; most reads are a single run of matches
+    one_run = (tb["lens"] == 1).mean()
+    assert one_run > 0.4
     fmi.close()

@@ -16,7 +16,15 @@ def _i64(t):
     return t.cpu().numpy().astype(np.int64)
 
 
-def test_traceback_golden(amd, dp_golden, tb_golden):
+@pytest.fixture(params=["shortcut", "dp-only"])
+def tb_mode(request, monkeypatch):
+    """the ungapped shortcut (default) and the plain DP-for-every-job path must both equal the reference"""
+    if request.param == "dp-only":
+        monkeypatch.setenv("NVBIO_AMD_NO_UNGAPPED_TRACEBACK", "1")
+    return request.param
+
+
+def test_traceback_golden(amd, dp_golden, tb_golden, tb_mode):
     g, t = dp_golden, tb_golden
     S = len(g["schemes"])
     nk = int(g["n_known"])
@@ -62,7 +70,7 @@ def test_traceback_golden(amd, dp_golden, tb_golden):
 
 
 @pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
-def test_traceback_packed_batch_vs_oracle(amd, orc, typ):
+def test_traceback_packed_batch_vs_oracle(amd, orc, typ, tb_mode):
     """nvBowtie-shaped: 4-bit reads with reversed / complemented flags and qualities against 2-bit genome
     windows (clipped at both genome ends, some shorter than the read), ragged read lengths, chunked scratch"""
     import torch
@@ -118,6 +126,11 @@ def test_traceback_packed_batch_vs_oracle(amd, orc, typ):
             # the scores and sinks are those of the scoring kernel
             s2, k2 = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, _scheme(amd, sv)), batch)
             assert np.array_equal(s2.cpu().numpy(), want[0]) and np.array_equal(amd.u32(k2), want[2])
+            # ... and can be handed over instead of being recomputed (NVBIO_TRACEBACK_SINKS_GIVEN)
+            sc, src, snk, cig, ln = op.enact(batch, cigar_stride=stride, scores=s2, sinks=k2)
+            assert np.array_equal(sc.cpu().numpy(), want[0]) and np.array_equal(amd.u32(snk), want[2])
+            assert np.array_equal(amd.u32(src), want[1]) and np.array_equal(amd.u32(ln), want[4])
+            assert np.array_equal(cig.cpu().numpy().view(np.uint16), want[3]), (sv, use_q)
     assert (want[4] > 3).any() and (want[4] == 0).any()           # gapped alignments and untraceable jobs are both in
 
 
