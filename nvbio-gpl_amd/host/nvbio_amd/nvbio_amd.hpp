@@ -13,6 +13,8 @@
 //   aln::BatchedBandedAlignmentScore<BAND, stream, AmdDeviceScheduler>
 //                                  ~ nvbio/alignment/batched.h:298 / batched_banded_inl.h:128-157:
 //                                    min_temp_storage / max_temp_storage / enact(stream, temp_size, temp)
+//   aln::BatchedBandedAlignmentTraceback<BAND, CHECKPOINTS, stream, AmdDeviceScheduler>
+//                                  ~ nvbio/alignment/batched.h:420-437; output = Alignment + nvBowtie's io::Cigar runs
 //   aln::batch_banded_alignment_score<BAND>(aligner, batch, scores, sinks)
 //                                  ~ nvbio/alignment/batched.h:185
 // Errors: the reference surfaces CUDA failures as nvbio::cuda_error exceptions
@@ -276,6 +278,49 @@ struct BatchedAlignmentScore
         check( nvbio_full_gotoh_score( device, (nvbio_alignment_type)aligner_type::TYPE, text_blocking ? 1 : 0, &sc, &stream.batch(),
                                        stream.max_pattern_length(), stream.max_text_length(), min_scores_dev,
                                        stream.scores(), stream.sinks(), temp, temp_size, s ) );
+    }
+};
+
+// a traceback stream in flat form: the jobs of a FlatAlignmentStream plus where each job's Alignment
+// {score, source, sink} and io::Cigar elements go (the role of nvBowtie's BestTracebackStream::output, which
+// copies context->backtracer into pipeline.cigar, traceback_inl.h:115-160)
+template <typename aligner_t>
+struct FlatTracebackStream : FlatAlignmentStream<aligner_t>
+{
+    FlatTracebackStream(const aligner_t& a, const nvbio_alignment_batch& b, int32_t* scores_dev, nvbio_uint2* sources_dev,
+                        nvbio_uint2* sinks_dev, uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                        bool sinks_given = false)
+        : FlatAlignmentStream<aligner_t>( a, b, scores_dev, sinks_dev, b.max_read_len, 0 ), m_sources( sources_dev ),
+          m_cigars( cigars_dev ), m_stride( cigar_stride ), m_lens( cigar_lens_dev ), m_given( sinks_given ) {}
+    nvbio_uint2* sources() const { return m_sources; }
+    uint16_t*    cigars()  const { return m_cigars; }
+    uint32_t     cigar_stride() const { return m_stride; }
+    uint32_t*    cigar_lens()   const { return m_lens; }
+    bool         sinks_given()  const { return m_given; }
+    nvbio_uint2* m_sources; uint16_t* m_cigars; uint32_t m_stride; uint32_t* m_lens; bool m_given;
+};
+
+// aln::BatchedBandedAlignmentTraceback<BAND_LEN,CHECKPOINTS,stream,scheduler> (nvbio/alignment/batched.h:420-437).
+// CHECKPOINTS is accepted for source compatibility and ignored: the direction vectors of the whole band are kept
+// in scratch instead of being recomputed between checkpoints (same result, see include/nvbio_amd.h).
+template <uint32_t BAND_LEN, uint32_t CHECKPOINTS, typename stream_type, typename scheduler = AmdDeviceScheduler>
+struct BatchedBandedAlignmentTraceback
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64_t min_temp_storage(uint32_t max_pattern_len, uint32_t, uint32_t stream_size)
+    {
+        uint64_t bytes = 0; nvbio_alignment_batch b = {}; b.n = stream_size; b.max_read_len = max_pattern_len;
+        check( nvbio_banded_gotoh_traceback_temp_bytes( &b, BAND_LEN, &bytes ) );
+        return bytes;
+    }
+    static uint64_t max_temp_storage(uint32_t p, uint32_t t, uint32_t n) { return min_temp_storage( p, t, n ); }
+    void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0)
+    {
+        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
+        check( nvbio_banded_gotoh_traceback( device, BAND_LEN, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(),
+                                             stream.scores(), stream.sources(), stream.sinks(), stream.cigars(), stream.cigar_stride(),
+                                             stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
+                                             temp, temp_size, s ) );
     }
 };
 
