@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
     args = ap.parse_args()
 
@@ -141,10 +143,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     n = int(args.ref_len)
@@ -169,15 +172,20 @@ def main():
     scheme_t = tuple(int(getattr(sv, f)) for f, _ in sv._fields_)
     min_score = params.min_score_for(M)
 
+    # the only exchange of the path: every rank's per-read best (score, position, strand), 8 bytes per read, to
+    # rank 0 over RCCL -- enqueued asynchronously after the batch's kernels so that it overlaps the next batch
+    gatherer = sharding.ResultGatherer(dist, world, rank, R, device, dst=0) if dist is not None else None
+
     def step(timers=None):
         bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers)
-        if dist is not None:
-            # the only exchange of the path: per-read best (score, position*2+strand) to rank 0 over RCCL
-            sharding.gather_results(dist, sharding.pack_result(bs, bp, brc), world, rank, dst=0)
+        if gatherer is not None:
+            gatherer.submit(sharding.pack_result64(bs, bp, brc))
         return bs, bp, brc, nc
 
     for _ in range(args.warmup):
         step()
+    if gatherer is not None:
+        gatherer.wait()
     timers = {}
     if dist is not None:
         dist.barrier()
@@ -185,6 +193,8 @@ def main():
     w0 = time.perf_counter()
     for _ in range(args.steps):
         bs, bp, brc, nc = step(timers)
+    if gatherer is not None:
+        gatherer.wait()                                               # every batch's results have landed on rank 0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -27,11 +27,21 @@ b, e = sharding.shard_bounds(len(d["reads"]), world, rank)
 bs, bp, brc, nc = cpu_pipeline.seed_and_extend_cpu(O, hidx, d["text"], int(d["n"]), d["reads"][b:e])
 packed = sharding.pack_result(torch.from_numpy(bs), torch.from_numpy(bp), torch.from_numpy(brc))
 allr = sharding.gather_results(dist, packed, world, rank, dst=0)
+# the 8-byte packing and the asynchronous double-buffered gatherer bench.py uses: equal shards, three batches
+p64 = sharding.pack_result64(torch.from_numpy(bs), torch.from_numpy(bp), torch.from_numpy(brc))
+rows = 700
+g = sharding.ResultGatherer(dist, world, rank, rows, "cpu")
+for k in range(3):
+    g.submit(p64[:rows] + 0 * k if k != 1 else torch.flip(p64[:rows], dims=[0]))
+g.wait()
 if rank == 0:
     s, p, r = sharding.unpack_result(allr)
-    np.savez(%(out)r, s=s.numpy(), p=p.numpy(), r=r.numpy())
+    last = torch.cat(g.result(0)); prev = torch.cat(g.result(1))
+    s64, p64u, r64 = sharding.unpack_result64(last)
+    np.savez(%(out)r, s=s.numpy(), p=p.numpy(), r=r.numpy(), s64=s64.numpy(), p64=p64u.numpy(), r64=r64.numpy(),
+             prev=prev.numpy(), last=last.numpy())
 else:
-    assert allr is None
+    assert allr is None and g.result() is None
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -76,3 +86,9 @@ def test_two_rank_gloo_equals_single_process(orc):
         assert np.array_equal(got["s"], want[0].astype(np.int64))
         assert np.array_equal(got["p"], want[1])
         assert np.array_equal(got["r"], want[2].astype(np.int64))
+        # asynchronous gatherer: batch 3 = the first 700 reads of each shard, batch 2 = the same reversed
+        b1 = (R + 1) // 2
+        idx = np.concatenate([np.arange(700), b1 + np.arange(700)])
+        assert np.array_equal(got["s64"], want[0][idx].astype(np.int64))
+        assert np.array_equal(got["p64"], want[1][idx]) and np.array_equal(got["r64"], want[2][idx].astype(np.int64))
+        assert np.array_equal(got["prev"].reshape(2, 700)[:, ::-1].reshape(-1), got["last"])
