@@ -288,7 +288,7 @@ def main():
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
-        "roofline": {"kernel": "fm_match_kernel<4,false> (seed pass, one strand of %d seeds per launch)" % n_seeds,
+        "roofline": {"kernel": "fm_match_kernel<4,false,true> (seed pass, one strand of %d seeds per launch)" % n_seeds,
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,

@@ -81,13 +81,15 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
 // ---------------------------------------------------------------------------------------------
 // match
 // ---------------------------------------------------------------------------------------------
-template <int BITS, bool COUNT>
+// TABLE: start from the k-mer table.  A template parameter (not just a flag) so that launches through the
+// reference's plain algorithm (NVBIO_FM_NO_KMER_TABLE) are a different kernel in profiler output.
+template <int BITS, bool COUNT, bool TABLE>
 __global__ void __launch_bounds__(256)
 fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, uint2* __restrict__ ranges, uint32_t* __restrict__ blocks)
 {
     const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
     const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
-    const bool tab  = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
+    const bool tab  = TABLE && (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
     const bool verify = (f.isa != nullptr) && (f.sa_log == 0) && !(flags & NVBIO_FM_NO_VERIFY) && !COUNT;
 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x)
@@ -457,9 +459,11 @@ nvbio_status nvbio_fm_match(nvbio_fm_index_t index, const nvbio_string_set* quer
     // against 9.8 ms for an exactly resident grid (8 per CU: tail imbalance) and 8.4 ms for 6 per CU
     const dim3 grid( grid_for( q.n ) ), block( 256 );
     hipStream_t s = (hipStream_t)stream;
+    const bool use_table = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE);
 #define NVB_LAUNCH_MATCH(BITS)                                                                                              \
-    if (blocks_dev) hipLaunchKernelGGL( (fm_match_kernel<BITS,true>),  grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev ); \
-    else            hipLaunchKernelGGL( (fm_match_kernel<BITS,false>), grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev )
+    if (blocks_dev)    hipLaunchKernelGGL( (fm_match_kernel<BITS,true,false>),  grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev ); \
+    else if (use_table) hipLaunchKernelGGL( (fm_match_kernel<BITS,false,true>),  grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev ); \
+    else                hipLaunchKernelGGL( (fm_match_kernel<BITS,false,false>), grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, blocks_dev )
     switch (queries->symbol_bits)
     {
     case 2: NVB_LAUNCH_MATCH(2); break;
