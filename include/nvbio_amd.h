@@ -191,6 +191,25 @@ nvbio_status nvbio_fm_basic_inv_psi(nvbio_fm_index_t index, const uint32_t* rows
  * rows_dev == pos_dev is allowed (nvBowtie locates in place, locate_inl.h:113-138). */
 nvbio_status nvbio_fm_locate(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
                              uint32_t* pos_dev, void* stream);
+/* match() + locate() fused for the searches that end in a single text occurrence (the common case of a seed
+ * pass: a 22-mer of a 3 Gbp genome).  As nvbio_fm_match, except that a search whose SA range has collapsed to
+ * ONE row before the pattern is exhausted is finished on the text to the left of SA[row] instead of by one
+ * rank step per remaining symbol: 2 dependent gathers instead of (remaining symbols + the later SA lookup).
+ * For such a query  direct_dev[i] = 1  and  ranges_dev[i] = (pos, pos)  where pos is the TEXT POSITION of the
+ * occurrence -- exactly locate(fmi, row) of the one row the reference's match() would end in -- or, if the rest
+ * of the pattern does not match, direct_dev[i] = 0 and the empty range (1,0).  Every other query gets
+ * direct_dev[i] = 0 and its SA range as from nvbio_fm_match.  Range sizes (and so nvbio_fm_filter_scan) are
+ * unaffected; nvbio_fm_filter_locate_direct expands the mix into the same hits, in the same order, as
+ * nvbio_fm_filter_locate does on the plain ranges.  Needs the handle to hold the full suffix array and the text
+ * (nvbio_fm_index_build with sa_int = 1), else NVBIO_ERR_UNSUPPORTED. */
+nvbio_status nvbio_fm_match_direct(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                                   nvbio_uint2* ranges_dev, uint8_t* direct_dev, void* stream);
+/* *yes = 1 iff the handle can serve nvbio_fm_match_direct (it holds the full suffix array and the text) */
+nvbio_status nvbio_fm_index_supports_direct(nvbio_fm_index_t index, int* yes);
+nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                           const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                           nvbio_uint2* hits_dev, void* stream);
+
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)
  * pos_dev[i] = lookup_ssa_iterator(jt[i]) = ssa[j/sa_int] + t      (fmindex_inl.h:445-460)

@@ -267,6 +267,22 @@ class FMIndex:
                                     _stream_ptr(self.device)))
         return (ranges, blocks) if want_blocks else ranges
 
+    def supports_direct(self):
+        yes = ctypes.c_int(0)
+        _check(lib().nvbio_fm_index_supports_direct(self._h, ctypes.byref(yes)))
+        return bool(yes.value)
+
+    def match_direct(self, queries, flags=0):
+        """(ranges, direct): as match(), but searches that collapse to one SA row finish on the text and report
+        the occurrence's text position, flagged in direct (nvbio_fm_match_direct; needs an index built with sa_int=1)"""
+        torch = _torch()
+        ranges = torch.empty((queries.n, 2), dtype=torch.int32, device=self.device)
+        direct = torch.empty(queries.n, dtype=torch.uint8, device=self.device)
+        qs = queries.c_struct()
+        _check(lib().nvbio_fm_match_direct(self._h, ctypes.byref(qs), ctypes.c_uint32(flags), _ptr(ranges), _ptr(direct),
+                                           _stream_ptr(self.device)))
+        return ranges, direct
+
     def rank(self, rows, syms):
         torch = _torch()
         rows = _dev_tensor(rows, torch.int32, self.device)
@@ -321,14 +337,14 @@ class FMIndexFilter:
 
     def __init__(self):
         self._index = None
-        self._ranges = self._slots = None
+        self._ranges = self._slots = self._direct = None
         self._n_hits = 0
         self._n_queries = 0
 
     def rank(self, index, string_set, flags=0):
         """enact the filter; returns the total number of hits (filter_inl.h:261-293)"""
         torch = _torch()
-        self._index, self._n_queries = index, string_set.n
+        self._index, self._n_queries, self._direct = index, string_set.n, None
         self._ranges = torch.empty((string_set.n, 2), dtype=torch.int32, device=index.device)
         self._slots = torch.empty(string_set.n, dtype=torch.int64, device=index.device)
         total = ctypes.c_uint64(0)
@@ -338,10 +354,11 @@ class FMIndexFilter:
         self._n_hits = total.value
         return self._n_hits
 
-    def rank_ranges(self, index, ranges):
-        """the scan half of rank() over ranges already computed by FMIndex.match (nvbio_fm_filter_scan)"""
+    def rank_ranges(self, index, ranges, direct=None):
+        """the scan half of rank() over ranges already computed by FMIndex.match (nvbio_fm_filter_scan), or by
+        FMIndex.match_direct (then pass its `direct` flags: locate() copies the positions those ranges hold)"""
         torch = _torch()
-        self._index, self._n_queries, self._ranges = index, ranges.shape[0], ranges
+        self._index, self._n_queries, self._ranges, self._direct = index, ranges.shape[0], ranges, direct
         self._slots = torch.empty(ranges.shape[0], dtype=torch.int64, device=index.device)
         total = ctypes.c_uint64(0)
         _check(lib().nvbio_fm_filter_scan(index._h, _ptr(ranges), ctypes.c_uint32(ranges.shape[0]), _ptr(self._slots),
@@ -354,6 +371,11 @@ class FMIndexFilter:
         torch = _torch()
         if hits is None:
             hits = torch.empty((end - begin, 2), dtype=torch.int32, device=self._index.device)
+        if self._direct is not None:
+            _check(lib().nvbio_fm_filter_locate_direct(self._index._h, _ptr(self._ranges), _ptr(self._slots), _ptr(self._direct),
+                                                       ctypes.c_uint32(self._n_queries), ctypes.c_uint64(begin),
+                                                       ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))
+            return hits
         _check(lib().nvbio_fm_filter_locate(self._index._h, _ptr(self._ranges), _ptr(self._slots),
                                             ctypes.c_uint32(self._n_queries), ctypes.c_uint64(begin),
                                             ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))

@@ -473,14 +473,18 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     hipLaunchKernelGGL( bwt_words_kernel, dim3( grid_for( words ) ), dim3(256), 0, s, t, (const uint32_t*)sa, (const uint32_t*)d_primary, words, bwt_occ, (uint4*)nullptr );
     hipLaunchKernelGGL( ssa_kernel, dim3( grid_for( n_ssa ) ), dim3(256), 0, s, (const uint32_t*)sa, sa_int, n_ssa, ssa );
     uint32_t* isa = nullptr; uint32_t* text_copy = nullptr;
+    if (sa_int == 1)                                             // the full SA + the text: nvbio_fm_match_direct can finish on the text
+    {
+        NVB_ALLOC( txt_, uint32_t, (size_t)t.n_words + 4u );
+        NVB_HIP( hipMemsetAsync( txt_ + t.n_words, 0, 4u * sizeof(uint32_t), s ) );
+        NVB_HIP( hipMemcpyAsync( txt_, text2_dev, (size_t)t.n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s ) );
+        text_copy = txt_;
+    }
     if (verify)
     {
         NVB_ALLOC( isa_, uint32_t, (size_t)n + 1u );
-        NVB_ALLOC( txt_, uint32_t, (size_t)t.n_words + 4u );
         hipLaunchKernelGGL( isa_kernel, dim3( grid_for( (uint64_t)n + 1u ) ), dim3(256), 0, s, (const uint32_t*)sa, (uint64_t)n, isa_ );
-        NVB_HIP( hipMemsetAsync( txt_ + t.n_words, 0, 4u * sizeof(uint32_t), s ) );
-        NVB_HIP( hipMemcpyAsync( txt_, text2_dev, (size_t)t.n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s ) );
-        isa = isa_; text_copy = txt_;
+        isa = isa_;
     }
     NVB_HIP( hipGetLastError() );
     NVB_HIP( hipStreamSynchronize( s ) );
@@ -517,7 +521,8 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
         return NVBIO_ERR_HIP;
     }
     scratch.forget( bwt_occ ); scratch.forget( ssa );           // ownership moves to the handle
-    if (isa) { scratch.forget( isa ); scratch.forget( text_copy ); }
+    if (isa) scratch.forget( isa );
+    if (text_copy) scratch.forget( text_copy );
     return fm_index_adopt( &view, device, kmer_len, true, s, out, isa, text_copy );
 }
 

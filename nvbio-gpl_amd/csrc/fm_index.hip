@@ -83,9 +83,16 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
 // ---------------------------------------------------------------------------------------------
 // TABLE: start from the k-mer table.  A template parameter (not just a flag) so that launches through the
 // reference's plain algorithm (NVBIO_FM_NO_KMER_TABLE) are a different kernel in profiler output.
-template <int BITS, bool COUNT, bool TABLE>
+// DIRECT (nvbio_fm_match_direct): a search whose range has collapsed to ONE row before the pattern is
+// exhausted is finished on the text: the only place the match can continue is to the left of SA[row], so the
+// rest of the pattern is compared with the text there (2 dependent gathers -- SA, text -- instead of one per
+// remaining symbol plus the SA lookup of a later locate).  Such a query reports its single hit as the TEXT
+// POSITION (ranges[i] = (pos, pos), direct[i] = 1) -- the position locate() would return for the final row;
+// a mismatch reports the empty range (1,0).  Needs the full SA and the text (handles built with sa_int = 1).
+template <int BITS, bool COUNT, bool TABLE, bool DIRECT = false>
 __global__ void __launch_bounds__(256)
-fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, uint2* __restrict__ ranges, uint32_t* __restrict__ blocks)
+fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, uint2* __restrict__ ranges, uint32_t* __restrict__ blocks,
+                uint8_t* __restrict__ direct = nullptr)
 {
     const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
     const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
@@ -118,8 +125,28 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
             if (ok) { const uint2 r = f.ktab[key]; x = r.x; y = r.y; s = f.kmer; }
         }
 
+        bool is_pos = false;
         for (; s < len && x <= y; ++s)
         {
+            if (DIRECT && x == y)
+            {
+                const uint32_t sv = f.ssa[x];
+                const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
+                const uint32_t r  = len - s;
+                bool ok = (p >= r);
+                if (ok)
+                {
+                    SymbolReader<2> tr( f.text );
+                    for (uint32_t t = 0; t < r && ok; ++t)
+                    {
+                        const uint32_t c = sym( s + t );
+                        ok = (c < 4u) && (c == tr.get( p - 1u - t ));
+                    }
+                }
+                if (ok) { x = y = p - r; is_pos = true; }
+                else    { x = 1u; y = 0u; }
+                break;
+            }
             if (verify && x == y && len - s >= 2u)
             {
                 // The range is ONE row: the match can only continue along the text to the left of
@@ -151,6 +178,7 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
         }
         ranges[i] = make_uint2( x, y );
         if (COUNT) blocks[i] = nblk;
+        if (DIRECT) direct[i] = is_pos ? 1u : 0u;
     }
 }
 
@@ -274,7 +302,7 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t* __restrict__
 
 __global__ void __launch_bounds__(256)
 fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint64_t* __restrict__ slots, const uint32_t n_queries,
-                        const uint64_t begin, const uint64_t end, uint2* __restrict__ hits)
+                        const uint64_t begin, const uint64_t end, uint2* __restrict__ hits, const uint8_t* __restrict__ direct)
 {
     __shared__ uint32_t s_q[2];
     const uint32_t mask    = (1u << f.sa_log) - 1u;
@@ -292,19 +320,21 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
         uint64_t h    = t_first + threadIdx.x;
         bool     have = h < t_end;
         uint32_t slot = 0, j = 0, t = 0;
+        bool     is_pos = false;                                 // the range of this query already holds a text position
         auto start = [&]() {
             slot = upper_bound_u64( slots, q_lo, q_hi, h );
             const uint64_t base = slot ? slots[slot - 1u] : 0ull;
             j = ranges[slot].x + (uint32_t)(h - base); t = 0;
+            is_pos = direct && direct[slot];
         };
         if (have) start();
         while (__any( have ))
         {
             if (have)
             {
-                if ((j & mask) == 0)
+                if (is_pos || (j & mask) == 0)
                 {
-                    hits[h - begin] = make_uint2( f.ssa[j >> f.sa_log] + t, slot );
+                    hits[h - begin] = make_uint2( is_pos ? j : f.ssa[j >> f.sa_log] + t, slot );
                     h += 256u; have = h < t_end;
                     if (have) start();
                 }
@@ -594,7 +624,63 @@ nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* r
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
-                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev );
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, (const uint8_t*)nullptr );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_index_supports_direct(nvbio_fm_index_t index, int* yes)
+{
+    NVB_REQUIRE( index && yes, "index/yes is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    *yes = (idx->text && idx->view.ssa_dev && idx->view.sa_int == 1) ? 1 : 0;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_match_direct(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t flags,
+                                   nvbio_uint2* ranges_dev, uint8_t* direct_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    StringSetDev q; NVB_CHECK( make_set( queries, &q ) );
+    if (q.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && direct_dev, "NULL device pointer" );
+    if (!(idx->text && idx->view.ssa_dev && idx->view.sa_int == 1))
+    {
+        set_error( "nvbio_fm_match_direct needs the full suffix array and the text: build the index with sa_int = 1" );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    const DevIndex f = idx->dev();
+    const dim3 grid( grid_for( q.n ) ), block( 256 );
+    hipStream_t s = (hipStream_t)stream;
+    const bool use_table = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE);
+#define NVB_LAUNCH_DIRECT(BITS)                                                                                              \
+    if (use_table) hipLaunchKernelGGL( (fm_match_kernel<BITS,false,true,true>),  grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, (uint32_t*)nullptr, direct_dev ); \
+    else           hipLaunchKernelGGL( (fm_match_kernel<BITS,false,false,true>), grid, block, 0, s, f, q, flags, (uint2*)ranges_dev, (uint32_t*)nullptr, direct_dev )
+    switch (queries->symbol_bits)
+    {
+    case 2: NVB_LAUNCH_DIRECT(2); break;
+    case 4: NVB_LAUNCH_DIRECT(4); break;
+    default: NVB_LAUNCH_DIRECT(8); break;
+    }
+#undef NVB_LAUNCH_DIRECT
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                           const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                           nvbio_uint2* hits_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (end <= begin) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && slots_dev && hits_dev && direct_dev, "NULL device pointer" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, direct_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

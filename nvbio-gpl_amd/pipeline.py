@@ -30,6 +30,7 @@ class SeedExtendParams:
         self.scheme = scheme or GotohScheme(2, 2, 6, -8, -3, -8, -3)
         self.min_score = min_score                  # None -> nvBowtie local(): int(0 + 10*ln(len)) (scoring.h:117-129)
         self.max_seed_hits = max_seed_hits          # None: every SA row of every seed range is extended (fmmap)
+        self.direct = True                          # use match_direct when the index holds the full SA and the text
 
     @classmethod
     def end_to_end(cls, constant_quality=True, **kw):
@@ -123,6 +124,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         tock(e)
         return rid.to(torch.int64), sel, (wb if return_windows else None)
 
+    use_direct = params.direct and fmi.supports_direct()
     results, n_cand = [], 0
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
@@ -130,10 +132,14 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         #    match kernel can be timed on its own)
         flt = FMIndexFilter()
         e = tick("match_fw" if strand == 0 else "match_rc")
-        ranges = fmi.match(qs, flags)
+        if use_direct:
+            # seeds whose range collapses to one row finish on the text and come back as positions
+            ranges, direct = fmi.match_direct(qs, flags)
+        else:
+            ranges, direct = fmi.match(qs, flags), None
         tock(e)
         e = tick("scan")
-        n_hits = flt.rank_ranges(fmi, ranges)
+        n_hits = flt.rank_ranges(fmi, ranges, direct)
         tock(e)
         if n_hits == 0:
             continue

@@ -159,6 +159,69 @@ def test_sa_isa_verification_shortcut_is_exact(amd, orc, k):
         amd.FMIndex.build(orc.pack2(text), n, sa_int=16, verify=True)
 
 
+@pytest.mark.parametrize("k", [0, 6, 9])
+def test_match_direct_gives_the_same_hits(amd, orc, k):
+    """nvbio_fm_match_direct: searches that collapse to one SA row finish on the text and report the position.
+    Checked against the reference algorithm: range sizes, and the hits of the filter expansion (value and
+    order), for hits, misses at every position, N's, patterns running off either end of the text, both scan
+    directions, complement; every direct position equals locate() of the reference's final row."""
+    from util import make_queries
+    rng = np.random.default_rng(77 + k)
+    n = 150001
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[5000:5600] = np.tile(np.array([1, 1, 2, 0, 3], dtype=np.uint8), 120)
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1)
+    assert fmi.supports_direct()
+    Q = 30000
+    syms, offs = make_queries(rng, text, Q, 2, 40, hit_every=1)
+    for q in range(0, Q, 3):
+        pos = int(rng.integers(offs[q], offs[q + 1]))
+        syms[pos] = (syms[pos] + 1 + rng.integers(0, 3)) % 4
+    syms[rng.integers(0, len(syms), 300)] = 4
+    for q in range(1, 400, 4):
+        L = offs[q + 1] - offs[q]
+        if L > 6:
+            m = int(rng.integers(3, L - 2))
+            syms[offs[q + 1] - m:offs[q + 1]] = text[:m]
+    for q in range(2, 400, 4):
+        L = offs[q + 1] - offs[q]
+        if L > 6:
+            m = int(rng.integers(3, L - 2))
+            syms[offs[q]:offs[q] + m] = text[n - m:]
+    comp = np.where(syms < 4, 3 - syms, syms).astype(np.uint8)
+    n_direct = 0
+    for flags, src, rev in ((0, syms, False), (amd.FM_SCAN_FORWARD, syms, True), (amd.FM_COMPLEMENT, comp, False),
+                            (amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT, comp, True)):
+        qs = amd.PackedStringSet(orc.pack4(syms), 4, Q, offsets=offs, ranges=True)
+        want = orc.match_batch(hidx, src, offs, reverse=rev).astype(np.int64)
+        ranges, direct = fmi.match_direct(qs, flags)
+        got, d = amd.u32(ranges).astype(np.int64), direct.cpu().numpy().astype(bool)
+        wsize = np.where(want[:, 1] >= want[:, 0], want[:, 1] + 1 - want[:, 0], 0)
+        gsize = np.where(got[:, 1] >= got[:, 0], got[:, 1] + 1 - got[:, 0], 0)
+        assert np.array_equal(wsize, gsize)
+        assert np.array_equal(got[~d & (wsize > 0)], want[~d & (wsize > 0)])        # untouched queries keep their SA range
+        assert (wsize[d] == 1).all()
+        assert np.array_equal(got[d, 0], hidx.sa[want[d, 0]].astype(np.int64))      # position == SA[final row]
+        n_direct += int(d.sum())
+        # the filter expansion gives the same hits in the same order as the plain path
+        flt = amd.FMIndexFilter()
+        total = flt.rank_ranges(fmi, ranges, direct)
+        plain = amd.FMIndexFilter()
+        assert plain.rank_ranges(fmi, fmi.match(qs, flags)) == total == int(wsize.sum())
+        assert np.array_equal(amd.u32(flt.locate(0, total)), amd.u32(plain.locate(0, total)))
+        b, e = total // 3, total // 3 + 1001
+        assert np.array_equal(amd.u32(flt.locate(b, e)), amd.u32(plain.locate(0, total))[b:e])
+    assert n_direct > 5000                                                           # the direct route was really taken
+    fmi.close()
+    # an adopted index (no text) cannot serve it
+    adopted = amd.FMIndex.from_arrays(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa)
+    assert not adopted.supports_direct()
+    with pytest.raises(amd.NvbioError):
+        adopted.match_direct(amd.PackedStringSet(orc.pack4(syms), 4, Q, offsets=offs, ranges=True))
+    adopted.close()
+
+
 def test_reference_index_files_roundtrip(amd, orc, tmp_path):
     """.bwt / .sa in the reference's on-disk format (fmindex_impl.cu:111-252; writers nvBWT.cu:303-342):
     files written independently from the oracle's index load into the oracle's arrays, and an index
