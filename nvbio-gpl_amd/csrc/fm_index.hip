@@ -128,25 +128,9 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
         bool is_pos = false;
         for (; s < len && x <= y; ++s)
         {
-            if (DIRECT && x == y)
-            {
-                const uint32_t sv = f.ssa[x];
-                const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
-                const uint32_t r  = len - s;
-                bool ok = (p >= r);
-                if (ok)
-                {
-                    SymbolReader<2> tr( f.text );
-                    for (uint32_t t = 0; t < r && ok; ++t)
-                    {
-                        const uint32_t c = sym( s + t );
-                        ok = (c < 4u) && (c == tr.get( p - 1u - t ));
-                    }
-                }
-                if (ok) { x = y = p - r; is_pos = true; }
-                else    { x = 1u; y = 0u; }
-                break;
-            }
+            // DIRECT: a lane whose range has collapsed leaves the loop and waits for its neighbours, so that the
+            // whole wave runs the two gathers of the tail below once, together, instead of once per collapse time
+            if (DIRECT && x == y) break;
             if (verify && x == y && len - s >= 2u)
             {
                 // The range is ONE row: the match can only continue along the text to the left of
@@ -175,6 +159,24 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
             const uint32_t c = sym( s );
             if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
             search_step<COUNT>( f, x, y, c, nblk );
+        }
+        if (DIRECT && s < len && x == y)
+        {
+            const uint32_t sv = f.ssa[x];
+            const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
+            const uint32_t r  = len - s;
+            bool ok = (p >= r);
+            if (ok)
+            {
+                SymbolReader<2> tr( f.text );
+                for (uint32_t t = 0; t < r && ok; ++t)
+                {
+                    const uint32_t c = sym( s + t );
+                    ok = (c < 4u) && (c == tr.get( p - 1u - t ));
+                }
+            }
+            if (ok) { x = y = p - r; is_pos = true; }
+            else    { x = 1u; y = 0u; }
         }
         ranges[i] = make_uint2( x, y );
         if (COUNT) blocks[i] = nblk;
