@@ -55,6 +55,25 @@ def main():
             print(json.dumps({"config": "1 sw-benchmark 100k x 100 x 4096", "type": name,
                               "blocking": "text" if tb else "pattern", "ms": ms,
                               "gcups": R * M * N / (ms * 1e-3) / 1e9}), flush=True)
+    # ---- config 5 shape: opposite-mate full DP, 150 bp mates in 400-symbol windows of a synthetic genome ----
+    P5, M5, W5, n5 = 2_000_000, 150, 400, 400_000_000
+    genome5 = bench.make_reference(n5, dev, seed=5)
+    reads5, pos5, rc5 = bench.make_reads(genome5, n5, P5, M5, dev, seed=6)
+    reads5 = torch.where(rc5[:, None], 3 - reads5.flip(1), reads5)
+    r45 = bench.pack4(reads5.reshape(-1))
+    roffs5 = (torch.arange(P5 + 1, device=dev) * M5).to(torch.int32)
+    g.manual_seed(7)
+    off5 = torch.randint(0, W5 - M5 - 8, (P5,), device=dev, generator=g)
+    wb5 = torch.clamp(pos5 - off5, min=0); we5 = torch.clamp(wb5 + W5, max=n5)
+    b5 = amd.AlignmentBatch(r45, 4, roffs5, genome5, 2, wb5.to(torch.int32), we5.to(torch.int32), max_read_len=M5)
+    for name, typ, sv in (("SEMI_GLOBAL e2e (0,-6,-8,-3)", amd.SEMI_GLOBAL, (0, 6, 6, -8, -3, -8, -3)),
+                          ("LOCAL (2,-6,-8,-3)", amd.LOCAL, (2, 6, 6, -8, -3, -8, -3))):
+        for tb in (True, False):
+            op = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(typ, amd.GotohScheme(*sv)), text_blocking=tb)
+            ms = timed(torch, lambda: op.enact(b5, M5, W5), reps=3)
+            print(json.dumps({"config": "5 opposite-mate full DP 2M x (150 x 400)", "type": name, "blocking": "text" if tb else "pattern",
+                              "ms": ms, "gcups": P5 * M5 * W5 / (ms * 1e-3) / 1e9}), flush=True)
+    del genome5, reads5, r45, b5
     if args.skip_index:
         return
 
