@@ -303,7 +303,10 @@ def main():
                      "without_kmer_table": {"ms_per_launch": no_table_ms,
                                             "achieved": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9,
                                             "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        "extend": {"kernel": "banded_gotoh_band31_pk_kernel<%s,4> (two alignments per lane, int16 packed)" % ("SEMI_GLOBAL" if args.mode == "e2e" else "LOCAL"),
+        "extend": {"kernel": ("ungapped_e2e31_kernel<4> (31 diagonals by XOR + popcount on bit planes; settles every candidate whose best diagonal "
+                              "beats any gapped alignment) + banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4> over the rest (two alignments per lane, "
+                              "int16 packed); gcups = cells of the full band DP / time, i.e. effective") if args.mode == "e2e" else
+                             "banded_gotoh_band31_pk_kernel<LOCAL,4> (two alignments per lane, int16 packed)",
                    "bound": "valu (integer; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},

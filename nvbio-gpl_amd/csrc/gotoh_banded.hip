@@ -18,6 +18,7 @@
 // wins" rule exactly.  Reads and windows are consumed straight from the packed HBM streams
 // (one dword per 8 read symbols / 16 text symbols).
 #include "gotoh_common.h"
+#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
 namespace nvbio_amd {
@@ -199,7 +200,8 @@ __device__ __forceinline__ uint32_t clamp_u32(const int64_t v, const uint32_t lo
 // symbol, the text 2 bits per symbol.
 template <int TYPE, int RBITS>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
-banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                              const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
 {
     constexpr int BAND = 31;
     constexpr uint32_t RMASK = (1u << RBITS) - 1u;
@@ -207,19 +209,23 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
     __syncthreads();
 
+    // with a job list (the jobs the ungapped pass could not settle) lane p works on entries 2p and 2p+1 of the list
+    const uint32_t n_jobs = job_list ? *job_count : b.n;
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (2u * pair >= b.n) return;
+    if (2u * pair >= n_jobs) return;
     const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
     const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
 
-    uint32_t first[2], M[2], tb[2], N[2], rows_all[2];
+    uint32_t first[2], M[2], tb[2], N[2], rows_all[2], out_id[2];
     bool     rev[2], comp[2], valid[2];
     #pragma unroll
     for (int u = 0; u < 2; ++u)
     {
-        const uint32_t job = 2u * pair + u;
-        valid[u] = job < b.n;
-        const uint32_t jj  = valid[u] ? job : 2u * pair;
+        const uint32_t slot = 2u * pair + u;
+        valid[u] = slot < n_jobs;
+        const uint32_t ss  = valid[u] ? slot : 2u * pair;
+        const uint32_t jj  = job_list ? job_list[ss] : ss;
+        out_id[u] = jj;
         const uint32_t rid = b.read_id ? b.read_id[jj] : jj;
         first[u] = b.read_offsets[rid];
         M[u]     = b.read_offsets[rid + 1] - first[u];
@@ -458,7 +464,218 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     }
     #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (valid[u]) { scores[2u * pair + u] = best[u]; sinks[2u * pair + u] = make_uint2( best_x[u], best_y[u] ); }
+        if (valid[u]) { scores[out_id[u]] = best[u]; sinks[out_id[u]] = make_uint2( best_x[u], best_y[u] ); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ungapped shortcut for end-to-end (SEMI_GLOBAL) scoring with match = 0 (nvBowtie's default mode).
+// Every alignment with at least one gap scores at most G = max(pattern gap open, text gap open) < 0: nothing
+// else in it can be positive.  The ungapped alignments are the 31 diagonals of the band, diagonal d scoring
+// U_d = -P * (number of rows i with read[i] != text[i+d]) for a constant mismatch penalty P.  Hence, if
+// U* = max over the reportable end columns d of U_d is > G, the DP's optimum is U*, the last row holds U* in
+// exactly the columns with U_d = U*, and BestSink's "last maximum wins" picks the largest such d -- all known
+// from 31 shifted XOR + popcounts over bit planes, about an eighth of the DP's instructions.  Jobs with
+// U* <= G (two or more mismatches at -6/-8, or an indel) are flagged and go through the DP unchanged.
+// Reportable end columns: d = 0 always, d >= 1 iff d < min(M+30, N) - (M-1) (gotoh_banded_inl.h:631-643); such
+// diagonals lie inside the text, so the band-31 cache quirk for symbols past the text end never touches them.
+// ---------------------------------------------------------------------------------------------
+template <int RBITS>
+__global__ void __launch_bounds__(256)
+ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                      uint8_t* __restrict__ need_dp)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+
+    if (N < M)                                                   // nothing reported (gotoh_banded_inl.h:422-423)
+    {
+        scores[job] = NVBIO_SCORE_MIN; sinks[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); need_dp[job] = 0;
+        return;
+    }
+    if (M == 0u || M > 161u) { need_dp[job] = 1; return; }      // planes below hold 192 text symbols
+
+    // bit planes: bit i of r* = row i of the pattern (low bit, high bit, "is N"); bit k of t* = text symbol k.
+    // Built a packed word at a time: bit-reverse the big-endian word so that symbol 0 sits lowest, squeeze every
+    // BITS-th bit together (3-4 shift/mask steps), drop the 8 / 16 plane bits at their storage offset, then
+    // shift the 192-bit planes so that bit 0 is row 0 (reversed reads: mirror first).
+    uint64_t rlo[3] = { 0, 0, 0 }, rhi[3] = { 0, 0, 0 }, rn[3] = { 0, 0, 0 }, tlo[4] = { 0, 0, 0, 0 }, thi[4] = { 0, 0, 0, 0 };
+    {
+        constexpr uint32_t RPW = 32u / RBITS;                                   // read symbols per word
+        const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
+        const uint32_t rbase = first & ~(RPW - 1u), roff = first - rbase;
+        const uint32_t rw0 = rbase / RPW, rw_last = (first + M - 1u) / RPW;
+        constexpr int RW = (161 + 15) * RBITS / 32 + 2;                         // words that can hold 161 symbols at any offset
+        // every word is loaded unconditionally (index clamped into the read, so always valid): no branches between the
+        // loads, they all issue back to back; plane bits outside the pattern are masked off below
+        uint32_t rw[RW];
+        #pragma unroll
+        for (int j = 0; j < RW; ++j) { const uint32_t widx = rw0 + (uint32_t)j; rw[j] = rwords[widx < rw_last ? widx : rw_last]; }
+        uint32_t tw[13];
+        {
+            const uint32_t* __restrict__ twords_ = (const uint32_t*)b.text;
+            const uint32_t T_ = N < 192u ? N : 192u;
+            const uint32_t tw0_ = (tb & ~15u) >> 4, tw_last_ = (tb + T_ - 1u) >> 4;
+            #pragma unroll
+            for (int j = 0; j < 13; ++j) { const uint32_t widx = tw0_ + (uint32_t)j; tw[j] = twords_[widx < tw_last_ ? widx : tw_last_]; }
+        }
+        #pragma unroll
+        for (int j = 0; j < RW; ++j)
+        {
+            {
+                const uint32_t w = __brev( rw[j] );
+                uint32_t lo, hi, nn;
+                if (RBITS == 4)
+                {
+                    // after the reversal symbol k holds value bits (b3,b2,b1,b0) at bit positions (4k, 4k+1, 4k+2, 4k+3)
+                    lo = (w >> 3) & 0x11111111u; hi = (w >> 2) & 0x11111111u; nn = ((w >> 1) | w) & 0x11111111u;
+                    lo = (lo | (lo >> 3)) & 0x03030303u; lo = (lo | (lo >> 6)) & 0x000F000Fu; lo = (lo | (lo >> 12)) & 0xFFu;
+                    hi = (hi | (hi >> 3)) & 0x03030303u; hi = (hi | (hi >> 6)) & 0x000F000Fu; hi = (hi | (hi >> 12)) & 0xFFu;
+                    nn = (nn | (nn >> 3)) & 0x03030303u; nn = (nn | (nn >> 6)) & 0x000F000Fu; nn = (nn | (nn >> 12)) & 0xFFu;
+                }
+                else
+                {
+                    lo = (w >> 1) & 0x55555555u; hi = w & 0x55555555u; nn = 0;
+                    lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
+                    hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+                }
+                constexpr int PB = (int)RPW;                                    // plane bits per word
+                const int bitpos = j * PB;                                      // compile-time: no dynamic plane index
+                if (bitpos < 192)
+                {
+                    rlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
+                    rhi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
+                    rn [bitpos >> 6] |= (uint64_t)nn << (bitpos & 63);
+                }
+            }
+        }
+        // bit p of the planes = storage symbol rbase + p.  Forward: row i = p - roff.  Reversed: row i = roff + M-1 - p.
+        auto shr192 = [](uint64_t (&v)[3], const uint32_t sh) {
+            const uint32_t ws = sh >> 6, bs = sh & 63u;
+            uint64_t x[5] = { v[0], v[1], v[2], 0ull, 0ull };
+            uint64_t y[4];
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = ws == 0u ? x[k] : (ws == 1u ? x[k + 1 < 5 ? k + 1 : 4] : (ws == 2u ? (k + 2 < 5 ? x[k + 2] : 0ull) : 0ull));
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = bs ? ((y[k] >> bs) | (y[k + 1] << (64u - bs))) : y[k];
+        };
+        auto mirror192 = [](uint64_t (&v)[3]) {
+            const uint64_t a = __brevll( v[2] ), c = __brevll( v[0] );
+            v[1] = __brevll( v[1] ); v[0] = a; v[2] = c;
+        };
+        if (rev)
+        {
+            mirror192( rlo ); mirror192( rhi ); mirror192( rn );               // bit r now = storage symbol rbase + 191 - r
+            const uint32_t sh = 192u - roff - M;                                // row i = bit i + sh
+            shr192( rlo, sh ); shr192( rhi, sh ); shr192( rn, sh );
+        }
+        else { shr192( rlo, roff ); shr192( rhi, roff ); shr192( rn, roff ); }
+        if (comp)                                                               // 3 - q for q < 4: flip both bits of the non-N rows
+        {
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) { rlo[k] ^= ~rn[k]; rhi[k] ^= ~rn[k]; }
+        }
+
+        const uint32_t toff = tb & 15u;
+        #pragma unroll
+        for (int j = 0; j < 13; ++j)
+        {
+            {
+                const uint32_t w = __brev( tw[j] );
+                uint32_t lo = (w >> 1) & 0x55555555u, hi = w & 0x55555555u;
+                lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
+                hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+                const int bitpos = j * 16;
+                tlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
+                thi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
+            }
+        }
+        // 208 plane bits (13 words) shifted down by toff < 16: bit 0 = text symbol 0 of the window
+        if (toff)
+        {
+            #pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+                tlo[k] = (tlo[k] >> toff) | (tlo[k + 1] << (64u - toff));
+                thi[k] = (thi[k] >> toff) | (thi[k + 1] << (64u - toff));
+            }
+            tlo[3] >>= toff; thi[3] >>= toff;
+        }
+    }
+    uint64_t rmask[3];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const int32_t left = (int32_t)M - 64 * k;
+        rmask[k] = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+    }
+
+    const uint32_t mb = M + 30u;
+    const uint32_t m  = (mb < N ? mb : N) - (M - 1u);
+    // the diagonal loop on 32-bit words: the text planes move down one bit per diagonal (one v_alignbit per word),
+    // a mismatch word is 5 logic ops, and v_bcnt accumulates the count
+    uint32_t pl[6], ph[6], pn[6], pm[6], ql[7], qh[7];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        pl[2*k] = (uint32_t)rlo[k]; pl[2*k+1] = (uint32_t)(rlo[k] >> 32);
+        ph[2*k] = (uint32_t)rhi[k]; ph[2*k+1] = (uint32_t)(rhi[k] >> 32);
+        pm[2*k] = (uint32_t)rmask[k]; pm[2*k+1] = (uint32_t)(rmask[k] >> 32);
+        pn[2*k] = (uint32_t)rn[k] & pm[2*k]; pn[2*k+1] = (uint32_t)(rn[k] >> 32) & pm[2*k+1];
+    }
+    #pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        ql[2*k] = (uint32_t)tlo[k]; ql[2*k+1] = (uint32_t)(tlo[k] >> 32);
+        qh[2*k] = (uint32_t)thi[k]; qh[2*k+1] = (uint32_t)(thi[k] >> 32);
+    }
+    ql[6] = (uint32_t)tlo[3]; qh[6] = (uint32_t)thi[3];
+
+    uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
+    for (uint32_t d = 0; d < 31u; ++d)
+    {
+        if (!(d == 0u || d < m)) break;                          // reportable columns are a prefix of 0..30
+        uint32_t cnt = 0;
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+            cnt += (uint32_t)__popc( mm );
+        }
+        if (cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+            qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+        }
+        ql[6] >>= 1; qh[6] >>= 1;
+    }
+    const int64_t U = -(int64_t)P * (int64_t)best_cnt;
+    if (U > (int64_t)G)
+    {
+        scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
+    }
+    else need_dp[job] = 1;
+}
+
+// host-side conditions of the shortcut: SEMI_GLOBAL, match = 0, one mismatch penalty for every quality,
+// non-positive gap terms
+static bool ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P)
+{
+    if (sc.match != 0) return false;
+    if (sc.mm_min < 0 || sc.mm_max < 0) return false;
+    if (b.quals != nullptr && sc.mm_min != sc.mm_max) return false;   // the penalty would depend on the row
+    if (sc.pat_go >= 0 || sc.txt_go >= 0 || sc.pat_ge > 0 || sc.txt_ge > 0) return false;
+    *P = sc.mm_min;                                               // quality 0 / constant ramp: mismatch = -mm_min
+    return true;
 }
 
 // the packed kernel is exact iff no intermediate value can leave the int16 range or meet the -16384 stand-in
@@ -480,10 +697,43 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
 }
 
 template <int TYPE, int RB>
-static void launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
+static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
     const uint32_t pairs = (b.n + 1u) / 2u;
-    hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks );
+    int32_t P = 0;
+    if (TYPE == NVBIO_SEMI_GLOBAL && ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" ))
+    {
+        // 1. settle the jobs whose best diagonal beats every gapped alignment; 2. compact the rest; 3. DP over the list
+        const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
+        size_t sel_bytes = 0;
+        hipcub::CountingInputIterator<uint32_t> ids( 0u );
+        NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
+        const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
+        const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+        void* aux = nullptr;
+        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        {
+            set_error( "banded score: out of device memory for the job list" );
+            return NVBIO_ERR_NOMEM;
+        }
+        uint8_t*  need_dp   = (uint8_t*)aux;
+        uint32_t* job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
+        uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
+        void*     sel_temp  = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, scores, sinks, need_dp );
+        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        if (e == hipSuccess)
+            hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                                (const uint32_t*)job_list, (const uint32_t*)job_count );
+        (void)hipFreeAsync( aux, s );
+        if (e != hipSuccess) { set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        NVB_HIP( hipGetLastError() );
+        return NVBIO_OK;
+    }
+    hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                        (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
 }
 
 template <int BAND, int TYPE>
@@ -492,8 +742,8 @@ static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t
 {
     if (BAND == 31 && packed_ok( TYPE, sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
     {
-        if      (rbits == 4 && tbits == 2) { launch_pk<TYPE,4>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
-        else if (rbits == 2 && tbits == 2) { launch_pk<TYPE,2>( b, sc, scores, sinks, s ); NVB_HIP( hipGetLastError() ); return NVBIO_OK; }
+        if      (rbits == 4 && tbits == 2) return launch_pk<TYPE,4>( b, sc, scores, sinks, s );
+        else if (rbits == 2 && tbits == 2) return launch_pk<TYPE,2>( b, sc, scores, sinks, s );
     }
     const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
 #define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks )
