@@ -15,6 +15,8 @@
 // job-interleaved in HBM (element i of job t at [i * jobs + t]) so that the 64 lanes of a wave
 // read and write 256 contiguous bytes per row.
 #include "gotoh_common.h"
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace nvbio_amd {
 
@@ -42,7 +44,8 @@ constexpr int STRIPE = 8;
 template <int TYPE, bool TEXT_BLOCKING, int RBITS, int TBITS>
 __global__ void __launch_bounds__(128)
 full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin, const uint32_t jobs, const int32_t* __restrict__ min_scores,
-                  uint32_t* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+                  uint32_t* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                  const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -50,7 +53,9 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // slot inside this launch
     if (t >= jobs) return;
-    const uint32_t job = job_begin + t;
+    // with a job list (the jobs the ungapped pass could not settle) slot t is entry job_begin + t of the list
+    if (job_list && job_begin + t >= *job_count) return;
+    const uint32_t job = job_list ? job_list[job_begin + t] : job_begin + t;
 
     const uint32_t rid   = b.read_id ? b.read_id[job] : job;
     const uint32_t first = b.read_offsets[rid];
@@ -148,13 +153,18 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 
             if (TYPE == NVBIO_LOCAL)
             {
+                // the row's cells are reported with j ascending and the LAST maximum wins: one packed
+                // (score << 4 | j) max per cell and a single compare per row give the same sink
+                int32_t key = -1;
                 #pragma unroll
                 for (int j = 1; j <= STRIPE; ++j)
-                    if (!last || block + j <= cols)
-                    {
-                        if (TEXT_BLOCKING) sink.report( H[j], block + j, i + 1u );
-                        else               sink.report( H[j], i + 1u, block + j );
-                    }
+                    if (!last || block + j <= cols) key = max2( key, (H[j] << 4) | j );
+                if (key >= 0)
+                {
+                    const uint32_t j = (uint32_t)(key & 15);
+                    if (TEXT_BLOCKING) sink.report( key >> 4, block + j, i + 1u );
+                    else               sink.report( key >> 4, i + 1u, block + j );
+                }
             }
             else if (!TEXT_BLOCKING && last && TYPE == NVBIO_SEMI_GLOBAL)
             {
@@ -203,12 +213,202 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
     sinks[job]  = make_uint2( sink.x, sink.y );
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ungapped shortcut for end-to-end (SEMI_GLOBAL, match = 0) full-matrix scoring: the same argument as
+// ungapped_e2e31_kernel (gotoh_banded.hip) over ALL diagonals of the window.  An alignment with a gap scores
+// at most G = max(gap opens) < 0; the ungapped alignments of the whole pattern are the diagonals d = 0..N-M,
+// U_d = -P * #{i : read[i] != text[i+d]}, ending in text column M+d.  If U* = max_d U_d > G, the optimum is
+// U*, reached in exactly the columns with U_d = U*, and both blockings report end columns in ascending order
+// with "last maximum wins": sink = (M + largest such d, M).  The stripe early exit (gotoh_inl.h:706-710,
+// 1106-1110) must provably stay silent, or the job goes to the DP: with pattern blocking the stripe maximum is
+// over all text positions of a pattern prefix, and every prefix of the optimal alignment scores >= U* (match =
+// 0), so U* >= min_score suffices; with text blocking it is over the pattern rows of one text column, where only
+// the first row is known to score >= -P, so min_score <= -P is required (stripes left of the alignment's start
+// can otherwise trip the test even though the optimum passes it -- the reference does exit there).
+// Anything else (U* <= G, N < M, windows over 496 symbols) is flagged for the DP as well.
+// Planes live in registers: 16 + 16 words of text, 6 x 3 of pattern; the text window slides one bit per
+// diagonal (v_alignbit), 32 diagonals per statically indexed outer step.
+// ---------------------------------------------------------------------------------------------
+template <int RBITS>
+__global__ void __launch_bounds__(256)
+ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t* __restrict__ min_scores, const bool text_blocking,
+                         int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    if (M == 0u || M > 161u || N < M || N > 496u) { need_dp[job] = 1; return; }
+
+    // ---- pattern planes (as in ungapped_e2e31_kernel): bit i = row i ----
+    uint64_t rlo[3] = { 0, 0, 0 }, rhi[3] = { 0, 0, 0 }, rn[3] = { 0, 0, 0 };
+    {
+        constexpr uint32_t RPW = 32u / RBITS;
+        const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
+        const uint32_t rbase = first & ~(RPW - 1u), roff = first - rbase;
+        const uint32_t rw0 = rbase / RPW, rw_last = (first + M - 1u) / RPW;
+        constexpr int RW = (161 + 15) * RBITS / 32 + 2;
+        uint32_t rw[RW];
+        #pragma unroll
+        for (int j = 0; j < RW; ++j) { const uint32_t widx = rw0 + (uint32_t)j; rw[j] = rwords[widx < rw_last ? widx : rw_last]; }
+        #pragma unroll
+        for (int j = 0; j < RW; ++j)
+        {
+            const uint32_t w = __brev( rw[j] );
+            uint32_t lo, hi, nn;
+            if (RBITS == 4)
+            {
+                lo = (w >> 3) & 0x11111111u; hi = (w >> 2) & 0x11111111u; nn = ((w >> 1) | w) & 0x11111111u;
+                lo = (lo | (lo >> 3)) & 0x03030303u; lo = (lo | (lo >> 6)) & 0x000F000Fu; lo = (lo | (lo >> 12)) & 0xFFu;
+                hi = (hi | (hi >> 3)) & 0x03030303u; hi = (hi | (hi >> 6)) & 0x000F000Fu; hi = (hi | (hi >> 12)) & 0xFFu;
+                nn = (nn | (nn >> 3)) & 0x03030303u; nn = (nn | (nn >> 6)) & 0x000F000Fu; nn = (nn | (nn >> 12)) & 0xFFu;
+            }
+            else
+            {
+                lo = (w >> 1) & 0x55555555u; hi = w & 0x55555555u; nn = 0;
+                lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
+                hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+            }
+            const int bitpos = j * (int)RPW;
+            if (bitpos < 192)
+            {
+                rlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
+                rhi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
+                rn [bitpos >> 6] |= (uint64_t)nn << (bitpos & 63);
+            }
+        }
+        auto shr192 = [](uint64_t (&v)[3], const uint32_t sh) {
+            const uint32_t ws = sh >> 6, bs = sh & 63u;
+            uint64_t x[5] = { v[0], v[1], v[2], 0ull, 0ull };
+            uint64_t y[4];
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = ws == 0u ? x[k] : (ws == 1u ? x[k + 1 < 5 ? k + 1 : 4] : (ws == 2u ? (k + 2 < 5 ? x[k + 2] : 0ull) : 0ull));
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = bs ? ((y[k] >> bs) | (y[k + 1] << (64u - bs))) : y[k];
+        };
+        auto mirror192 = [](uint64_t (&v)[3]) {
+            const uint64_t a = __brevll( v[2] ), c = __brevll( v[0] );
+            v[1] = __brevll( v[1] ); v[0] = a; v[2] = c;
+        };
+        if (rev)
+        {
+            mirror192( rlo ); mirror192( rhi ); mirror192( rn );
+            const uint32_t sh = 192u - roff - M;
+            shr192( rlo, sh ); shr192( rhi, sh ); shr192( rn, sh );
+        }
+        else { shr192( rlo, roff ); shr192( rhi, roff ); shr192( rn, roff ); }
+        if (comp)
+        {
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) { rlo[k] ^= ~rn[k]; rhi[k] ^= ~rn[k]; }
+        }
+    }
+    uint32_t pl[6], ph[6], pn[6], pm[6];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const int32_t left = (int32_t)M - 64 * k;
+        const uint64_t mask = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+        pl[2*k] = (uint32_t)rlo[k]; pl[2*k+1] = (uint32_t)(rlo[k] >> 32);
+        ph[2*k] = (uint32_t)rhi[k]; ph[2*k+1] = (uint32_t)(rhi[k] >> 32);
+        pm[2*k] = (uint32_t)mask;   pm[2*k+1] = (uint32_t)(mask >> 32);
+        pn[2*k] = (uint32_t)rn[k] & pm[2*k]; pn[2*k+1] = (uint32_t)(rn[k] >> 32) & pm[2*k+1];
+    }
+
+    // ---- text planes: 512 bits, bit k = window symbol k (32 packed words cover 496 symbols at any offset) ----
+    uint32_t tl[17], th[17];
+    {
+        const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
+        const uint32_t toff = tb & 15u;
+        const uint32_t tw0 = tb >> 4, tw_last = (tb + N - 1u) >> 4;
+        uint32_t lo16[33], hi16[33];
+        #pragma unroll
+        for (int j = 0; j < 32; ++j)
+        {
+            const uint32_t widx = tw0 + (uint32_t)j;
+            const uint32_t w = __brev( twords[widx < tw_last ? widx : tw_last] );
+            uint32_t lo = (w >> 1) & 0x55555555u, hi = w & 0x55555555u;
+            lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
+            hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+            lo16[j] = lo; hi16[j] = hi;
+        }
+        lo16[32] = 0; hi16[32] = 0;
+        uint32_t a[17], c[17];
+        #pragma unroll
+        for (int k = 0; k < 16; ++k) { a[k] = lo16[2*k] | (lo16[2*k+1] << 16); c[k] = hi16[2*k] | (hi16[2*k+1] << 16); }
+        a[16] = 0; c[16] = 0;
+        // drop the toff (< 16) symbols in front of the window
+        #pragma unroll
+        for (int k = 0; k < 16; ++k)
+        {
+            tl[k] = __builtin_amdgcn_alignbit( a[k + 1], a[k], toff );
+            th[k] = __builtin_amdgcn_alignbit( c[k + 1], c[k], toff );
+        }
+        tl[16] = 0; th[16] = 0;
+    }
+
+    const uint32_t last_d = N - M;                               // diagonals 0..N-M end inside the window
+    uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
+    #pragma unroll
+    for (int wo = 0; wo < 16; ++wo)                              // 32 diagonals per step; d <= N - M <= 495
+    {
+        if ((uint32_t)wo * 32u > last_d) break;
+        uint32_t ql[7], qh[7];
+        #pragma unroll
+        for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 17) ? tl[wo + k] : 0u; qh[k] = (wo + k < 17) ? th[wo + k] : 0u; }
+        const uint32_t d_end = ((uint32_t)wo * 32u + 31u < last_d) ? (uint32_t)wo * 32u + 31u : last_d;
+        for (uint32_t d = (uint32_t)wo * 32u; d <= d_end; ++d)
+        {
+            uint32_t cnt = 0;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                cnt += (uint32_t)__popc( mm );
+            }
+            if (cnt <= best_cnt) { best_cnt = cnt; best_d = d; }
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+            }
+            ql[6] >>= 1; qh[6] >>= 1;
+        }
+    }
+    const int64_t U = -(int64_t)P * (int64_t)best_cnt;
+    const int32_t min_score = min_scores ? min_scores[job] : NVBIO_SCORE_MIN;
+    const bool exit_silent = text_blocking ? ((int64_t)min_score <= -(int64_t)P) : (U >= (int64_t)min_score);
+    if (U > (int64_t)G && U >= (int64_t)min_score && exit_silent)
+    {
+        scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
+    }
+    else need_dp[job] = 1;
+}
+
+static bool full_ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P)
+{
+    if (sc.match != 0) return false;
+    if (sc.mm_min < 0 || sc.mm_max < 0) return false;
+    if (b.quals != nullptr && sc.mm_min != sc.mm_max) return false;
+    if (sc.pat_go >= 0 || sc.txt_go >= 0 || sc.pat_ge > 0 || sc.txt_ge > 0) return false;
+    *P = sc.mm_min;
+    return true;
+}
+
 template <int TYPE, bool TB>
 nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
-                         const int32_t* min_scores, uint32_t* column, int32_t* scores, uint2* sinks, hipStream_t s)
+                         const int32_t* min_scores, uint32_t* column, int32_t* scores, uint2* sinks, hipStream_t s,
+                         const uint32_t* job_list, const uint32_t* job_count)
 {
     const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
-#define NVB_GO(RB, TBITS) hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks )
+#define NVB_GO(RB, TBITS) hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks, job_list, job_count )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -223,13 +423,14 @@ nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits,
 
 template <bool TB>
 nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
-                         const int32_t* min_scores, uint32_t* column, int32_t* scores, uint2* sinks, hipStream_t s)
+                         const int32_t* min_scores, uint32_t* column, int32_t* scores, uint2* sinks, hipStream_t s,
+                         const uint32_t* job_list, const uint32_t* job_count)
 {
     switch (type)
     {
-    case NVBIO_GLOBAL:      return launch_bits<NVBIO_GLOBAL,TB>     ( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s );
-    case NVBIO_LOCAL:       return launch_bits<NVBIO_LOCAL,TB>      ( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s );
-    case NVBIO_SEMI_GLOBAL: return launch_bits<NVBIO_SEMI_GLOBAL,TB>( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s );
+    case NVBIO_GLOBAL:      return launch_bits<NVBIO_GLOBAL,TB>     ( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s, job_list, job_count );
+    case NVBIO_LOCAL:       return launch_bits<NVBIO_LOCAL,TB>      ( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s, job_list, job_count );
+    case NVBIO_SEMI_GLOBAL: return launch_bits<NVBIO_SEMI_GLOBAL,TB>( b, sc, rbits, tbits, job_begin, jobs, min_scores, column, scores, sinks, s, job_list, job_count );
     }
     set_error( "invalid alignment type %d", type );
     return NVBIO_ERR_INVALID;
@@ -266,6 +467,36 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
                      scheme->txt_gap_open, scheme->txt_gap_ext };
 
+    // ---- end-to-end shortcut: settle the jobs whose best diagonal beats every gapped alignment, compact the rest ----
+    uint32_t* job_list = nullptr; uint32_t* job_count = nullptr; void* aux = nullptr;
+    {
+        int32_t P = 0;
+        if (type == NVBIO_SEMI_GLOBAL && batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2) &&
+            full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" ))
+        {
+            const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
+            size_t sel_bytes = 0;
+            hipcub::CountingInputIterator<uint32_t> ids( 0u );
+            NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
+            const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
+            const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+            if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+            {
+                set_error( "full Gotoh: out of device memory for the job list" );
+                return NVBIO_ERR_NOMEM;
+            }
+            uint8_t* need_dp = (uint8_t*)aux;
+            job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
+            job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
+            void* sel_temp = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+            const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
+            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
+            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
+            const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+            if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        }
+    }
+
     // boundary columns: caller scratch if given, else stream-ordered scratch; jobs are processed in
     // as many launches as the scratch allows (at least one wave of jobs per launch)
     void*    owned = nullptr;
@@ -274,7 +505,12 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     if (column)
     {
         cap_jobs = temp_bytes / (rows * sizeof(uint32_t));
-        NVB_REQUIRE( cap_jobs >= 64 || cap_jobs >= b.n, "temp_bytes too small (see nvbio_full_gotoh_temp_bytes)" );
+        if (!(cap_jobs >= 64 || cap_jobs >= b.n))
+        {
+            if (aux) (void)hipFreeAsync( aux, s );
+            set_error( "invalid argument: temp_bytes too small (see nvbio_full_gotoh_temp_bytes)" );
+            return NVBIO_ERR_INVALID;
+        }
     }
     else
     {
@@ -284,6 +520,7 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
         if (cap_jobs < 64) cap_jobs = 64;
         if (hipMallocAsync( &owned, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
         {
+            if (aux) (void)hipFreeAsync( aux, s );
             set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
         }
@@ -294,9 +531,10 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     {
         const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
         st = text_blocking ?
-            launch_type<true> ( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s ) :
-            launch_type<false>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s );
+            launch_type<true> ( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s, job_list, job_count ) :
+            launch_type<false>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s, job_list, job_count );
     }
     if (owned) (void)hipFreeAsync( owned, s );
+    if (aux)   (void)hipFreeAsync( aux, s );
     return st;
 }

@@ -92,3 +92,70 @@ def test_opposite_mate_shape(amd, orc):
                     p = 3 - p
                 ok, s, k = orc.full_gotoh(typ, blocking, oracle.Scheme(*sv), p, text[wb[j]:we[j]], q, int(ms[j]))
                 assert got_s[j] == s and tuple(got_k[j]) == k, (blocking, typ, j)
+
+
+@pytest.mark.parametrize("shortcut", [True, False])
+def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypatch):
+    """nvBowtie's end-to-end scheme (match 0) through the full-matrix kernel: jobs whose best diagonal beats every
+    gapped alignment are settled without a DP, the rest go through it over a job list -- scores and sinks of
+    every job equal the reference algorithm's, with and without min_score (stripe early exit), for reads with 0-3
+    mismatches, indels, N's, reversed / complemented mates, windows up to and beyond the shortcut's 496 symbols,
+    windows shorter than the read, both blockings"""
+    if not shortcut:
+        monkeypatch.setenv("NVBIO_AMD_NO_UNGAPPED_SCORE", "1")
+    rng = np.random.default_rng(23)
+    G = 300000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    text[1000:1400] = np.tile(text[1000:1020], 20)                  # a tandem repeat: several diagonals tie
+    R, M = 1400, 150
+    lens = np.full(R, M); lens[::9] = rng.integers(40, 161, len(lens[::9]))
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(0, G - 700, R); starts[:40] = rng.integers(1000, 1200, 40)
+    wlen = rng.integers(150, 497, R); wlen[::11] = rng.integers(497, 640, len(wlen[::11])); wlen[::13] = rng.integers(60, 150, len(wlen[::13]))
+    off = (rng.random(R) * np.maximum(wlen - lens, 1)).astype(np.int64)
+    reads = []
+    for j in range(R):
+        p = starts[j] + off[j]
+        r = text[p:p + lens[j]].copy()
+        k = int(rng.integers(0, 4))
+        if k:
+            pos = rng.integers(0, lens[j], k); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        if j % 7 == 0:
+            c = int(rng.integers(5, lens[j] - 5)); g = int(rng.integers(1, 4))
+            r = np.concatenate([r[:c], r[c + g:], rng.integers(0, 4, g, dtype=np.uint8)]) if j % 2 else \
+                np.concatenate([r[:c], rng.integers(0, 4, g, dtype=np.uint8), r[c:lens[j] - g]])
+        if j % 29 == 0:
+            r[int(rng.integers(0, lens[j]))] = 4
+        reads.append(r.astype(np.uint8))
+    flags = rng.integers(0, 4, R).astype(np.uint8)
+    # store each read so that the flagged view (reverse / complement) is the mutated locus
+    stored = []
+    for j, r in enumerate(reads):
+        v = r.copy()
+        if flags[j] & 2:
+            v = np.where(v < 4, 3 - v, v).astype(np.uint8)
+        if flags[j] & 1:
+            v = v[::-1]
+        stored.append(v)
+    flat = np.concatenate(stored)
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    wb = starts.astype(np.uint32); we = np.minimum(starts + wlen, G).astype(np.uint32)
+    ms = rng.integers(-60, 1, R).astype(np.int32); ms[::5] = oracle.SCORE_MIN
+    sv = (0, 6, 6, -8, -3, -8, -3)
+    settled = 0
+    for use_q in (False, True):
+        for min_scores in (None, ms):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals if use_q else None, flags=flags)
+            for blocking in (1, 0):
+                sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), text_blocking=bool(blocking)).enact(
+                    batch, 161, 640, min_scores=min_scores)
+                got_s, got_k = sc.cpu().numpy(), amd.u32(sk)
+                for j in range(R):
+                    q = quals[roffs[j]:roffs[j + 1]]
+                    if flags[j] & 1:
+                        q = q[::-1]
+                    ok, s_, k_ = orc.full_gotoh(oracle.SEMI_GLOBAL, blocking, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]],
+                                               q if use_q else None, int(min_scores[j]) if min_scores is not None else oracle.SCORE_MIN)
+                    assert got_s[j] == s_ and tuple(got_k[j]) == k_, (use_q, min_scores is not None, blocking, j, lens[j], wlen[j])
+                    settled += int(s_ > -8)
+    assert settled > 2000                                           # plenty of jobs the shortcut can settle
