@@ -216,7 +216,7 @@ def main():
     # ---- traceback of every read's best alignment (not part of the timed step) ----
     tb_ms, tb_info = None, None
     if not args.no_traceback:
-        _, _, _, _, bwb = pipeline.seed_and_extend(fmi, genome, n, batch, params, None, return_windows=True)
+        _, _, _, _, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, None, return_windows=True)
         tms = []
         for _ in range(3):
             tt = {}

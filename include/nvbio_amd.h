@@ -300,6 +300,20 @@ typedef struct
 
 enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };
 
+/* Paired-end: the genome window in which the opposite mate of an anchored mate is aligned (full-matrix DP),
+ * BestOppositeScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate
+ * (alignment_utils.h:52-88).  g_pos = the anchor hit's locus (hit.loc), anchor_rc its strand, anchor = 0 if mate 1 is
+ * the anchor, opposite_gapped_len = opposite mate length + aln::max_text_gaps(aligner, min_score, length)
+ * (nvbio/alignment/utils_inl.h:141-162).  flags_dev = how the opposite mate is read (NVBIO_READ_REVERSE |
+ * NVBIO_READ_COMPLEMENT when it aligns reverse-complemented); valid_dev = 0 where the window is empty or starts
+ * past the genome end (the reference skips such hits). */
+enum { NVBIO_PE_POLICY_FF = 0, NVBIO_PE_POLICY_FR = 1, NVBIO_PE_POLICY_RF = 2, NVBIO_PE_POLICY_RR = 3 };
+nvbio_status nvbio_opposite_mate_windows(int device, const uint32_t* g_pos_dev, const uint8_t* anchor_rc_dev, uint32_t n,
+                                         uint32_t anchor_len, uint32_t opposite_gapped_len, uint32_t anchor, uint32_t policy,
+                                         uint32_t min_frag_len, uint32_t max_frag_len, uint32_t overlap, uint32_t genome_len,
+                                         uint32_t* win_begin_dev, uint32_t* win_end_dev, uint8_t* flags_dev, uint8_t* valid_dev,
+                                         void* stream);
+
 /* scores_dev[i], sinks_dev[i] = BestSink<int32> (score, (text_end, pattern_end)) after
  * aln::banded_alignment_score<band>( GotohAligner<type>, pattern, quals, text, min_score, sink )
  * (nvbio/alignment/gotoh/gotoh_banded_inl.h:397-688; batched form batched_banded_inl.h:34-157).

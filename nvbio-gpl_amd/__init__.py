@@ -551,6 +551,39 @@ def hits_to_diagonals(hits, seeds_per_read, seed_interval, seed_len, read_len, s
     return keys
 
 
+PE_POLICY_FF, PE_POLICY_FR, PE_POLICY_RF, PE_POLICY_RR = 0, 1, 2, 3
+
+
+def max_text_gaps(scheme, min_score, pattern_len):
+    """aln::max_text_gaps for a Gotoh aligner (nvbio/alignment/utils_inl.h:141-162): the largest number of reference
+    gaps an alignment of pattern_len symbols can hold without dropping below min_score"""
+    c = scheme.c
+    score = pattern_len * c.match
+    if score < min_score:
+        return 0
+    score += c.txt_gap_open
+    n = 0
+    while score >= min_score and n < pattern_len:
+        score += c.txt_gap_ext
+        n += 1
+    return (n - 1) & 0xFFFFFFFF
+
+
+def opposite_mate_windows(g_pos, anchor_rc, anchor_len, opposite_gapped_len, anchor, genome_len, policy=PE_POLICY_FR,
+                          min_frag_len=0, max_frag_len=500, overlap=True):
+    """BestOppositeScoreStream::init_context's window (nvBowtie score_inl.h:389-425): (win_begin, win_end, flags, valid)"""
+    torch = _torch()
+    n, dev = g_pos.shape[0], g_pos.device
+    wb = torch.empty(n, dtype=torch.int32, device=dev); we = torch.empty(n, dtype=torch.int32, device=dev)
+    flags = torch.empty(n, dtype=torch.uint8, device=dev); valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    _check(lib().nvbio_opposite_mate_windows(
+        FMIndex._dev_index(dev), _ptr(g_pos), _ptr(anchor_rc), ctypes.c_uint32(n), ctypes.c_uint32(anchor_len),
+        ctypes.c_uint32(opposite_gapped_len), ctypes.c_uint32(anchor), ctypes.c_uint32(policy), ctypes.c_uint32(min_frag_len),
+        ctypes.c_uint32(max_frag_len), ctypes.c_uint32(1 if overlap else 0), ctypes.c_uint32(genome_len), _ptr(wb), _ptr(we),
+        _ptr(flags), _ptr(valid), _stream_ptr(dev)))
+    return wb, we, flags, valid
+
+
 def diagonals_to_windows(keys, band, read_len, genome_len):
     """genome_infixes + nvBowtie's window rule: (read_id, flags, win_begin, win_end) of every candidate key"""
     torch = _torch()

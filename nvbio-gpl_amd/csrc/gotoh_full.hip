@@ -225,8 +225,8 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 // 0), so U* >= min_score suffices; with text blocking it is over the pattern rows of one text column, where only
 // the first row is known to score >= -P, so min_score <= -P is required (stripes left of the alignment's start
 // can otherwise trip the test even though the optimum passes it -- the reference does exit there).
-// Anything else (U* <= G, N < M, windows over 496 symbols) is flagged for the DP as well.
-// Planes live in registers: 16 + 16 words of text, 6 x 3 of pattern; the text window slides one bit per
+// Anything else (U* <= G, N < M, windows over 528 symbols) is flagged for the DP as well.
+// Planes live in registers: 17 + 17 words of text, 6 x 3 of pattern; the text window slides one bit per
 // diagonal (v_alignbit), 32 diagonals per statically indexed outer step.
 // ---------------------------------------------------------------------------------------------
 template <int RBITS>
@@ -244,7 +244,7 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
     const uint32_t tb    = b.win_begin[job];
     const uint32_t N     = b.win_end[job] - tb;
-    if (M == 0u || M > 161u || N < M || N > 496u) { need_dp[job] = 1; return; }
+    if (M == 0u || M > 161u || N < M || N > 528u) { need_dp[job] = 1; return; }
 
     // ---- pattern planes (as in ungapped_e2e31_kernel): bit i = row i ----
     uint64_t rlo[3] = { 0, 0, 0 }, rhi[3] = { 0, 0, 0 }, rn[3] = { 0, 0, 0 };
@@ -321,15 +321,15 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
         pn[2*k] = (uint32_t)rn[k] & pm[2*k]; pn[2*k+1] = (uint32_t)(rn[k] >> 32) & pm[2*k+1];
     }
 
-    // ---- text planes: 512 bits, bit k = window symbol k (32 packed words cover 496 symbols at any offset) ----
-    uint32_t tl[17], th[17];
+    // ---- text planes: 544 bits, bit k = window symbol k (34 packed words cover 528 symbols at any offset) ----
+    uint32_t tl[18], th[18];
     {
         const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
         const uint32_t toff = tb & 15u;
         const uint32_t tw0 = tb >> 4, tw_last = (tb + N - 1u) >> 4;
-        uint32_t lo16[33], hi16[33];
+        uint32_t lo16[35], hi16[35];
         #pragma unroll
-        for (int j = 0; j < 32; ++j)
+        for (int j = 0; j < 34; ++j)
         {
             const uint32_t widx = tw0 + (uint32_t)j;
             const uint32_t w = __brev( twords[widx < tw_last ? widx : tw_last] );
@@ -338,30 +338,30 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
             hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
             lo16[j] = lo; hi16[j] = hi;
         }
-        lo16[32] = 0; hi16[32] = 0;
-        uint32_t a[17], c[17];
+        lo16[34] = 0; hi16[34] = 0;
+        uint32_t a[18], c[18];
         #pragma unroll
-        for (int k = 0; k < 16; ++k) { a[k] = lo16[2*k] | (lo16[2*k+1] << 16); c[k] = hi16[2*k] | (hi16[2*k+1] << 16); }
-        a[16] = 0; c[16] = 0;
+        for (int k = 0; k < 17; ++k) { a[k] = lo16[2*k] | (lo16[2*k+1] << 16); c[k] = hi16[2*k] | (hi16[2*k+1] << 16); }
+        a[17] = 0; c[17] = 0;
         // drop the toff (< 16) symbols in front of the window
         #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < 17; ++k)
         {
             tl[k] = __builtin_amdgcn_alignbit( a[k + 1], a[k], toff );
             th[k] = __builtin_amdgcn_alignbit( c[k + 1], c[k], toff );
         }
-        tl[16] = 0; th[16] = 0;
+        tl[17] = 0; th[17] = 0;
     }
 
     const uint32_t last_d = N - M;                               // diagonals 0..N-M end inside the window
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
     #pragma unroll
-    for (int wo = 0; wo < 16; ++wo)                              // 32 diagonals per step; d <= N - M <= 495
+    for (int wo = 0; wo < 17; ++wo)                              // 32 diagonals per step; d <= N - M <= 527
     {
         if ((uint32_t)wo * 32u > last_d) break;
         uint32_t ql[7], qh[7];
         #pragma unroll
-        for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 17) ? tl[wo + k] : 0u; qh[k] = (wo + k < 17) ? th[wo + k] : 0u; }
+        for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 18) ? tl[wo + k] : 0u; qh[k] = (wo + k < 18) ? th[wo + k] : 0u; }
         const uint32_t d_end = ((uint32_t)wo * 32u + 31u < last_d) ? (uint32_t)wo * 32u + 31u : last_d;
         for (uint32_t d = (uint32_t)wo * 32u; d <= d_end; ++d)
         {

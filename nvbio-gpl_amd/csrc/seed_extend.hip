@@ -45,9 +45,72 @@ diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n,
     }
 }
 
+// opposite-mate window of a paired-end alignment: BestOppositeScoreStream::init_context
+// (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate (alignment_utils.h:52-88)
+__global__ void __launch_bounds__(256)
+opposite_mate_windows_kernel(const uint32_t* __restrict__ g_pos, const uint8_t* __restrict__ anchor_rc, const uint32_t n,
+                             const uint32_t a_len, const uint32_t o_gapped_len, const uint32_t anchor, const uint32_t policy,
+                             const uint32_t min_frag, const uint32_t max_frag, const uint32_t overlap, const uint32_t genome_len,
+                             uint32_t* __restrict__ wb, uint32_t* __restrict__ we, uint8_t* __restrict__ flags, uint8_t* __restrict__ valid)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint64_t g = g_pos[i];
+        const bool anchor_fw = anchor_rc[i] == 0;
+        const bool anchor_1  = (anchor == 0u);
+        bool left, fw;
+        switch (policy)
+        {
+        case NVBIO_PE_POLICY_FF: left = (anchor_1 != anchor_fw); fw =  anchor_fw; break;
+        case NVBIO_PE_POLICY_RR: left = (anchor_1 == anchor_fw); fw =  anchor_fw; break;
+        case NVBIO_PE_POLICY_FR: left = !anchor_fw;              fw = !anchor_fw; break;
+        default:                 left =  anchor_fw;              fw = !anchor_fw; break;     // RF
+        }
+        uint64_t begin, end;
+        if (left)
+        {
+            const uint64_t max_end = g + a_len + o_gapped_len > min_frag ? g + a_len + o_gapped_len - min_frag : 0ull;
+            begin = g + a_len > max_frag ? g + a_len - max_frag : 0ull;
+            end   = overlap ? g + a_len : g;
+            end   = end < max_end ? end : max_end;
+        }
+        else
+        {
+            const uint64_t min_begin = g + min_frag > o_gapped_len ? g + min_frag - o_gapped_len : 0ull;
+            end   = g + max_frag;
+            begin = overlap ? g : g + a_len;
+            begin = begin > min_begin ? begin : min_begin;
+        }
+        end = end < genome_len ? end : genome_len;
+        const bool ok = begin < genome_len && begin < end;
+        wb[i] = ok ? (uint32_t)begin : 0u;
+        we[i] = ok ? (uint32_t)end : 0u;
+        flags[i] = fw ? (uint8_t)0 : (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT);
+        valid[i] = ok ? 1 : 0;
+    }
+}
+
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_opposite_mate_windows(int device, const uint32_t* g_pos_dev, const uint8_t* anchor_rc_dev, uint32_t n,
+                                                    uint32_t anchor_len, uint32_t opposite_gapped_len, uint32_t anchor, uint32_t policy,
+                                                    uint32_t min_frag_len, uint32_t max_frag_len, uint32_t overlap, uint32_t genome_len,
+                                                    uint32_t* win_begin_dev, uint32_t* win_end_dev, uint8_t* flags_dev, uint8_t* valid_dev,
+                                                    void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( g_pos_dev && anchor_rc_dev && win_begin_dev && win_end_dev && flags_dev && valid_dev, "NULL device pointer" );
+    NVB_REQUIRE( policy <= NVBIO_PE_POLICY_RR, "invalid paired-end policy" );
+    NVB_REQUIRE( anchor <= 1u, "anchor must be 0 or 1" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( opposite_mate_windows_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        g_pos_dev, anchor_rc_dev, n, anchor_len, opposite_gapped_len, anchor, policy, min_frag_len, max_frag_len, overlap,
+                        genome_len, win_begin_dev, win_end_dev, flags_dev, valid_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
 
 extern "C" nvbio_status nvbio_hits_to_diagonals(int device, const nvbio_uint2* hits_dev, uint64_t n_hits, uint32_t seeds_per_read,
                                                 uint32_t seed_interval, uint32_t seed_len, uint32_t read_len, uint32_t strand,

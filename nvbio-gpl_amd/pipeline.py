@@ -75,7 +75,9 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end, or -1),
     best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events.
     return_windows: also return best_wb[int64 R], the window begin of each read's best candidate (-1 if
-    none; the largest one if several candidates tie on the whole selection key) -- what traceback_best needs."""
+    none; the largest one if several candidates tie on the whole selection key) -- what traceback_best needs --
+    and best_g[int64 R], that candidate's locus (hit.loc: the diagonal clamped at the genome start), the
+    anchor position of paired-end opposite-mate windows."""
     import torch
     from . import diagonals_to_windows, hits_to_diagonals
     dev = fmi.device
@@ -122,7 +124,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
         sel = pack_best_key(torch, scores, rc, pos)
         tock(e)
-        return rid.to(torch.int64), sel, (wb if return_windows else None)
+        g = torch.clamp((keys & ((1 << 33) - 1)) - 1024, min=0) if return_windows else None
+        return rid.to(torch.int64), sel, (wb if return_windows else None), g
 
     use_direct = params.direct and fmi.supports_direct()
     results, n_cand = [], 0
@@ -163,13 +166,14 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     best_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
     if not results:
         if return_windows:
-            return best_score, best_pos, best_rc, 0, torch.full((R,), -1, dtype=torch.int64, device=dev)
+            none = torch.full((R,), -1, dtype=torch.int64, device=dev)
+            return best_score, best_pos, best_rc, 0, none, none.clone()
         return best_score, best_pos, best_rc, 0
 
     # 5. best candidate per read
     e = tick("reduce")
     top = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    for rid, sel, _ in results:
+    for rid, sel, _, _ in results:
         top.scatter_reduce_(0, rid, sel, "amax", include_self=True)
     has = top >= 0
     sv = top >> 34
@@ -179,10 +183,12 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     tock(e)
     if return_windows:
         best_wb = torch.full((R,), -1, dtype=torch.int64, device=dev)
-        for rid, sel, wb in results:
+        best_g = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        for rid, sel, wb, g in results:
             win = sel == top[rid]
             best_wb.scatter_reduce_(0, rid[win], (wb.to(torch.int64) & 0xFFFFFFFF)[win], "amax", include_self=True)
-        return best_score, best_pos, best_rc, int(n_cand), best_wb
+            best_g.scatter_reduce_(0, rid[win], g[win], "amax", include_self=True)
+        return best_score, best_pos, best_rc, int(n_cand), best_wb, best_g
     return best_score, best_pos, best_rc, int(n_cand)
 
 
@@ -224,3 +230,78 @@ def traceback_best(genome2, genome_len, reads, params, best_score, best_rc, best
         ev.record()
     pos = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
     return ids, sc, pos, src, snk, cig, ln
+
+
+
+class PairedEndParams:
+    """nvBowtie's paired-end defaults (bowtie2_cuda_driver.cu:116-120): FR policy, fragments up to 500, mates may overlap"""
+
+    def __init__(self, policy=None, min_frag_len=0, max_frag_len=500, overlap=True):
+        from . import PE_POLICY_FR
+        self.policy = PE_POLICY_FR if policy is None else policy
+        self.min_frag_len, self.max_frag_len, self.overlap = min_frag_len, max_frag_len, overlap
+
+
+def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers=None):
+    """A paired-end composition of the path's operators in nvBowtie's shape: each mate in turn is the anchor --
+    seed-and-extend as a single end, best candidate per read -- and the other mate is scored by full-matrix DP inside the
+    window the fragment-length constraints allow around the anchor (BestOppositeScoreStream, score_inl.h:283-456), with
+    min_score = the opposite mate's own worst admissible score.  The pair with the higher anchor + opposite score wins
+    (ties: mate 1 as anchor).  Returns a dict of per-pair tensors: anchor (0/1, -1 if no pair), score1/2, pos1/2 (end
+    positions), rc1/2.  (nvBowtie additionally iterates over several anchor candidates and tightens min_score with the
+    pairs found so far; that policy is not part of this path.)"""
+    import torch
+    from . import BatchedAlignmentScore, max_text_gaps, opposite_mate_windows
+    pe = pe or PairedEndParams()
+    dev = fmi.device
+    R = mates1.n
+    assert mates2.n == R
+    worst = -(1 << 30)
+    out = {}
+    cand = []
+    for anchor, (a, o) in enumerate(((mates1, mates2), (mates2, mates1))):
+        tag = "_a%d" % anchor
+        sub = None if timers is None else {}
+        bs, bp, brc, nc, bwb, bg = seed_and_extend(fmi, genome2, genome_len, a, params, sub, return_windows=True)
+        if timers is not None:
+            for k, v in sub.items():
+                timers.setdefault(k, []).extend(v)
+        ids = torch.nonzero((bg >= 0) & (bs >= params.min_score_for(a.read_len))).view(-1)
+        o_min = params.min_score_for(o.read_len)
+        gaps = max_text_gaps(params.scheme, o_min, o.read_len)
+        g32 = torch.where(bg[ids] >= 2 ** 31, bg[ids] - 2 ** 32, bg[ids]).to(torch.int32)
+        wb, we, flags, valid = opposite_mate_windows(g32, brc[ids].contiguous(), a.read_len, o.read_len + gaps, anchor, genome_len,
+                                                     pe.policy, pe.min_frag_len, pe.max_frag_len, pe.overlap)
+        keep = torch.nonzero(valid).view(-1)
+        ids, wb, we, flags = ids[keep], wb[keep].contiguous(), we[keep].contiguous(), flags[keep].contiguous()
+        read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * o.read_len
+        batch = AlignmentBatch(o.reads4, 4, read_off, genome2, 2, wb, we, quals=o.quals, read_id=ids.to(torch.int32), flags=flags,
+                               device=dev, max_read_len=o.read_len)
+        ms = torch.full((ids.numel(),), o_min, dtype=torch.int32, device=dev)
+        ev = None
+        if timers is not None:
+            a_ev, ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            timers.setdefault("opposite" + tag, []).append((a_ev, ev)); a_ev.record()
+        osc, osk = BatchedAlignmentScore(GotohAligner(params.aln_type, params.scheme), text_blocking=False).enact(
+            batch, o.read_len, pe.max_frag_len, min_scores=ms)
+        if ev is not None:
+            ev.record()
+        ok = osc >= o_min                                            # hit.opposite_score = score >= min_score ? score : worst
+        o_score = torch.full((R,), worst, dtype=torch.int64, device=dev)
+        o_pos = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        o_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
+        sel = ids[ok]
+        o_score[sel] = osc[ok].to(torch.int64)
+        o_pos[sel] = (wb[ok].to(torch.int64) & 0xFFFFFFFF) + (osk[ok][:, 0].to(torch.int64) & 0xFFFFFFFF)
+        o_rc[sel] = (flags[ok] != 0).to(torch.uint8)
+        cand.append((bs.to(torch.int64), bp, brc, o_score, o_pos, o_rc))
+    (s1a, p1a, r1a, s2a, p2a, r2a), (s2b, p2b, r2b, s1b, p1b, r1b) = cand
+    pair_a = torch.where(s2a > worst, s1a + s2a, torch.full_like(s1a, worst))
+    pair_b = torch.where(s1b > worst, s2b + s1b, torch.full_like(s1b, worst))
+    use_b = pair_b > pair_a
+    paired = (pair_a > worst) | (pair_b > worst)
+    out["anchor"] = torch.where(paired, use_b.to(torch.int64), torch.full_like(pair_a, -1))
+    out["score1"] = torch.where(use_b, s1b, s1a); out["pos1"] = torch.where(use_b, p1b, p1a); out["rc1"] = torch.where(use_b, r1b, r1a)
+    out["score2"] = torch.where(use_b, s2b, s2a); out["pos2"] = torch.where(use_b, p2b, p2a); out["rc2"] = torch.where(use_b, r2b, r2a)
+    out["pair_score"] = torch.maximum(pair_a, pair_b)
+    return out

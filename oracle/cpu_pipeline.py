@@ -107,7 +107,7 @@ def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, se
 
 
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
-                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0):
+                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, want_loci=False):
     """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates); with
     traceback_stride > 0 also a dict with the traceback of every aligned read's best candidate (the one with
     the largest window begin among candidates tying on the selection key)."""
@@ -139,6 +139,8 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
     best_pos = np.full(R, -1, dtype=np.int64)
     best_rc = np.zeros(R, dtype=np.uint8)
     if not cands:
+        if want_loci:
+            return best_score, best_pos, best_rc, 0, np.full(R, -1, dtype=np.int64)
         return best_score, best_pos, best_rc, 0
     keys = np.unique(np.concatenate(cands))
     rid = keys >> 34
@@ -166,6 +168,11 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
     best_score = np.where(has & (sv > 0), sv - (1 << 20), best_score).astype(np.int32)
     best_pos = np.where(has, top & ((1 << 33) - 1), best_pos)
     best_rc = np.where(has, (top >> 33) & 1, best_rc).astype(np.uint8)
+    if want_loci:
+        best_g = np.full(R, -1, dtype=np.int64)
+        win = packed == top[rid]
+        np.maximum.at(best_g, rid[win], g_pos[win].astype(np.int64))
+        return best_score, best_pos, best_rc, len(keys), best_g
     if traceback_stride:
         best_wb = np.full(R, -1, dtype=np.int64)
         win = packed == top[rid]
@@ -179,3 +186,76 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
         tb = dict(ids=ids, scores=sc, pos=twb + src[:, 0].astype(np.int64), sources=src, sinks=snk, cigars=cig, lens=ln)
         return best_score, best_pos, best_rc, len(keys), tb
     return best_score, best_pos, best_rc, len(keys)
+
+
+
+def max_text_gaps(scheme, min_score, pattern_len):
+    """aln::max_text_gaps, Gotoh aligner (nvbio/alignment/utils_inl.h:141-162)"""
+    score = pattern_len * scheme.match
+    if score < min_score:
+        return 0
+    score += scheme.txt_gap_open
+    n = 0
+    while score >= min_score and n < pattern_len:
+        score += scheme.txt_gap_ext
+        n += 1
+    return (n - 1) & 0xFFFFFFFF
+
+
+def opposite_window(g, anchor_fw, a_len, o_gapped_len, anchor, genome_len, policy=1, min_frag=0, max_frag=500, overlap=True):
+    """BestOppositeScoreStream::init_context (nvBowtie score_inl.h:389-425) + frame_opposite_mate
+    (alignment_utils.h:52-88), one hit: (begin, end, opposite_is_fw, valid)"""
+    anchor_1 = anchor == 0
+    if policy == 0:
+        left, fw = (anchor_1 != anchor_fw), anchor_fw
+    elif policy == 3:
+        left, fw = (anchor_1 == anchor_fw), anchor_fw
+    elif policy == 1:
+        left, fw = (not anchor_fw), (not anchor_fw)
+    else:
+        left, fw = anchor_fw, (not anchor_fw)
+    if left:
+        max_end = g + a_len + o_gapped_len - min_frag if g + a_len + o_gapped_len > min_frag else 0
+        begin = g + a_len - max_frag if g + a_len > max_frag else 0
+        end = g + a_len if overlap else g
+        end = min(end, max_end)
+    else:
+        min_begin = g + min_frag - o_gapped_len if g + min_frag > o_gapped_len else 0
+        end = g + max_frag
+        begin = g if overlap else g + a_len
+        begin = max(begin, min_begin)
+    end = min(end, genome_len)
+    return begin, end, fw, (begin < genome_len and begin < end)
+
+
+def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_of, aln_type, max_frag=500):
+    """the composition of nvbio-gpl_amd/pipeline.py:paired_end on the oracle's functions"""
+    R = len(mates1)
+    worst = -(1 << 30)
+    cand = []
+    for anchor, (a, o) in enumerate(((mates1, mates2), (mates2, mates1))):
+        a_len, o_len = a.shape[1], o.shape[1]
+        bs, bp, brc, nc, bg = seed_and_extend_cpu(O, hidx, text, genome_len, a, aln_type=aln_type, scheme=scheme, want_loci=True)
+        o_min = min_score_of(o_len)
+        gaps = max_text_gaps(scheme, o_min, o_len)
+        o_score = np.full(R, worst, dtype=np.int64); o_pos = np.full(R, -1, dtype=np.int64); o_rc = np.zeros(R, dtype=np.uint8)
+        for r in range(R):
+            if bg[r] < 0 or bs[r] < min_score_of(a_len):
+                continue
+            begin, end, fw, valid = opposite_window(int(bg[r]), brc[r] == 0, a_len, o_len + gaps, anchor, genome_len, max_frag=max_frag)
+            if not valid:
+                continue
+            p = o[r] if fw else np.where(o[r][::-1] < 4, 3 - o[r][::-1], o[r][::-1]).astype(np.uint8)
+            ok, s_, k_ = O.full_gotoh(aln_type, 0, scheme, p, text[begin:end], None, o_min)
+            if s_ >= o_min:
+                o_score[r] = s_; o_pos[r] = begin + k_[0]; o_rc[r] = 0 if fw else 1
+        cand.append((bs.astype(np.int64), bp, brc, o_score, o_pos, o_rc))
+    (s1a, p1a, r1a, s2a, p2a, r2a), (s2b, p2b, r2b, s1b, p1b, r1b) = cand
+    pair_a = np.where(s2a > worst, s1a + s2a, worst)
+    pair_b = np.where(s1b > worst, s2b + s1b, worst)
+    use_b = pair_b > pair_a
+    paired = (pair_a > worst) | (pair_b > worst)
+    return dict(anchor=np.where(paired, use_b.astype(np.int64), -1),
+                score1=np.where(use_b, s1b, s1a), pos1=np.where(use_b, p1b, p1a), rc1=np.where(use_b, r1b, r1a),
+                score2=np.where(use_b, s2b, s2a), pos2=np.where(use_b, p2b, p2a), rc2=np.where(use_b, r2b, r2a),
+                pair_score=np.maximum(pair_a, pair_b))

@@ -99,7 +99,7 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
     """nvBowtie's end-to-end scheme (match 0) through the full-matrix kernel: jobs whose best diagonal beats every
     gapped alignment are settled without a DP, the rest go through it over a job list -- scores and sinks of
     every job equal the reference algorithm's, with and without min_score (stripe early exit), for reads with 0-3
-    mismatches, indels, N's, reversed / complemented mates, windows up to and beyond the shortcut's 496 symbols,
+    mismatches, indels, N's, reversed / complemented mates, windows up to and beyond the shortcut's 528 symbols,
     windows shorter than the read, both blockings"""
     if not shortcut:
         monkeypatch.setenv("NVBIO_AMD_NO_UNGAPPED_SCORE", "1")
@@ -111,7 +111,7 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
     lens = np.full(R, M); lens[::9] = rng.integers(40, 161, len(lens[::9]))
     roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
     starts = rng.integers(0, G - 700, R); starts[:40] = rng.integers(1000, 1200, 40)
-    wlen = rng.integers(150, 497, R); wlen[::11] = rng.integers(497, 640, len(wlen[::11])); wlen[::13] = rng.integers(60, 150, len(wlen[::13]))
+    wlen = rng.integers(150, 529, R); wlen[::11] = rng.integers(529, 640, len(wlen[::11])); wlen[::17] = 528; wlen[::13] = rng.integers(60, 150, len(wlen[::13]))
     off = (rng.random(R) * np.maximum(wlen - lens, 1)).astype(np.int64)
     reads = []
     for j in range(R):

@@ -44,7 +44,7 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
         assert params.min_score_for(150) == -90
     rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
     g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
-    bs, bp, brc, nc, bwb = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, return_windows=True)
+    bs, bp, brc, nc, bwb, bg = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, return_windows=True)
     assert want[3] <= nc <= want[3] * 1.10           # adjacent-duplicate removal may keep a few repeats
     assert np.array_equal(bs.cpu().numpy(), want[0])
     assert np.array_equal(bp.cpu().numpy(), want[1])
@@ -69,4 +69,42 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     # reads with one indel carry exactly one gap element; most reads are a single run of matches
     one_run = (tb["lens"] == 1).mean()
     assert one_run > 0.4
+    fmi.close()
+
+
+def test_paired_end_equals_cpu_path(amd, orc):
+    """FR pairs with insert ~ N(350, 50): each mate anchored in turn, the other scored by full-matrix DP inside the
+    opposite-mate window (nvBowtie's rule), best pair per read -- equal to the same composition on the oracle"""
+    import torch
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    rng = np.random.default_rng(9)
+    G = 1_000_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    hidx = orc.build_index(text)
+    genome2 = orc.pack2(text)
+    fmi = amd.FMIndex.build(genome2, G, kmer_len=10, sa_int=1)
+    R, M = 3000, 150
+    ins = np.clip(rng.normal(350, 50, R), 160, 500).astype(np.int64)
+    left = rng.integers(0, G - 520, R)
+    left[:20] = rng.integers(0, 30, 20); left[20:40] = G - 520 - rng.integers(0, 10, 20)      # fragments at both genome ends
+    m1 = mutate_reads(rng, text, left, M)                                                     # forward mate at the fragment start
+    m2 = mutate_reads(rng, text, left + ins - M, M)
+    m2 = (3 - m2[:, ::-1]).astype(np.uint8)                                                   # reverse mate at its end (FR)
+    swap = rng.random(R) < 0.5                                                                # the fragment comes from either strand
+    m1[swap], m2[swap] = m2[swap].copy(), m1[swap].copy()
+    m2[-30:] = rng.integers(0, 4, (30, M))                                                    # mates that belong nowhere
+    params = pipeline.SeedExtendParams.end_to_end()
+    want = cpu_pipeline.paired_end_cpu(orc, hidx, text, G, m1, m2, oracle.Scheme(0, 6, 6, -8, -3, -8, -3), params.min_score_for,
+                                       oracle.SEMI_GLOBAL)
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    b1 = pipeline.ReadBatch(torch.from_numpy(orc.pack4(m1.reshape(-1)).view(np.int32)).cuda(), R, M)
+    b2 = pipeline.ReadBatch(torch.from_numpy(orc.pack4(m2.reshape(-1)).view(np.int32)).cuda(), R, M)
+    got = pipeline.paired_end(fmi, g_dev, G, b1, b2, params)
+    for k in ("anchor", "pair_score", "score1", "score2", "pos1", "pos2", "rc1", "rc2"):
+        assert np.array_equal(got[k].cpu().numpy().astype(np.int64), want[k].astype(np.int64)), k
+    paired = want["anchor"] >= 0
+    assert paired[:-30].mean() > 0.97 and not paired[-30:].any()
+    # concordant FR pairs: opposite strands, ends within the fragment
+    ok = paired & (want["rc1"] != want["rc2"]) & (np.abs(want["pos1"] - want["pos2"]) <= 500)
+    assert ok.sum() >= 0.99 * paired.sum()
     fmi.close()
