@@ -29,7 +29,9 @@ class SeedExtendParams:
         # nvBowtie local() scheme (scoring_inl.h:72-93): match 2, mismatch 2..6 by quality, gaps 5+3 / 3
         self.scheme = scheme or GotohScheme(2, 2, 6, -8, -3, -8, -3)
         self.min_score = min_score                  # None -> nvBowtie local(): int(0 + 10*ln(len)) (scoring.h:117-129)
-        self.max_seed_hits = max_seed_hits          # None: every SA row of every seed range is extended (fmmap)
+        self.max_seed_hits = max_seed_hits          # None: every SA row of every seed range is extended (fmmap); k: only
+                                                    # the first k rows of a seed's SA range (a deterministic stand-in for
+                                                    # nvBowtie's max_hits cap, which guards against repeat seeds)
         self.direct = True                          # use match_direct when the index holds the full SA and the text
 
     @classmethod
@@ -97,8 +99,6 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         if b is not None:
             b.record()
 
-    if params.max_seed_hits is not None:
-        raise NotImplementedError("max_seed_hits policy is not built yet")
 
     # 1. seeds: infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernel
     #    (uniform_seeds_functor semantics; no offset array is materialised)
@@ -141,6 +141,12 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         else:
             ranges, direct = fmi.match(qs, flags), None
         tock(e)
+        if params.max_seed_hits is not None:
+            # keep the first max_seed_hits rows of every range (empty ranges, x > y, stay empty; direct ones hold 1 hit)
+            x = ranges[:, 0].to(torch.int64) & 0xFFFFFFFF
+            y = ranges[:, 1].to(torch.int64) & 0xFFFFFFFF
+            ycap = torch.minimum(y, x + (params.max_seed_hits - 1))
+            ranges = torch.stack([ranges[:, 0], torch.where(ycap >= 2 ** 31, ycap - 2 ** 32, ycap).to(torch.int32)], dim=1).contiguous()
         e = tick("scan")
         n_hits = flt.rank_ranges(fmi, ranges, direct)
         tock(e)
@@ -155,6 +161,10 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         #    removes nearly all duplicates without a sort; a survivor only costs a repeated extension)
         e = tick("diagonals")
         keys = torch.unique_consecutive(hits_to_diagonals(hits, spr, S_int, L, M, strand))
+        if keys.numel() > 2 * R:
+            # repeats: the seeds of a read list the same loci over and over, interleaved, so the adjacent compare misses
+            # them; a sort-based unique costs far less than extending every copy (not taken on unique-ish genomes)
+            keys = torch.unique(keys)
         tock(e)
         n_cand += keys.numel()
         # (running this strand's VALU-bound extension on a second stream beside the other strand's

@@ -107,7 +107,8 @@ def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, se
 
 
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
-                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, want_loci=False):
+                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, want_loci=False,
+                        max_seed_hits=None):
     """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates); with
     traceback_stride > 0 also a dict with the traceback of every aligned read's best candidate (the one with
     the largest window begin among candidates tying on the selection key)."""
@@ -125,6 +126,13 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
         flat = np.ascontiguousarray(seeds.reshape(-1))
         offs = (np.arange(R * spr + 1) * L).astype(np.uint32)
         total, ranges, slots = O.filter_rank(hidx, flat, offs)
+        if max_seed_hits is not None:                    # first max_seed_hits rows of every SA range
+            x = ranges[:, 0].astype(np.int64); y = ranges[:, 1].astype(np.int64)
+            ranges = np.stack([x, np.where(y >= x, np.minimum(y, x + max_seed_hits - 1), y)], axis=1).astype(np.uint32)
+            sizes = np.where(ranges[:, 1].astype(np.int64) >= ranges[:, 0].astype(np.int64),
+                             ranges[:, 1].astype(np.int64) + 1 - ranges[:, 0], 0)
+            slots = np.cumsum(sizes).astype(np.uint64)
+            total = int(sizes.sum())
         if total == 0:
             continue
         hits = O.filter_locate(hidx, ranges, slots, 0, total)

@@ -13,6 +13,42 @@ from util import mutate_reads
 pytestmark = pytest.mark.gpu
 
 
+def test_pipeline_seed_hit_cap_on_repeats(amd, orc):
+    """a genome with a 40-copy repeat: without a cap every read from it extends 9 seeds x 40 rows; with
+    max_seed_hits = 4 only the first 4 rows of each seed's SA range -- same composition on the oracle"""
+    import torch
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    rng = np.random.default_rng(3)
+    G = 600_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    unit = rng.integers(0, 4, 400, dtype=np.uint8)
+    for c in range(40):
+        text[20000 + 9000 * c:20400 + 9000 * c] = unit
+    hidx = orc.build_index(text)
+    genome2 = orc.pack2(text)
+    fmi = amd.FMIndex.build(genome2, G, kmer_len=9, sa_int=1)
+    R, M = 4000, 150
+    starts = rng.integers(0, G - M - 8, R)
+    starts[:600] = 20000 + 9000 * rng.integers(0, 40, 600) + rng.integers(0, 240, 600)      # reads inside the repeat
+    reads = mutate_reads(rng, text, starts, M)
+    rcm = rng.random(R) < 0.5
+    reads[rcm] = 3 - reads[rcm][:, ::-1]
+    rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    n_c = []
+    for cap in (None, 4):
+        params = pipeline.SeedExtendParams.end_to_end(max_seed_hits=cap)
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
+                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3), max_seed_hits=cap)
+        bs, bp, brc, nc = pipeline.seed_and_extend(fmi, g_dev, G, rb, params)
+        assert np.array_equal(bs.cpu().numpy(), want[0]) and np.array_equal(bp.cpu().numpy(), want[1])
+        assert np.array_equal(brc.cpu().numpy(), want[2])
+        assert want[3] <= nc <= want[3] * 1.10
+        n_c.append(nc)
+    assert n_c[1] < n_c[0] / 2                                  # the cap removed most of the repeat's candidates
+    fmi.close()
+
+
 @pytest.mark.parametrize("mode", ["local", "e2e"])
 def test_pipeline_equals_cpu_path(amd, orc, mode):
     import torch
