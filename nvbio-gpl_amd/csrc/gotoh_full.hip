@@ -392,6 +392,213 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     else need_dp[job] = 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit packed pattern-blocking kernel: one lane owns TWO jobs of the same shape (M = max_pattern_len,
+// N = max_text_len -- the opposite-mate windows of a read batch), one in each half of every register, as
+// banded_gotoh_band31_pk_kernel does for the banded DP.  The boundary column already is the reference's int16
+// (H,E) pair; here the registers are too, which is exact as long as no real score can leave +-16000 (host
+// check) -- the infimum cells stay representable: -32768 - min(Go,Ge) + Ge >= -32768.  Equality of the row's
+// text symbol with the stripe's 8 pattern symbols comes from one XOR on 2-bit packed symbols per job.
+// Jobs of any other shape go through full_gotoh_kernel (a second job list).
+// ---------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pk(const int a, const int b) { v2s r; r.x = (short)a; r.y = (short)b; return r; }
+__device__ __forceinline__ v2s pk_max(const v2s a, const v2s b) { return __builtin_elementwise_max( a, b ); }
+__device__ __forceinline__ v2s pk_bits(const uint32_t u) { return __builtin_bit_cast( v2s, u ); }
+__device__ __forceinline__ uint32_t bits_pk(const v2s v) { return __builtin_bit_cast( uint32_t, v ); }
+
+template <int TYPE, int RBITS>
+__global__ void __launch_bounds__(128)
+full_gotoh_pb_pk_kernel(const BatchDev b, const SchemeDev sc, const uint32_t M, const uint32_t N, const uint32_t pair_begin, const uint32_t pairs,
+                        const int32_t* __restrict__ min_scores, uint2* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                        const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
+{
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // pair slot inside this launch
+    if (t >= pairs) return;
+    const uint32_t n_jobs = *job_count;
+    const uint32_t slot0 = 2u * (pair_begin + t);
+    if (slot0 >= n_jobs) return;
+
+    uint32_t job[2], first[2], tb[2]; bool rev[2], comp[2], valid[2]; int32_t min_score[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        valid[u] = slot0 + u < n_jobs;
+        job[u]   = job_list[valid[u] ? slot0 + u : slot0];
+        const uint32_t rid = b.read_id ? b.read_id[job[u]] : job[u];
+        first[u] = b.read_offsets[rid];
+        const uint32_t fl = b.flags ? b.flags[job[u]] : 0u;
+        rev[u]  = (fl & NVBIO_READ_REVERSE) != 0;
+        comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
+        tb[u]   = b.win_begin[job[u]];
+        min_score[u] = min_scores ? min_scores[job[u]] : NVBIO_SCORE_MIN;
+    }
+
+    SymbolReader<2> trd0( b.text ), trd1( b.text );
+    SymbolReader<RBITS> prd0( b.reads ), prd1( b.reads );
+
+    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    const v2s GO = pk( G_o, G_o ), GE = pk( G_e, G_e );
+    const int gm = G_o > G_e ? G_o : G_e;
+    const v2s GM = pk( gm, gm ), INF = pk( infimum, infimum ), ZERO = pk( 0, 0 ), K16 = pk( 16, 16 );
+    const int32_t V = sc.match;
+
+    uint2* col = column + t;                                    // element i at col[i * pairs]: (cell of job 0, cell of job 1)
+    for (uint32_t i = 0; i < N; ++i)                             // GotohScoringContext::init (gotoh_inl.h:56-74)
+    {
+        const int32_t x = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + sc.txt_ge * (int32_t)i : 0;
+        const int32_t y = (TYPE == NVBIO_LOCAL) ? 0 : infimum;
+        const uint32_t c = pack_cell( x, y );
+        col[(size_t)i * pairs] = make_uint2( c, c );
+    }
+
+    Sink sink[2]; sink[0].init(); sink[1].init();
+    bool alive[2] = { true, true };
+    const uint32_t nb        = (M + STRIPE - 1u) / STRIPE;
+    const uint32_t end_block = (STRIPE * nb > (uint32_t)STRIPE) ? STRIPE * nb : (uint32_t)STRIPE;
+    const uint32_t jm = ((M - 1u) & (STRIPE - 1u)) + 1u;
+
+    v2s c_mm[STRIPE], c_dv[STRIPE];
+    #pragma unroll
+    for (int j = 0; j < STRIPE; ++j) { c_mm[j] = ZERO; c_dv[j] = ZERO; }
+    uint32_t cs[2] = { 0, 0 }, cnot[2] = { 0x5555u, 0x5555u };  // stripe symbols, 2 bits each; bit 2j set where column j can never match
+    v2s H[STRIPE + 1], F[STRIPE + 1];
+
+    for (uint32_t block = 0; block < end_block && (alive[0] || alive[1]); block += STRIPE)
+    {
+        const bool last = (block + STRIPE >= end_block);
+        #pragma unroll
+        for (int j = 0; j < STRIPE; ++j)
+        {
+            if (block + j < M)
+            {
+                int mm2[2];
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t idx = rev[u] ? first[u] + M - 1u - (block + j) : first[u] + block + j;
+                    uint32_t q = u ? prd1.get( idx ) : prd0.get( idx );
+                    if (comp[u] && q < 4u) q = 3u - q;
+                    const uint32_t qq = b.quals ? b.quals[idx] : 0u;
+                    mm2[u] = s_mm[qq < 63u ? qq : 63u];
+                    cs[u]   = (cs[u] & ~(3u << (2 * j))) | ((q & 3u) << (2 * j));
+                    cnot[u] = (cnot[u] & ~(1u << (2 * j))) | ((q > 3u ? 1u : 0u) << (2 * j));
+                }
+                c_mm[j] = pk( mm2[0], mm2[1] );
+                c_dv[j] = pk( V - mm2[0], V - mm2[1] );
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j <= STRIPE; ++j)
+        {
+            const int h0 = (TYPE != NVBIO_LOCAL) ? ((block + j > 0) ? G_o + G_e * (int32_t)(block + j - 1u) : 0) : 0;     // :676-681
+            H[j] = pk( h0, h0 ); F[j] = INF;
+        }
+        v2s max_score = pk( -32768, -32768 );
+        v2s temp_i    = H[0];
+
+        for (uint32_t i = 0; i < N; ++i)
+        {
+            const uint32_t r0 = trd0.get( tb[0] + i ), r1 = trd1.get( tb[1] + i );
+            // equality of the row's text symbol with the stripe's 8 pattern symbols, job 0 at even bits, job 1 at odd bits
+            const uint32_t x0 = cs[0] ^ (r0 * 0x5555u), x1 = cs[1] ^ (r1 * 0x5555u);
+            const uint32_t e0 = ~(x0 | (x0 >> 1)) & 0x5555u & ~cnot[0];
+            const uint32_t e1 = ~(x1 | (x1 >> 1)) & 0x5555u & ~cnot[1];
+            const uint32_t EQ = e0 | (e1 << 1);
+
+            v2s H_diag = temp_i;
+            const uint2 cell = col[(size_t)i * pairs];
+            H[0] = temp_i = pk( cell_h( cell.x ), cell_h( cell.y ) );
+            v2s E = pk( cell_e( cell.x ), cell_e( cell.y ) );
+            v2s key = pk( -1, -1 );
+            #pragma unroll
+            for (int j = 1; j <= STRIPE; ++j)
+            {
+                const v2s f = pk_max( F[j] + GE, H[j] + GO );
+                F[j] = f;
+                E = pk_max( E + GE, H[j - 1] + GO );
+                const uint32_t eq01 = ((EQ >> (2 * (j - 1))) & 1u) | (((EQ >> (2 * (j - 1) + 1)) & 1u) << 16);
+                const v2s d = H_diag + c_mm[j - 1] + pk_bits( eq01 ) * c_dv[j - 1];
+                v2s hi = pk_max( pk_max( E, f ), d );
+                if (TYPE == NVBIO_LOCAL) hi = pk_max( hi, ZERO );
+                H_diag = H[j];
+                H[j]   = hi;
+                if (TYPE == NVBIO_LOCAL && (!last || block + j <= M)) key = pk_max( key, hi * K16 + pk( j, j ) );
+            }
+            col[(size_t)i * pairs] = make_uint2( pack_cell( H[STRIPE].x, E.x ), pack_cell( H[STRIPE].y, E.y ) );
+            max_score = pk_max( max_score, H[STRIPE] );
+
+            if (TYPE == NVBIO_LOCAL)
+            {
+                const int k0 = key.x, k1 = key.y;
+                if (alive[0] && k0 >= 0) sink[0].report( k0 >> 4, i + 1u, block + (uint32_t)(k0 & 15) );
+                if (alive[1] && k1 >= 0) sink[1].report( k1 >> 4, i + 1u, block + (uint32_t)(k1 & 15) );
+            }
+            else if (last && TYPE == NVBIO_SEMI_GLOBAL)
+            {
+                v2s v = ZERO;
+                #pragma unroll
+                for (int j = 1; j <= STRIPE; ++j) if ((uint32_t)j == jm) v = H[j];
+                if (alive[0]) sink[0].report( v.x, i + 1u, M );
+                if (alive[1]) sink[1].report( v.y, i + 1u, M );
+            }
+        }
+        if (!last)
+        {
+            const int32_t missing = (int32_t)(M - block - STRIPE);
+            if ((int32_t)max_score.x + missing * V < min_score[0]) alive[0] = false;     // stripe early exit, per job
+            if ((int32_t)max_score.y + missing * V < min_score[1]) alive[1] = false;
+        }
+    }
+    if (TYPE == NVBIO_GLOBAL)
+    {
+        v2s v = ZERO;
+        #pragma unroll
+        for (int j = 1; j <= STRIPE; ++j) if ((uint32_t)j == jm) v = H[j];
+        if (alive[0]) sink[0].report( v.x, N, M );
+        if (alive[1]) sink[1].report( v.y, N, M );
+    }
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (valid[u]) { scores[job[u]] = sink[u].score; sinks[job[u]] = make_uint2( sink[u].x, sink[u].y ); }
+}
+
+// jobs of the batch's dominant shape that still need the DP go to the packed kernel, the other ones that need it
+// to full_gotoh_kernel: two flag arrays for two DeviceSelect passes
+__global__ void __launch_bounds__(256)
+classify_shape_kernel(const BatchDev b, const uint32_t M0, const uint32_t N0, const uint8_t* __restrict__ need_dp,
+                      uint8_t* __restrict__ to_packed, uint8_t* __restrict__ to_plain)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t rid = b.read_id ? b.read_id[job] : job;
+    const uint32_t M = b.read_offsets[rid + 1] - b.read_offsets[rid];
+    const uint32_t N = b.win_end[job] - b.win_begin[job];
+    const bool need = need_dp ? need_dp[job] != 0 : true;
+    const bool uni  = (M == M0 && N == N0);
+    to_packed[job] = (need && uni) ? 1 : 0;
+    to_plain[job]  = (need && !uni) ? 1 : 0;
+}
+
+static bool full_packed_ok(const int type, const SchemeDev& sc, const uint32_t M, const uint32_t N)
+{
+    if (M == 0 || N == 0) return false;
+    if (sc.match < 0 || sc.mm_min < 0 || sc.mm_max < 0) return false;
+    int64_t step = sc.match;
+    const int64_t c[] = { sc.mm_min, sc.mm_max, -(int64_t)sc.pat_go, -(int64_t)sc.pat_ge, -(int64_t)sc.txt_go, -(int64_t)sc.txt_ge };
+    for (int64_t v : c) { if (v < 0) return false; if (v > step) step = v; }       // gap terms must be <= 0, penalties >= 0
+    if (step > 4096) return false;
+    if (((int64_t)M + N) * step > 12000) return false;
+    if (type == NVBIO_LOCAL && (int64_t)sc.match * M > 2000) return false;          // (score << 4 | column) must fit an int16
+    return true;
+}
+
 static bool full_ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P)
 {
     if (sc.match != 0) return false;
@@ -467,34 +674,60 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
                      scheme->txt_gap_open, scheme->txt_gap_ext };
 
-    // ---- end-to-end shortcut: settle the jobs whose best diagonal beats every gapped alignment, compact the rest ----
-    uint32_t* job_list = nullptr; uint32_t* job_count = nullptr; void* aux = nullptr;
+    // ---- which jobs need which kernel --------------------------------------------------------------------------
+    //  1. end-to-end shortcut (ungapped_full_e2e_kernel): settles the jobs whose best diagonal beats every gapped
+    //     alignment and flags the rest (need_dp);
+    //  2. pattern blocking, packable scheme: the flagged jobs of the batch's dominant shape (M = max_pattern_len,
+    //     N = max_text_len) go to the 16-bit packed kernel two per lane (list A), the others to the int32 kernel (list B);
+    //     otherwise every flagged job goes to the int32 kernel (list B).
+    //  The lists and their lengths stay on the device.
+    uint32_t *list_a = nullptr, *count_a = nullptr, *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
+    int32_t P = 0;
+    const bool packable_bits = batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2);
+    const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" );
+    const bool packed   = !text_blocking && packable_bits && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
+                          !getenv( "NVBIO_AMD_NO_PACKED_DP" );
+    if (shortcut || packed)
     {
-        int32_t P = 0;
-        if (type == NVBIO_SEMI_GLOBAL && batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2) &&
-            full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" ))
+        size_t sel_bytes = 0;
+        hipcub::CountingInputIterator<uint32_t> ids( 0u );
+        NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
+        const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
+        const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+        if (hipMallocAsync( &aux, 3u * flags_bytes + 2u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        {
+            set_error( "full Gotoh: out of device memory for the job lists" );
+            return NVBIO_ERR_NOMEM;
+        }
+        uint8_t* need_dp   = (uint8_t*)aux;
+        uint8_t* to_packed = need_dp + flags_bytes;
+        uint8_t* to_plain  = to_packed + flags_bytes;
+        list_a    = (uint32_t*)(to_plain + flags_bytes);
+        job_list  = (uint32_t*)((uint8_t*)list_a + list_bytes);
+        count_a   = (uint32_t*)((uint8_t*)job_list + list_bytes);
+        job_count = count_a + 1;
+        void* sel_temp = (uint8_t*)count_a + 256u;
+        const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
+        if (shortcut)
         {
             const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
-            size_t sel_bytes = 0;
-            hipcub::CountingInputIterator<uint32_t> ids( 0u );
-            NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
-            const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
-            const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-            if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
-            {
-                set_error( "full Gotoh: out of device memory for the job list" );
-                return NVBIO_ERR_NOMEM;
-            }
-            uint8_t* need_dp = (uint8_t*)aux;
-            job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
-            job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
-            void* sel_temp = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
-            const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
             if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
             else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
-            const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
-            if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
         }
+        hipError_t e = hipSuccess;
+        if (packed)
+        {
+            hipLaunchKernelGGL( classify_shape_kernel, grid, block, 0, s, b, max_pattern_len, max_text_len, shortcut ? (const uint8_t*)need_dp : (const uint8_t*)nullptr,
+                                to_packed, to_plain );
+            e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, to_packed, list_a, count_a, (int)b.n, s );
+            if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, to_plain, job_list, job_count, (int)b.n, s );
+        }
+        else
+        {
+            list_a = nullptr; count_a = nullptr;
+            e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        }
+        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
     // boundary columns: caller scratch if given, else stream-ordered scratch; jobs are processed in
@@ -527,6 +760,29 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
         column = (uint32_t*)owned;
     }
     nvbio_status st = NVBIO_OK;
+    if (list_a)
+    {
+        // packed kernel over list A: a pair of jobs shares a lane and a column of (cell, cell) pairs -- the same bytes per job
+        const uint64_t cap_pairs = cap_jobs / 2u ? cap_jobs / 2u : 1u;
+        const uint64_t all_pairs = ((uint64_t)b.n + 1u) / 2u;
+        for (uint64_t pb = 0; pb < all_pairs && st == NVBIO_OK; pb += cap_pairs)
+        {
+            const uint32_t pairs = (uint32_t)((all_pairs - pb) < cap_pairs ? (all_pairs - pb) : cap_pairs);
+            const dim3 grid( (pairs + 127u) / 128u ), block( 128 );
+#define NVB_PK(TYPE_, RB) hipLaunchKernelGGL( (full_gotoh_pb_pk_kernel<TYPE_,RB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)pb, pairs, \
+                                              min_scores_dev, (uint2*)column, scores_dev, (uint2*)sinks_dev, (const uint32_t*)list_a, (const uint32_t*)count_a )
+            if (batch->read_bits == 4)
+            {
+                if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 4 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 4 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 4 );
+            }
+            else
+            {
+                if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 2 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 2 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 2 );
+            }
+#undef NVB_PK
+            if (hipGetLastError() != hipSuccess) { set_error( "packed full Gotoh launch failed" ); st = NVBIO_ERR_HIP; }
+        }
+    }
     for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
     {
         const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);

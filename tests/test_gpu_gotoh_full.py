@@ -159,3 +159,66 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
                     assert got_s[j] == s_ and tuple(got_k[j]) == k_, (use_q, min_scores is not None, blocking, j, lens[j], wlen[j])
                     settled += int(s_ > -8)
     assert settled > 2000                                           # plenty of jobs the shortcut can settle
+
+
+@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL", "GLOBAL"])
+def test_packed_pattern_blocking_kernel(amd, orc, typ):
+    """pattern blocking on a batch of one dominant shape (150 x 400, the opposite-mate case): those jobs run two per
+    lane in 16-bit registers, odd-shaped ones through the int32 kernel; odd job counts, reversed / complemented
+    reads, qualities, N's, per-job min_score (early exit of one job of a pair only), with and without the
+    end-to-end shortcut in front -- every score and sink equals the reference algorithm's"""
+    typ = getattr(oracle, typ)
+    rng = np.random.default_rng(41)
+    G = 200000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R, M, W = 701, 150, 400
+    lens = np.full(R, M); lens[5::50] = rng.integers(60, 150, len(lens[5::50]))
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(0, G - 500, R)
+    wlen = np.full(R, W); wlen[7::40] = rng.integers(150, 400, len(wlen[7::40]))
+    off = rng.integers(0, 200, R)
+    reads = []
+    for j in range(R):
+        r = text[starts[j] + off[j]:starts[j] + off[j] + lens[j]].copy()
+        k = int(rng.integers(0, 6))
+        if k:
+            pos = rng.integers(0, lens[j], k); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        if j % 5 == 0:
+            c = int(rng.integers(5, lens[j] - 5)); g = int(rng.integers(1, 5))
+            r = np.concatenate([r[:c], r[c + g:], rng.integers(0, 4, g, dtype=np.uint8)]) if j % 2 else \
+                np.concatenate([r[:c], rng.integers(0, 4, g, dtype=np.uint8), r[c:lens[j] - g]])
+        if j % 31 == 0:
+            r[int(rng.integers(0, lens[j]))] = 4
+        if j % 23 == 0:
+            r = rng.integers(0, 4, lens[j]).astype(np.uint8)        # unrelated: exercises the early exit
+        reads.append(r.astype(np.uint8))
+    flags = rng.integers(0, 4, R).astype(np.uint8)
+    stored = []
+    for j, r in enumerate(reads):
+        v = r.copy()
+        if flags[j] & 2:
+            v = np.where(v < 4, 3 - v, v).astype(np.uint8)
+        if flags[j] & 1:
+            v = v[::-1]
+        stored.append(v)
+    flat = np.concatenate(stored)
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    wb = starts.astype(np.uint32); we = (starts + wlen).astype(np.uint32)
+    for sv in ((2, 2, 6, -8, -3, -8, -3), (0, 6, 6, -8, -3, -8, -3)):
+        if typ == oracle.LOCAL and sv[0] == 0:
+            continue
+        lo = -100 if sv[0] == 0 else 100
+        ms = rng.integers(lo, lo + 150, R).astype(np.int32); ms[::4] = oracle.SCORE_MIN
+        for use_q in (True, False):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals if use_q else None, flags=flags)
+            for min_scores in (ms, None):
+                sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(typ, _scheme(amd, sv)), text_blocking=False).enact(
+                    batch, M, W, min_scores=min_scores)
+                got_s, got_k = sc.cpu().numpy(), amd.u32(sk)
+                for j in range(R):
+                    q = quals[roffs[j]:roffs[j + 1]]
+                    if flags[j] & 1:
+                        q = q[::-1]
+                    ok, s_, k_ = orc.full_gotoh(typ, 0, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]], q if use_q else None,
+                                               int(min_scores[j]) if min_scores is not None else oracle.SCORE_MIN)
+                    assert got_s[j] == s_ and tuple(got_k[j]) == k_, (sv, use_q, min_scores is not None, j, lens[j], wlen[j])
