@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--mode", choices=("e2e", "local"), default="e2e",
                     help="nvBowtie scoring mode of the extension: end-to-end (default, SURVEY 8d config 3) or local")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-direct", action="store_true", help="plain match() + locate() instead of the fused direct-position seed pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
