@@ -210,6 +210,14 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
                                            const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
                                            nvbio_uint2* hits_dev, void* stream);
 
+/* nvbio_fm_filter_locate[_direct] and nvbio_hits_to_diagonals (below) in one pass: the expansion writes each hit's
+ * diagonal key (read << 34 | strand << 33 | diagonal + 1024) instead of the (position, query) pair; direct_dev may
+ * be NULL (plain ranges).  keys_dev[h - begin] equals nvbio_hits_to_diagonals of the hit nvbio_fm_filter_locate writes. */
+nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                              const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                              uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                              uint32_t strand, uint64_t* keys_dev, void* stream);
+
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)
  * pos_dev[i] = lookup_ssa_iterator(jt[i]) = ssa[j/sa_int] + t      (fmindex_inl.h:445-460)
@@ -299,6 +307,14 @@ typedef struct
 } nvbio_alignment_batch;
 
 enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };
+
+/* Best candidate per read after the extension (the per-read score reduction of examples/fmmap/fmmap.cu:367-376, with a
+ * total order): for candidate i of read keys_dev[i] >> 34,
+ *   sel = max(scores[i] + 2^20, 0) << 34 | strand << 33 | (win_begin[i] + sinks[i].x)     (end position, hit.sink)
+ * and best_dev[read] = max(best_dev[read], sel) by 64-bit atomic max.  The caller zero-initialises best_dev;
+ * a read without candidates keeps 0.  */
+nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                         const uint32_t* win_begin_dev, uint64_t n, uint64_t* best_dev, void* stream);
 
 /* Paired-end: the genome window in which the opposite mate of an anchored mate is aligned (full-matrix DP),
  * BestOppositeScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate

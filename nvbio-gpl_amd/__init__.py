@@ -381,6 +381,17 @@ class FMIndexFilter:
                                             ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))
         return hits
 
+    def locate_diagonals(self, begin, end, seeds_per_read, seed_interval, seed_len, read_len, strand):
+        """locate() and hits_to_diagonals() in one pass (nvbio_fm_filter_locate_diagonals): int64 keys
+        read << 34 | strand << 33 | diagonal + 1024 of hit indices [begin, end)"""
+        torch = _torch()
+        keys = torch.empty(end - begin, dtype=torch.int64, device=self._index.device)
+        _check(lib().nvbio_fm_filter_locate_diagonals(
+            self._index._h, _ptr(self._ranges), _ptr(self._slots), _ptr(self._direct), ctypes.c_uint32(self._n_queries),
+            ctypes.c_uint64(begin), ctypes.c_uint64(end), ctypes.c_uint32(seeds_per_read), ctypes.c_uint32(seed_interval),
+            ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), ctypes.c_uint32(strand), _ptr(keys), _stream_ptr(self._index.device)))
+        return keys
+
     def n_hits(self):
         return self._n_hits
 
@@ -549,6 +560,14 @@ def hits_to_diagonals(hits, seeds_per_read, seed_interval, seed_len, read_len, s
                                          ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), ctypes.c_uint32(strand),
                                          _ptr(keys), _stream_ptr(hits.device)))
     return keys
+
+
+def best_candidate_reduce(keys, scores, sinks, win_begin, best):
+    """best[read] = max(best[read], selection key of each candidate) by 64-bit atomic max (nvbio_best_candidate_reduce);
+    best: int64 tensor, zero-initialised by the caller, one entry per read"""
+    _check(lib().nvbio_best_candidate_reduce(FMIndex._dev_index(keys.device), _ptr(keys), _ptr(scores), _ptr(sinks), _ptr(win_begin),
+                                             ctypes.c_uint64(keys.shape[0]), _ptr(best), _stream_ptr(keys.device)))
+    return best
 
 
 PE_POLICY_FF, PE_POLICY_FR, PE_POLICY_RF, PE_POLICY_RR = 0, 1, 2, 3

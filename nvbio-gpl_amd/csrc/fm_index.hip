@@ -302,9 +302,15 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t* __restrict__
     return lo;
 }
 
+// seed enumeration of a hit's query id -> its diagonal key (hit_to_diagonal, examples/fmmap/fmmap.cu:92-117; see
+// nvbio_hits_to_diagonals): with KEYS the expansion writes the 8-byte key instead of the (position, query) pair
+struct DiagSpec { uint32_t spr, interval, seed_len, read_len, strand; };
+
+template <bool KEYS>
 __global__ void __launch_bounds__(256)
 fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint64_t* __restrict__ slots, const uint32_t n_queries,
-                        const uint64_t begin, const uint64_t end, uint2* __restrict__ hits, const uint8_t* __restrict__ direct)
+                        const uint64_t begin, const uint64_t end, uint2* __restrict__ hits, const uint8_t* __restrict__ direct,
+                        const DiagSpec ds, uint64_t* __restrict__ keys)
 {
     __shared__ uint32_t s_q[2];
     const uint32_t mask    = (1u << f.sa_log) - 1u;
@@ -336,7 +342,15 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
             {
                 if (is_pos || (j & mask) == 0)
                 {
-                    hits[h - begin] = make_uint2( is_pos ? j : f.ssa[j >> f.sa_log] + t, slot );
+                    const uint32_t pos = is_pos ? j : f.ssa[j >> f.sa_log] + t;
+                    if (KEYS)
+                    {
+                        const uint32_t rid = slot / ds.spr;
+                        uint32_t       p   = (slot - rid * ds.spr) * ds.interval;
+                        if (ds.strand) p = ds.read_len - p - ds.seed_len;
+                        keys[h - begin] = ((uint64_t)rid << 34) | ((uint64_t)(ds.strand & 1u) << 33) | ((uint64_t)pos + 1024u - p);
+                    }
+                    else hits[h - begin] = make_uint2( pos, slot );
                     h += 256u; have = h < t_end;
                     if (have) start();
                 }
@@ -625,8 +639,8 @@ nvbio_status nvbio_fm_filter_locate(nvbio_fm_index_t index, const nvbio_uint2* r
     FMIndexImpl* idx = (FMIndexImpl*)index;
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
-                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, (const uint8_t*)nullptr );
+    hipLaunchKernelGGL( fm_filter_locate_kernel<false>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, (const uint8_t*)nullptr, DiagSpec{}, (uint64_t*)nullptr );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }
@@ -681,8 +695,28 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
     FMIndexImpl* idx = (FMIndexImpl*)index;
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    hipLaunchKernelGGL( fm_filter_locate_kernel, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
-                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, direct_dev );
+    hipLaunchKernelGGL( fm_filter_locate_kernel<false>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)hits_dev, direct_dev, DiagSpec{}, (uint64_t*)nullptr );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                              const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                              uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                              uint32_t strand, uint64_t* keys_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    if (end <= begin) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && slots_dev && keys_dev, "NULL device pointer" );
+    NVB_REQUIRE( seeds_per_read > 0, "seeds_per_read must be positive" );
+    NVB_REQUIRE( (uint64_t)(seeds_per_read - 1u) * seed_interval + seed_len <= read_len, "seeds do not fit the read" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, strand };
+    hipLaunchKernelGGL( fm_filter_locate_kernel<true>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
+                        idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)nullptr, direct_dev, ds, keys_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

@@ -45,6 +45,24 @@ diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n,
     }
 }
 
+// best candidate per read: selection key = (score + 2^20, clamped at 0) << 34 | strand << 33 | end position, end position
+// = window begin + sink.x (hit.sink, score_inl.h:127-129); one 64-bit atomic max per candidate into best[read]
+// (fmmap reduces the score per read the same way, examples/fmmap/fmmap.cu:367-376; the key makes the choice unique
+// and independent of the order candidates arrive in)
+__global__ void __launch_bounds__(256)
+best_candidate_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                      const uint32_t* __restrict__ wb, const uint64_t n, unsigned long long* __restrict__ best)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t k   = keys[i];
+        const int64_t  s   = (int64_t)scores[i] + (1ll << 20);
+        const uint64_t pos = (uint64_t)wb[i] + (uint64_t)sinks[i].x;
+        const uint64_t sel = ((uint64_t)(s > 0 ? s : 0) << 34) | (k & (1ull << 33)) | (pos & ((1ull << 33) - 1ull));
+        atomicMax( &best[k >> 34], (unsigned long long)sel );
+    }
+}
+
 // opposite-mate window of a paired-end alignment: BestOppositeScoreStream::init_context
 // (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate (alignment_utils.h:52-88)
 __global__ void __launch_bounds__(256)
@@ -136,6 +154,18 @@ extern "C" nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* k
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipLaunchKernelGGL( diagonals_to_windows_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
                         keys_dev, n, band, read_len, genome_len, read_id_dev, flags_dev, win_begin_dev, win_end_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                    const uint32_t* win_begin_dev, uint64_t n, uint64_t* best_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && scores_dev && sinks_dev && win_begin_dev && best_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( best_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (unsigned long long*)best_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

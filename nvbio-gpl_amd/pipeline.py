@@ -81,7 +81,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     and best_g[int64 R], that candidate's locus (hit.loc: the diagonal clamped at the genome start), the
     anchor position of paired-end opposite-mate windows."""
     import torch
-    from . import diagonals_to_windows, hits_to_diagonals
+    from . import best_candidate_reduce, diagonals_to_windows
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
@@ -99,7 +99,6 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         if b is not None:
             b.record()
 
-
     # 1. seeds: infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernel
     #    (uniform_seeds_functor semantics; no offset array is materialised)
     qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
@@ -107,10 +106,11 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
     aligner = GotohAligner(params.aln_type, params.scheme)
+    top = torch.zeros((R,), dtype=torch.int64, device=dev)      # best selection key per read (0: no candidate)
 
     def extend(keys, tag):
-        """candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106) and
-        the banded Gotoh of every one of them; returns (read ids, selection keys)"""
+        """candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106), the banded Gotoh of
+        every one of them, and the per-read reduction of the selection keys into `top` (one atomic max per candidate)"""
         e = tick("windows" + tag)
         rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len)
         tock(e)
@@ -119,13 +119,15 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
                                flags=flags, device=dev, max_read_len=M)
         scores, sinks = BatchedBandedAlignmentScore(params.band, aligner).enact(batch)
         tock(e)
-        e = tick("pack" + tag)
+        e = tick("reduce")
+        best_candidate_reduce(keys, scores, sinks, wb, top)
+        tock(e)
+        if not return_windows:
+            return None
         rc = (keys >> 33) & 1
         pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
-        sel = pack_best_key(torch, scores, rc, pos)
-        tock(e)
-        g = torch.clamp((keys & ((1 << 33) - 1)) - 1024, min=0) if return_windows else None
-        return rid.to(torch.int64), sel, (wb if return_windows else None), g
+        g = torch.clamp((keys & ((1 << 33) - 1)) - 1024, min=0)
+        return rid.to(torch.int64), pack_best_key(torch, scores, rc, pos), wb, g
 
     use_direct = params.direct and fmi.supports_direct()
     results, n_cand = [], 0
@@ -152,15 +154,15 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         tock(e)
         if n_hits == 0:
             continue
-        # 3. SA rows -> text positions, tagged with their seed
+        # 3. + 4. SA rows -> text positions -> diagonal keys (hit_to_diagonal, examples/fmmap/fmmap.cu:92-117) in one
+        #    pass over the hits; consecutive seeds of a read that agree on the diagonal collapse to one candidate (hits
+        #    arrive in seed order, so an adjacent compare removes nearly all duplicates without a sort; a survivor only
+        #    costs a repeated extension)
         e = tick("locate")
-        hits = flt.locate(0, n_hits)
+        keys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand)
         tock(e)
-        # 4. hit -> diagonal (examples/fmmap/fmmap.cu:92-117); consecutive seeds of a read that agree on
-        #    the diagonal collapse to one candidate (hits arrive in seed order, so an adjacent compare
-        #    removes nearly all duplicates without a sort; a survivor only costs a repeated extension)
         e = tick("diagonals")
-        keys = torch.unique_consecutive(hits_to_diagonals(hits, spr, S_int, L, M, strand))
+        keys = torch.unique_consecutive(keys)
         if keys.numel() > 2 * R:
             # repeats: the seeds of a read list the same loci over and over, interleaved, so the adjacent compare misses
             # them; a sort-based unique costs far less than extending every copy (not taken on unique-ish genomes)
@@ -174,18 +176,15 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     best_score = torch.full((R,), SCORE_MIN, dtype=torch.int32, device=dev)
     best_pos = torch.full((R,), -1, dtype=torch.int64, device=dev)
     best_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
-    if not results:
+    if n_cand == 0:
         if return_windows:
             none = torch.full((R,), -1, dtype=torch.int64, device=dev)
             return best_score, best_pos, best_rc, 0, none, none.clone()
         return best_score, best_pos, best_rc, 0
 
-    # 5. best candidate per read
-    e = tick("reduce")
-    top = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    for rid, sel, _, _ in results:
-        top.scatter_reduce_(0, rid, sel, "amax", include_self=True)
-    has = top >= 0
+    # 5. best candidate per read (already reduced into `top` by extend)
+    e = tick("unpack")
+    has = top > 0
     sv = top >> 34
     best_score = torch.where(has & (sv > 0), (sv - SCORE_BIAS).to(torch.int32), best_score)
     best_pos = torch.where(has, top & ((1 << 33) - 1), best_pos)

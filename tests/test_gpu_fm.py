@@ -191,4 +191,24 @@ def test_seed_enumeration_and_diagonal_helpers(amd, orc, big):
         assert np.array_equal(amd.u32(we).astype(np.int64), np.minimum(wwb + 31 + M, G))
         assert np.array_equal(amd.u32(r).astype(np.int64), rid)
         assert (fl.cpu().numpy() == (3 if strand else 0)).all()
+    # the fused forms: filter expansion straight to diagonal keys; per-read best candidate by atomic max
+    for strand, flags in ((0, 0), (1, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT)):
+        flt = amd.FMIndexFilter()
+        total = flt.rank(fmi, enumerated, flags)
+        assert total > 0
+        keys = flt.locate_diagonals(0, total, spr, S, L, M, strand)
+        assert torch.equal(keys, amd.hits_to_diagonals(flt.locate(0, total), spr, S, L, M, strand))
+        b, e = total // 4, total // 4 + 777
+        assert torch.equal(flt.locate_diagonals(b, e, spr, S, L, M, strand), keys[b:e])
+    n = 20000
+    ck = torch.from_numpy(((rng.integers(0, 500, n).astype(np.int64) << 34) | (rng.integers(0, 2, n).astype(np.int64) << 33))).cuda()
+    sc_ = torch.from_numpy(rng.integers(-200, 300, n).astype(np.int32)).cuda()
+    sk_ = torch.from_numpy(rng.integers(0, 181, (n, 2)).astype(np.int32)).cuda()
+    wb_ = torch.from_numpy(rng.integers(0, 2 ** 31 - 200, n).astype(np.int32)).cuda()
+    best = amd.best_candidate_reduce(ck, sc_, sk_, wb_, torch.zeros(500, dtype=torch.int64, device="cuda:0")).cpu().numpy()
+    sel = ((sc_.cpu().numpy().astype(np.int64) + (1 << 20)) << 34) | (ck.cpu().numpy() & (1 << 33)) | \
+          (wb_.cpu().numpy().astype(np.int64) + sk_.cpu().numpy()[:, 0])
+    want = np.zeros(500, dtype=np.int64)
+    np.maximum.at(want, ck.cpu().numpy() >> 34, sel)
+    assert np.array_equal(best, want)
     fmi.close()
