@@ -168,19 +168,36 @@ public:
 
     FMIndexFilter() : m_index( nullptr ), m_n_queries( 0 ), m_n_occurrences( 0 ) {}
 
-    // enact the filter; returns the total number of hits (filter_inl.h:261-293)
-    uint64_t rank(const fm_index& index, const string_set& set, hipStream_t stream = 0)
+    // enact the filter; returns the total number of hits (filter_inl.h:261-293).
+    // allow_direct: let searches that collapse to one SA row finish on the text (nvbio_fm_match_direct) when the index
+    // holds the full SA and the text -- same hits from locate(), faster; ranges() then holds a text position, not an SA
+    // row, for the queries flagged in direct(), so leave it off if the caller reads ranges() itself.
+    uint64_t rank(const fm_index& index, const string_set& set, hipStream_t stream = 0, bool allow_direct = false)
     {
         m_index = &index; m_n_queries = set.size();
         m_ranges.resize( m_n_queries ); m_slots.resize( m_n_queries );
-        check( nvbio_fm_filter_rank( index.handle(), &set.c, 0u, m_ranges.data(), m_slots.data(), &m_n_occurrences, stream ) );
+        int can = 0;
+        if (allow_direct) check( nvbio_fm_index_supports_direct( index.handle(), &can ) );
+        m_is_direct = can != 0;
+        if (m_is_direct)
+        {
+            m_direct.resize( m_n_queries );
+            check( nvbio_fm_match_direct( index.handle(), &set.c, 0u, m_ranges.data(), m_direct.data(), stream ) );
+            check( nvbio_fm_filter_scan( index.handle(), m_ranges.data(), m_n_queries, m_slots.data(), &m_n_occurrences, stream ) );
+        }
+        else
+            check( nvbio_fm_filter_rank( index.handle(), &set.c, 0u, m_ranges.data(), m_slots.data(), &m_n_occurrences, stream ) );
         return m_n_occurrences;
     }
     // enumerate the hits [begin,end) into caller-owned device memory (filter_inl.h:299-393)
     void locate(uint64_t begin, uint64_t end, hit_type* hits_dev, hipStream_t stream = 0)
     {
-        check( nvbio_fm_filter_locate( m_index->handle(), m_ranges.data(), m_slots.data(), m_n_queries, begin, end, hits_dev, stream ) );
+        if (m_is_direct)
+            check( nvbio_fm_filter_locate_direct( m_index->handle(), m_ranges.data(), m_slots.data(), m_direct.data(), m_n_queries, begin, end, hits_dev, stream ) );
+        else
+            check( nvbio_fm_filter_locate( m_index->handle(), m_ranges.data(), m_slots.data(), m_n_queries, begin, end, hits_dev, stream ) );
     }
+    const uint8_t* direct() const { return m_is_direct ? m_direct.data() : nullptr; }
     uint32_t n_queries() const { return m_n_queries; }
     uint64_t n_hits()    const { return m_n_occurrences; }
     const range_type* ranges() const { return m_ranges.data(); }
@@ -191,6 +208,8 @@ private:
     uint64_t                   m_n_occurrences;
     device_vector<range_type>  m_ranges;
     device_vector<uint64_t>    m_slots;
+    device_vector<uint8_t>     m_direct;
+    bool                       m_is_direct = false;
 };
 
 namespace aln {

@@ -58,6 +58,19 @@ int main()
     orc_filter_locate( &oidx, want_ranges.data(), want_slots.data(), Q, 0, total, want_hits.data() );
     for (uint64_t h = 0; h < total; ++h) REQUIRE( hits[h].x == want_hits[2*h] && hits[h].y == want_hits[2*h+1] );
 
+    // the same filter on an index that holds the full SA and the text, allowed to finish single-row searches on the
+    // text (nvbio_fm_match_direct): identical hits
+    {
+        fm_index fmi1( d_text2.data(), n, 0, 8, 0, 1 );
+        FMIndexFilter<amd_device_tag> direct;
+        REQUIRE( direct.rank( fmi1, string_set::uniform( d_q.data(), 8, L, Q ), 0, true ) == want_total && direct.direct() != nullptr );
+        device_vector<nvbio_uint2> d_hits1( total );
+        direct.locate( 0, total, d_hits1.data() );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<nvbio_uint2> hits1 = d_hits1.to_host();
+        for (uint64_t h = 0; h < total; ++h) REQUIRE( hits1[h].x == want_hits[2*h] && hits1[h].y == want_hits[2*h+1] );
+    }
+
     // banded Gotoh through BatchedBandedAlignmentScore, SimpleGotohScheme, all three types
     const uint32_t J = 3000, M = 100;
     std::vector<uint8_t> pats( J * M ); std::vector<uint32_t> poffs( J + 1 ), wb( J ), we( J );
