@@ -415,6 +415,20 @@ def SimpleGotohScheme(match, mismatch, gap_open, gap_ext):
     return GotohScheme(match, -mismatch, -mismatch, gap_open, gap_ext, gap_open, gap_ext)
 
 
+def EditDistanceScheme():
+    """the scheme under which the Gotoh kernels compute the reference's edit-distance aligner: EditDistanceSWScheme
+    (match 0, mismatch -1, insertion = deletion = -1; nvbio/alignment/ed/ed_banded_inl.h:37-69 runs the banded
+    linear-gap SW with it), and with open = extension the affine recurrences give the same H in every cell -- pinned
+    against the reference in tests/golden/ed_golden.npz"""
+    return GotohScheme(0, 1, 1, -1, -1, -1, -1)
+
+
+def make_edit_distance_aligner(type):
+    """aln::make_edit_distance_aligner<TYPE>() (nvbio/alignment/alignment.h:382) for the BANDED scoring / traceback
+    entry points (the aligner of examples/fmmap/fmmap.cu:346-359 and of nvBowtie --scoring ed)"""
+    return GotohAligner(type, EditDistanceScheme())
+
+
 class GotohAligner:
     """aln::GotohAligner<TYPE, scheme> (nvbio/alignment/alignment.h:437-449)"""
 

@@ -243,6 +243,16 @@ struct GotohAligner
 template <AlignmentType T, typename scheme_type>
 GotohAligner<T,scheme_type> make_gotoh_aligner(const scheme_type& s) { return GotohAligner<T,scheme_type>( s ); }
 
+// the reference's edit-distance aligner on the banded entry points: EditDistanceSWScheme (match 0, mismatch -1,
+// insertion = deletion = -1; nvbio/alignment/ed/ed_banded_inl.h:37-69) -- with equal open and extension costs the
+// Gotoh recurrences give the same scores and sinks (pinned against the reference: tests/golden/ed_golden.npz)
+struct EditDistanceScheme
+{
+    nvbio_gotoh_scheme flat() const { const nvbio_gotoh_scheme s = { 0, 1, 1, -1, -1, -1, -1 }; return s; }
+};
+template <AlignmentType T>
+GotohAligner<T,EditDistanceScheme> make_edit_distance_aligner() { return GotohAligner<T,EditDistanceScheme>( EditDistanceScheme() ); }
+
 struct AmdDeviceScheduler {};
 
 // a stream of alignment jobs in flat form (see nvbio_alignment_batch)

@@ -37,6 +37,13 @@ def _c32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
 
 
+# the banded edit-distance aligner is the banded linear-gap Smith-Waterman with (match 0, mismatch -1, gap -1)
+# (ed/ed_banded_inl.h:37-69, EditDistanceSWScheme); with equal open and extension costs the Gotoh recurrences
+# produce the same H in every cell (F <= H and E <= H make "extend" never better than "open"), hence the same
+# scores and sinks -- checked against the reference in tests/test_oracle_vs_reference.py and pinned in ed_golden.npz
+ED_SCHEME = (0, 1, 1, -1, -1, -1, -1)
+
+
 def cigar_from_ops(ops, clip_before, clip_after):
     """nvBowtie's Backtracker (alignment_utils.h:115-157) over a recorded op string: run-length io::Cigar
     elements (type | len << 2) in backtracking order, soft clips only when non-zero"""
@@ -446,6 +453,15 @@ class Reference:
                                               _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
                                               ctypes.c_uint32(len(txt)), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc),
                                               _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_ed(self, band, typ, pat, txt):
+        """aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE> ) (ed/ed_banded_inl.h:37-69)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_banded_ed(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                    _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
     def banded_gotoh_traceback(self, band, typ, scheme, pat, txt, quals=None, cap=4096):

@@ -253,6 +253,34 @@ int full_type(int type, const scheme_type& scheme,
 
 } // anonymous namespace
 
+// banded edit distance: aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE>, ... ) (nvbio/alignment/ed/ed_banded_inl.h:37-69 ->
+// sw/sw_banded_inl.h:281-520 with EditDistanceSWScheme) -- the aligner of examples/fmmap/fmmap.cu:346-359 and of nvBowtie --scoring ed
+template <uint32 BAND, aln::AlignmentType TYPE>
+int banded_ed_run(const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::BestSink<int32> best;
+    const bool ok = aln::banded_alignment_score<BAND>(
+        aln::make_edit_distance_aligner<TYPE>(),
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        Field_traits<int32>::min(),
+        best );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+template <uint32 BAND>
+int banded_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return banded_ed_run<BAND,aln::GLOBAL>     ( pat, M, txt, N, score, sink );
+    case 1: return banded_ed_run<BAND,aln::LOCAL>      ( pat, M, txt, N, score, sink );
+    case 2: return banded_ed_run<BAND,aln::SEMI_GLOBAL>( pat, M, txt, N, score, sink );
+    }
+    return -1;
+}
 extern "C" {
 
 // Build an FM-index over text[0,n) (one 2-bit symbol per byte) exactly as
@@ -421,6 +449,18 @@ int ref_banded_gotoh_ex(uint32_t band, int type, const int32_t* sc,
     return quals ?
         banded_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
         banded_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+int ref_banded_ed(uint32_t band, int type, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t* score, uint32_t* sink)
+{
+    switch (band)
+    {
+    case 3:  return banded_ed_type<3> ( type, pat, M, txt, N, score, sink );
+    case 7:  return banded_ed_type<7> ( type, pat, M, txt, N, score, sink );
+    case 15: return banded_ed_type<15>( type, pat, M, txt, N, score, sink );
+    case 31: return banded_ed_type<31>( type, pat, M, txt, N, score, sink );
+    }
+    return -1;
 }
 
 // banded traceback through the reference (M <= 1024).  ops: one byte per op in BACKTRACKING order

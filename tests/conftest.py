@@ -57,6 +57,11 @@ def dp_golden():
 
 
 @pytest.fixture(scope="session")
+def ed_golden():
+    return np.load(os.path.join(GOLDEN, "ed_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def tb_golden():
     return np.load(os.path.join(GOLDEN, "tb_golden.npz"), allow_pickle=False)
 

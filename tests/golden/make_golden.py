@@ -15,6 +15,7 @@ Fixtures:
                   random pairs (substitutions, indels, N's, qualities, clipped windows, N < M),
                   each scored by the reference with banded Gotoh (bands 3/7/15/31 x 3 types) and
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
+  ed_golden.npz   the same pairs scored by the reference's banded edit-distance aligner.
   tb_golden.npz   the same pairs traced back by the reference (banded_alignment_traceback, bands
                   3/7/15/31 x 3 types): score, source, sink and the run-length CIGAR.
 """
@@ -233,6 +234,27 @@ def make_tb(R):
     print("tb_golden.npz: %d pairs, %d cigar elements" % (n, pos))
 
 
+def make_ed(R):
+    """ed_golden.npz: the reference's banded edit-distance aligner (EditDistanceAligner<TYPE>, the aligner of
+    examples/fmmap and of nvBowtie --scoring ed) on every pair of dp_golden.npz, bands 3/7/15/31 x 3 types"""
+    g = np.load(os.path.join(HERE, "dp_golden.npz"))
+    n = len(g["pat_off"]) - 1
+    bands = [int(b) for b in g["bands"]]
+    ed = np.zeros((n, len(bands), 3, 4), dtype=np.int64)          # ok, score, sink.x, sink.y  (ok = -1: not pinned)
+    for i in range(n):
+        pat = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+        txt = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+        for bi, b in enumerate(bands):
+            for typ in range(3):
+                if len(txt) < b - 1:
+                    ed[i, bi, typ, 0] = -1
+                    continue
+                ok, s_, sk = R.banded_ed(b, typ, pat, np.concatenate([txt, np.full(64, 255, dtype=np.uint8)])[:len(txt)])
+                ed[i, bi, typ] = (ok, s_, np.int64(np.int32(np.uint32(sk[0]))), np.int64(np.int32(np.uint32(sk[1]))))
+    np.savez_compressed(os.path.join(HERE, "ed_golden.npz"), ed=ed, bands=np.array(bands))
+    print("ed_golden.npz: %d pairs" % n)
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -240,3 +262,4 @@ if __name__ == "__main__":
     make_fm(R)
     make_dp(R)
     make_tb(R)
+    make_ed(R)

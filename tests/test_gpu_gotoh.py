@@ -166,3 +166,22 @@ def test_packed_band31_kernel_equals_int32_and_oracle(amd, orc, typ):
     wsc, wsk = orc.banded_gotoh_packed_batch(31, typ, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text),
                                              wb[sel], we[sel], read_id=rid[sel], flags=flags[sel])
     assert np.array_equal(sc.cpu().numpy(), wsc) and np.array_equal(amd.u32(sk), wsk)
+
+
+def test_banded_edit_distance_golden(amd, dp_golden, ed_golden):
+    """make_edit_distance_aligner through the banded kernels == the reference's EditDistanceAligner (fmmap, nvBowtie
+    --scoring ed), every band and type, on the reference's own outputs"""
+    g, e = dp_golden, ed_golden
+    n = len(g["pat_off"]) - 1
+    cases = np.arange(n, dtype=np.uint32)
+    batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1], read_id=cases)
+    checked = 0
+    for bi, band in enumerate(e["bands"]):
+        for typ in range(3):
+            sc, sk = amd.batch_banded_alignment_score(int(band), amd.make_edit_distance_aligner(typ), batch)
+            sc, sk = sc.cpu().numpy().astype(np.int64), sk.cpu().numpy().astype(np.int64)
+            want = e["ed"][:, bi, typ]
+            pin = want[:, 0] >= 0
+            assert np.array_equal(sc[pin], want[pin, 1]) and np.array_equal(sk[pin], want[pin, 2:4]), (band, typ)
+            checked += int(pin.sum())
+    assert checked > 4000

@@ -200,6 +200,31 @@ def test_banded_traceback_golden(orc, dp_golden, tb_golden):
     assert oracle.cigar_string(r[4]) == "147M2D3M" and r[1] == -11 and r[2] == (13, 0) and r[3] == (165, 150)
 
 
+def test_banded_edit_distance_golden(orc, dp_golden, ed_golden):
+    """the reference's banded edit-distance aligner (fmmap's, nvBowtie --scoring ed) == banded Gotoh with
+    (match 0, mismatch -1, open = extension = -1): equal open and extension costs make the recurrences coincide"""
+    g, e = dp_golden, ed_golden
+    sc = oracle.Scheme(*oracle.ED_SCHEME)
+    checked = 0
+    for i in range(len(g["pat_off"]) - 1):
+        p, t, _ = _case(g, i)
+        for bi, b in enumerate(e["bands"]):
+            for typ in range(3):
+                want = e["ed"][i, bi, typ]
+                if want[0] < 0:
+                    continue
+                ok, s, sk = orc.banded_gotoh(int(b), typ, sc, p, t)
+                assert (ok, s, np.int64(np.int32(np.uint32(sk[0]))), np.int64(np.int32(np.uint32(sk[1])))) == tuple(int(v) for v in want), (i, b, typ)
+                checked += 1
+    assert checked > 4000
+    # the reference's functional tests (alignment_test.cu:643-705): edit distances 0, -2, -2, 0, -2, -2
+    def enc(x):
+        return np.array(["ACGT".index(c) for c in x], dtype=np.uint8)
+    for pat, txt, want in (("GGGTGCTCAA", "AAAAGGGTGCTCAA", 0), ("GGGTAAGCTC", "AAAAGGGTGCTCAA", -2), ("AAGGGTGCTC", "AAAAGGGTGCAATC", -2),
+                           ("AAAAGGGTGC", "AAAAGGGTGCTCAA", 0), ("AAAAGGGTG", "AAAAGGAAGTGCTC", -2), ("CACCGGGT", "AACAGGGTGCTC", -2)):
+        assert orc.banded_gotoh(7, oracle.SEMI_GLOBAL, sc, enc(pat), enc(txt))[1] == want
+
+
 def test_full_gotoh_golden(orc, dp_golden):
     g = dp_golden
     S = len(g["schemes"])

@@ -61,6 +61,8 @@ def test_gotoh_fuzz(orc, ref):
         sc = SCHEMES[it % len(SCHEMES)]
         for typ in range(3):
             assert ref.banded_gotoh(band, typ, sc, pat, txt, quals) == orc.banded_gotoh(band, typ, sc, pat, txt, quals)
+            if quals is None:   # edit distance == Gotoh(0, -1, -1, -1) (ed/ed_banded_inl.h:37-69 -> sw/sw_banded_inl.h)
+                assert ref.banded_ed(band, typ, pat, txt) == orc.banded_gotoh(band, typ, oracle.Scheme(*oracle.ED_SCHEME), pat, txt)
             # traceback: Alignment {score, source, sink}, the op string and the clips (banded_inl.h:354-417)
             r, rs, rsrc, rsnk, rops, rclips = ref.banded_gotoh_traceback(band, typ, sc, pat, txt, quals)
             ok, s, src, snk, cig, ops = orc.banded_gotoh_traceback(band, typ, sc, pat, txt, quals)
