@@ -49,7 +49,7 @@ def test_pipeline_seed_hit_cap_on_repeats(amd, orc):
     fmi.close()
 
 
-@pytest.mark.parametrize("mode", ["local", "e2e"])
+@pytest.mark.parametrize("mode", ["local", "e2e", "fmmap-ed"])
 def test_pipeline_equals_cpu_path(amd, orc, mode):
     import torch
     pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
@@ -73,6 +73,10 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     if mode == "local":
         params = pipeline.SeedExtendParams()
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, traceback_stride=24)
+    elif mode == "fmmap-ed":                              # examples/fmmap: semi-global edit distance (fmmap.cu:346-359)
+        params = pipeline.SeedExtendParams(aln_type=oracle.SEMI_GLOBAL, scheme=amd.EditDistanceScheme(), min_score=-15)
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
+                                                scheme=oracle.Scheme(*oracle.ED_SCHEME), traceback_stride=24)
     else:                                                 # nvBowtie default mode, constant quality
         params = pipeline.SeedExtendParams.end_to_end()
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
