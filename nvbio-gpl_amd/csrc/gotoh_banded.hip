@@ -481,8 +481,8 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
 // ---------------------------------------------------------------------------------------------
 template <int RBITS>
 __global__ void __launch_bounds__(256)
-ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
-                      uint8_t* __restrict__ need_dp)
+ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
+                      int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= b.n) return;
@@ -637,6 +637,9 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, int32_
         qh[2*k] = (uint32_t)thi[k]; qh[2*k+1] = (uint32_t)(thi[k] >> 32);
     }
     ql[6] = (uint32_t)tlo[3]; qh[6] = (uint32_t)thi[3];
+    uint32_t ql0[7], qh0[7];
+    #pragma unroll
+    for (int k = 0; k < 7; ++k) { ql0[k] = ql[k]; qh0[k] = qh[k]; }
 
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
     for (uint32_t d = 0; d < 31u; ++d)
@@ -659,7 +662,63 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, int32_
         ql[6] >>= 1; qh[6] >>= 1;
     }
     const int64_t U = -(int64_t)P * (int64_t)best_cnt;
-    if (U > (int64_t)G)
+    bool settled = U > (int64_t)G;
+    if (!settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u)
+    {
+        // Second chance (two mismatches at nvBowtie's -6 / -8 / -3).  U* <= G, but one gap plus one mismatch and two gaps
+        // both score below U*: the only gapped alignments that could reach U* have exactly ONE gap and NO mismatch, i.e. a
+        // prefix of the read matching one diagonal exactly and the rest matching a diagonal g columns away, for the few gap
+        // lengths g with open + (g-1) ext >= U*.  With lead_d / tail_d = the exactly matching prefix / suffix lengths of
+        // diagonal d, a text gap (d-g -> d) exists iff lead_{d-g} + tail_d >= M, a pattern gap (d -> d-g) iff
+        // lead_d + tail_{d-g} + g >= M.  If none exists the optimum is U* and only ungapped diagonals reach it.
+        // (N >= M + 30: all 31 diagonals lie inside the text, so no sentinel cell is involved.)
+        int32_t gmax = 0;
+        while (gmax < 5 && (int64_t)gap_open + (int64_t)gmax * gap_ext >= U) ++gmax;      // lengths 1..gmax can reach U*
+        if (gmax >= 1 && gmax <= 4)
+        {
+            #pragma unroll
+            for (int k = 0; k < 7; ++k) { ql[k] = ql0[k]; qh[k] = qh0[k]; }
+            uint32_t lead_prev[4] = { 0, 0, 0, 0 }, tail_prev[4] = { 0, 0, 0, 0 };        // diagonals d-1 .. d-4
+            bool gapped = false;
+            for (uint32_t d = 0; d < 31u && !gapped; ++d)
+            {
+                uint32_t first = M, last = 0xFFFFFFFFu;
+                #pragma unroll
+                for (int k = 5; k >= 0; --k)
+                {
+                    const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                    if (mm) first = 32u * k + (uint32_t)__builtin_ctz( mm );
+                }
+                #pragma unroll
+                for (int k = 0; k < 6; ++k)
+                {
+                    const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                    if (mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
+                }
+                const uint32_t lead = first;                                               // rows 0..lead-1 match
+                const uint32_t tail = (last == 0xFFFFFFFFu) ? M : M - 1u - last;           // the last `tail` rows match
+                #pragma unroll
+                for (int g = 1; g <= 4; ++g)
+                    if (g <= gmax && d >= (uint32_t)g)
+                    {
+                        if (lead_prev[g - 1] + tail >= M) gapped = true;                   // text gap of g: diagonal d-g, then d
+                        if (lead + tail_prev[g - 1] + (uint32_t)g >= M) gapped = true;     // pattern gap of g: diagonal d, then d-g
+                    }
+                #pragma unroll
+                for (int k = 3; k > 0; --k) { lead_prev[k] = lead_prev[k - 1]; tail_prev[k] = tail_prev[k - 1]; }
+                lead_prev[0] = lead; tail_prev[0] = tail;
+                #pragma unroll
+                for (int k = 0; k < 6; ++k)
+                {
+                    ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                    qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+                }
+                ql[6] >>= 1; qh[6] >>= 1;
+            }
+            settled = !gapped;
+        }
+    }
+    if (settled)
     {
         scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
     }
@@ -720,7 +779,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         uint32_t* job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
         uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
         void*     sel_temp  = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
-        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, scores, sinks, need_dp );
+        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp );
         const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
             hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,

@@ -185,3 +185,53 @@ def test_banded_edit_distance_golden(amd, dp_golden, ed_golden):
             assert np.array_equal(sc[pin], want[pin, 1]) and np.array_equal(sk[pin], want[pin, 2:4]), (band, typ)
             checked += int(pin.sum())
     assert checked > 4000
+
+
+def test_end_to_end_shortcut_edge_cases(amd, orc):
+    """the ungapped shortcut and its second chance (U* <= G but only single-gap, mismatch-free alignments could reach
+    it): reads with 0-3 substitutions, and reads whose only difference is a 1-4 bp indel a few bases from either end --
+    there the ungapped diagonal has two or three mismatches while a gapped alignment scores higher, so the DP must be
+    taken -- under several schemes (different admissible gap lengths), windows at full width and clipped"""
+    rng = np.random.default_rng(91)
+    G = 400000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    text[5000:5300] = np.tile(text[5000:5003], 100)                 # period-3 repeat: shifted diagonals match too
+    M = 150
+    reads, g_pos = [], []
+    def locus():
+        return int(rng.integers(100, G - 400))
+    for k in range(4):                                              # substitutions only
+        for _ in range(300):
+            p = locus(); r = text[p:p + M].copy()
+            pos = rng.choice(M, k, replace=False)
+            r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+            reads.append(r); g_pos.append(p)
+    for _ in range(1500):                                           # one indel near an end, nothing else
+        p = locus(); g = int(rng.integers(1, 5)); e = int(rng.integers(1, 7))
+        at = e if rng.random() < 0.5 else M - e
+        src = text[p:p + M + 8].copy()
+        if rng.random() < 0.5:
+            r = np.concatenate([src[:at], src[at + g:]])[:M]        # deletion from the read
+        else:
+            r = np.concatenate([src[:at], rng.integers(0, 4, g, dtype=np.uint8), src[at:]])[:M]
+        reads.append(r.astype(np.uint8)); g_pos.append(p)
+    for _ in range(300):                                            # inside the repeat
+        p = int(rng.integers(5000, 5100)); r = text[p:p + M].copy()
+        k = int(rng.integers(0, 3)); pos = rng.choice(M, k, replace=False); r[pos] = (r[pos] + 1) % 4
+        reads.append(r); g_pos.append(p)
+    R = len(reads)
+    flat = np.concatenate(reads)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    g_pos = np.array(g_pos, dtype=np.int64) + rng.integers(-3, 4, R)
+    wb = (g_pos - 15).astype(np.uint32)
+    we = (wb + 31 + M).astype(np.uint32)
+    we[::17] -= rng.integers(1, 25, len(we[::17])).astype(np.uint32)    # clipped windows (N < M + 30)
+    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 2, 2, -5, -1, -5, -1), (0, 4, 4, -6, -6, -6, -6), (0, 3, 3, -3, -3, -9, -1)):
+        wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we)
+        batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M)
+        sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+        bad = np.nonzero(sc.cpu().numpy() != wsc)[0]
+        assert len(bad) == 0, (sv, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]])
+        assert np.array_equal(amd.u32(sk), wsk), sv
+    # the indel reads really are cases where a gapped alignment beats a 2-3 mismatch diagonal
+    assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
