@@ -231,7 +231,8 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 // ---------------------------------------------------------------------------------------------
 template <int RBITS>
 __global__ void __launch_bounds__(256)
-ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t* __restrict__ min_scores, const bool text_blocking,
+ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext, const bool second_chance,
+                         const int32_t* __restrict__ min_scores, const bool text_blocking,
                          int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,7 +386,73 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     const int64_t U = -(int64_t)P * (int64_t)best_cnt;
     const int32_t min_score = min_scores ? min_scores[job] : NVBIO_SCORE_MIN;
     const bool exit_silent = text_blocking ? ((int64_t)min_score <= -(int64_t)P) : (U >= (int64_t)min_score);
-    if (U > (int64_t)G && U >= (int64_t)min_score && exit_silent)
+    bool settled = U > (int64_t)G;
+    if (!settled && second_chance && (int64_t)G - P < U && 2 * (int64_t)G < U && U >= (int64_t)min_score && exit_silent)
+    {
+        // Second chance, as in ungapped_e2e31_kernel: one gap plus one mismatch and two gaps score below U*, so only
+        // single-gap, mismatch-free alignments could reach it: text gap (diagonal d-g then d) iff lead_{d-g} + tail_d >= M,
+        // pattern gap (d then d-g) iff lead_d + tail_{d-g} + g >= M, for the gap lengths g with open + (g-1) ext >= U*.
+        // The matrix has no band, so a pattern gap may also sit at the very start or end of the read: tail_d + g >= M or
+        // lead_d + g >= M on any diagonal.  (second_chance requires equal pattern / text gap costs: the boundary
+        // rows and columns charge one or the other depending on the blocking.)
+        int32_t gmax = 0;
+        while (gmax < 5 && (int64_t)gap_open + (int64_t)gmax * gap_ext >= U) ++gmax;
+        if (gmax >= 1 && gmax <= 4)
+        {
+            uint32_t lead_prev[4] = { 0, 0, 0, 0 }, tail_prev[4] = { 0, 0, 0, 0 };
+            bool gapped = false;
+            #pragma unroll
+            for (int wo = 0; wo < 17; ++wo)
+            {
+                if ((uint32_t)wo * 32u > last_d || gapped) break;
+                uint32_t ql[7], qh[7];
+                #pragma unroll
+                for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 18) ? tl[wo + k] : 0u; qh[k] = (wo + k < 18) ? th[wo + k] : 0u; }
+                const uint32_t d_end = ((uint32_t)wo * 32u + 31u < last_d) ? (uint32_t)wo * 32u + 31u : last_d;
+                for (uint32_t d = (uint32_t)wo * 32u; d <= d_end && !gapped; ++d)
+                {
+                    uint32_t first = M, last = 0xFFFFFFFFu;
+                    #pragma unroll
+                    for (int k = 5; k >= 0; --k)
+                    {
+                        const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                        if (mm) first = 32u * k + (uint32_t)__builtin_ctz( mm );
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                    {
+                        const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                        if (mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
+                    }
+                    const uint32_t lead = first;
+                    const uint32_t tail = (last == 0xFFFFFFFFu) ? M : M - 1u - last;
+                    #pragma unroll
+                    for (int g = 1; g <= 4; ++g)
+                        if (g <= gmax)
+                        {
+                            if (lead + (uint32_t)g >= M || tail + (uint32_t)g >= M) gapped = true;      // pattern gap at an end of the read
+                            if (d >= (uint32_t)g)
+                            {
+                                if (lead_prev[g - 1] + tail >= M) gapped = true;
+                                if (lead + tail_prev[g - 1] + (uint32_t)g >= M) gapped = true;
+                            }
+                        }
+                    #pragma unroll
+                    for (int k = 3; k > 0; --k) { lead_prev[k] = lead_prev[k - 1]; tail_prev[k] = tail_prev[k - 1]; }
+                    lead_prev[0] = lead; tail_prev[0] = tail;
+                    #pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                    {
+                        ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                        qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+                    }
+                    ql[6] >>= 1; qh[6] >>= 1;
+                }
+            }
+            settled = !gapped;
+        }
+    }
+    if (settled && U >= (int64_t)min_score && exit_silent)
     {
         scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
     }
@@ -711,8 +778,9 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
         if (shortcut)
         {
             const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
-            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
-            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
+            const bool second_chance = (sc.pat_go == sc.txt_go && sc.pat_ge == sc.txt_ge);
+            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
+            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
         }
         hipError_t e = hipSuccess;
         if (packed)

@@ -124,6 +124,13 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
             c = int(rng.integers(5, lens[j] - 5)); g = int(rng.integers(1, 4))
             r = np.concatenate([r[:c], r[c + g:], rng.integers(0, 4, g, dtype=np.uint8)]) if j % 2 else \
                 np.concatenate([r[:c], rng.integers(0, 4, g, dtype=np.uint8), r[c:lens[j] - g]])
+        if j % 5 == 3:
+            # the only difference is a 1-4 bp indel a few bases from an end: the best diagonal has 2-3 mismatches but
+            # a single-gap alignment scores higher -- the shortcut's second chance must hand these to the DP
+            r = text[p:p + lens[j]].copy(); src = text[p:p + lens[j] + 8]
+            g = int(rng.integers(1, 5)); e = int(rng.integers(1, 7)); at = e if rng.random() < 0.5 else lens[j] - e
+            r = np.concatenate([src[:at], src[at + g:]])[:lens[j]] if rng.random() < 0.5 else \
+                np.concatenate([src[:at], rng.integers(0, 4, g, dtype=np.uint8), src[at:]])[:lens[j]]
         if j % 29 == 0:
             r[int(rng.integers(0, lens[j]))] = 4
         reads.append(r.astype(np.uint8))
