@@ -296,6 +296,19 @@ class Oracle:
             _p(sinks, _u32p), cigars.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cigar_stride), _p(lens, _u32p))
         return scores, sources, sinks, cigars, lens
 
+    def full_gotoh_traceback(self, typ, scheme, pat, txt, quals=None, min_score=SCORE_MIN, cap=4096):
+        """-> (traced, score, source, sink, cigar uint16[]) -- x = text, y = pattern; cigar in backtracking order"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        cig = np.zeros(cap, dtype=np.uint16); cl = ctypes.c_uint32()
+        ok = self.lib.orc_full_gotoh_traceback(
+            ctypes.c_int(typ), ctypes.byref(scheme), _p(pat, _u8p), _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+            ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p),
+            cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap), ctypes.byref(cl))
+        assert cl.value <= cap
+        return ok, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), cig[:cl.value].copy()
+
     def full_gotoh(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN):
         pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
         sc = ctypes.c_int32()
@@ -484,6 +497,22 @@ class Reference:
             ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(n_txt), ctypes.c_int32(SCORE_MIN),
             ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p), _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no),
             _p(clips, _u32p))
+        assert no.value <= cap
+        return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
+
+    def full_gotoh_traceback(self, typ, scheme, pat, txt, quals=None, min_score=SCORE_MIN, cap=8192):
+        """the reference's alignment_traceback<256,1024,64> with a recording backtracer
+        -> (n_clip_calls, score, source, sink, ops uint8[] in backtracking order, (clip_before, clip_after))"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        arr = scheme.as_array()
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        ops = np.zeros(cap, dtype=np.uint8); clips = np.zeros(2, dtype=np.uint32)
+        no = ctypes.c_uint32()
+        r = self.lib.ref_full_gotoh_traceback_ex(
+            ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p), _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+            ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p), _p(ops, _u8p),
+            ctypes.c_uint32(cap), ctypes.byref(no), _p(clips, _u32p))
         assert no.value <= cap
         return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
 

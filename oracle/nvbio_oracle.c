@@ -700,9 +700,11 @@ static int full_text_blocking(int type, const orc_gotoh_scheme* sc,
 }
 
 /* pattern blocking (:444-841): stripes over the pattern, a column of short2 over the text */
+/* dirs (optional, N*M bytes, row = text position): each cell's direction vector hdir | edir | fdir as
+ * GotohSubmatrixContext::new_cell stores it (gotoh_inl.h:423-436; rules :503-538) */
 static int full_pattern_blocking(int type, const orc_gotoh_scheme* sc,
                                  const uint8_t* pat, const uint8_t* quals, uint32_t M,
-                                 const uint8_t* txt, uint32_t N, int32_t min_score, best_sink* sink)
+                                 const uint8_t* txt, uint32_t N, int32_t min_score, best_sink* sink, uint8_t* dirs)
 {
     const int32_t G_o = sc->pat_gap_open, G_e = sc->pat_gap_ext;
     const int32_t infimum = -32768 - imin( G_o, G_e );
@@ -743,11 +745,21 @@ static int full_pattern_blocking(int type, const orc_gotoh_scheme* sc,
             int32_t E = ty[i];
             for (uint32_t j = 1; j <= STRIPE; ++j)
             {
-                F[j] = imax( F[j] + G_e, H[j] + G_o );
-                E    = imax( E + G_e, H[j-1] + G_o );
+                const int32_t ftop = F[j] + G_e, htop = H[j] + G_o;
+                F[j] = imax( ftop, htop );
+                const int32_t eleft = E + G_e, hleft = H[j-1] + G_o;
+                E    = imax( eleft, hleft );
                 const int32_t d  = H_diag + ((r_i == q_sym[j-1]) ? sc->match : orc_mismatch( sc, q_qual[j-1] ));
                 int32_t       hi = imax( imax( E, F[j] ), d );
                 if (type == ORC_LOCAL) hi = imax( hi, 0 );
+                if (dirs && block + j <= M)
+                {
+                    /* SUBSTITUTION 0, INSERTION 1 (from E), DELETION 2 (from F), SINK 3, INSERTION_EXT 4, DELETION_EXT 8 */
+                    const int32_t top = F[j], left = E;
+                    uint8_t hdir = top > left ? (top > d ? 2u : 0u) : (left > d ? 1u : 0u);
+                    if (type == ORC_LOCAL && hi == 0) hdir = 3u;
+                    dirs[(size_t)i * M + (block + j - 1u)] = (uint8_t)(hdir | (eleft > hleft ? 4u : 0u) | (ftop > htop ? 8u : 0u));
+                }
                 H_diag = H[j];
                 H[j]   = hi;
             }
@@ -785,9 +797,64 @@ int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* sc,
     best_sink sink; sink_init( &sink );
     const int ok = blocking ?
         full_text_blocking(    type, sc, pat, quals, M, txt, N, min_score, &sink ) :
-        full_pattern_blocking( type, sc, pat, quals, M, txt, N, min_score, &sink );
+        full_pattern_blocking( type, sc, pat, quals, M, txt, N, min_score, &sink, 0 );
     *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
     return ok;
+}
+
+/* full-matrix traceback: aln::alignment_traceback (nvbio/alignment/alignment_inl.h:355-455): pattern-blocking score
+ * pass, clip(pattern_len - sink.y), the walk of priv::alignment_traceback (gotoh/gotoh_inl.h:1573-1640) over the
+ * direction vectors, the implicit first row / column (:437-452), clip(source.y) -- delivered to nvBowtie's
+ * run-length Backtracker as in orc_banded_gotoh_traceback (INSERTION = pattern symbol without text, DELETION = text
+ * symbol without pattern).  Coordinates: x = text, y = pattern.  The reference recomputes 64-column blocks from int16
+ * checkpoints; equal to the single pass here while every score fits int16. */
+int orc_full_gotoh_traceback(int type, const orc_gotoh_scheme* sc,
+                             const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                             const uint8_t* txt, uint32_t N, int32_t min_score,
+                             int32_t* score, uint32_t source[2], uint32_t sink_out[2],
+                             uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len)
+{
+    best_sink best; sink_init( &best );
+    uint8_t* dirs = (uint8_t*)malloc( (size_t)(N ? N : 1) * (M ? M : 1) );
+    full_pattern_blocking( type, sc, pat, quals, M, txt, N, min_score, &best, dirs );
+    *score = best.score; sink_out[0] = sink_out[1] = source[0] = source[1] = 0xFFFFFFFFu; *cigar_len = 0;
+    if (best.x == 0xFFFFFFFFu || best.y == 0xFFFFFFFFu) { free( dirs ); return 0; }
+    sink_out[0] = best.x; sink_out[1] = best.y;
+
+    uint32_t clen = 0; int prev = 255;
+#define CIG_PUSH(type_, len_) do { if (clen < cigar_cap) cigar[clen] = (uint16_t)((type_) | ((len_) << 2)); ++clen; } while (0)
+#define OP_PUSH(op_) do { if (prev == (int)(op_)) { if (clen - 1 < cigar_cap) cigar[clen-1] += 4; } else { CIG_PUSH( op_, 1u ); prev = (int)(op_); } } while (0)
+    if (M - best.y) CIG_PUSH( 3u, M - best.y );
+    int32_t row = (int32_t)best.x, col = (int32_t)best.y - 1;
+    int state = 0;                                                          /* HSTATE 0, ESTATE 1, FSTATE 2 */
+    int found = 0;
+    while (row > 0 && col >= 0)
+    {
+        const uint8_t op = dirs[(size_t)(row - 1) * M + col];
+        const uint8_t h_op = op & 3u;
+        if (type == ORC_LOCAL && state == 0 && h_op == 3u) { found = 1; break; }
+        if (state == 1)      { if ((op & 4u) == 0) state = 0; --col; OP_PUSH( 1u ); }          /* E: INSERTION */
+        else if (state == 2) { if ((op & 8u) == 0) state = 0; --row; OP_PUSH( 2u ); }          /* F: DELETION  */
+        else
+        {
+            if (h_op == 1u) state = 1;
+            else if (h_op == 2u) state = 2;
+            else { --col; --row; OP_PUSH( 0u ); }
+        }
+    }
+    (void)found;
+    uint32_t sx = (uint32_t)row, sy = (uint32_t)(col + 1);
+    if (type == ORC_SEMI_GLOBAL || type == ORC_GLOBAL)                       /* the implicit first row (alignment_inl.h:437-445) */
+        if (sx == 0) for (; sy > 0; --sy) OP_PUSH( 1u );
+    if (type == ORC_GLOBAL)                                                  /* ... and first column (:446-452) */
+        if (sy == 0) for (; sx > 0; --sx) OP_PUSH( 2u );
+    if (sy) CIG_PUSH( 3u, sy );
+#undef OP_PUSH
+#undef CIG_PUSH
+    source[0] = sx; source[1] = sy;
+    *cigar_len = clen;
+    free( dirs );
+    return 1;
 }
 
 void orc_banded_gotoh_batch(uint32_t band, int type, const orc_gotoh_scheme* s,

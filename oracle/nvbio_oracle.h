@@ -148,6 +148,15 @@ void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_
                                    uint32_t n, int32_t* scores, uint32_t* sources, uint32_t* sinks,
                                    uint16_t* cigars, uint32_t cigar_stride, uint32_t* cigar_lens);
 
+/* full-matrix Gotoh traceback: aln::alignment_traceback (nvbio/alignment/alignment_inl.h:355-455, walk
+ * gotoh/gotoh_inl.h:1573-1640) through nvBowtie's run-length Backtracker; x = text, y = pattern; cigar as in
+ * orc_banded_gotoh_traceback.  Returns 1 if an alignment was traced, 0 if nothing was reported. */
+int orc_full_gotoh_traceback(int type, const orc_gotoh_scheme* s,
+                             const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                             const uint8_t* txt, uint32_t N, int32_t min_score,
+                             int32_t* score, uint32_t source[2], uint32_t sink[2],
+                             uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len);
+
 /* full-matrix Gotoh, 8-column stripes with an int16 (short2) boundary column
  * (gotoh_inl.h:444-841 pattern blocking, :847-1256 text blocking; alignment_score_dispatch :1283-1330).
  * blocking: 0 = PatternBlockingTag (alignment_score default), 1 = TextBlockingTag (sw-benchmark).

@@ -281,6 +281,39 @@ int banded_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint3
     }
     return -1;
 }
+
+// aln::alignment_traceback<MAX_PATTERN_LEN,MAX_TEXT_LEN,CHECKPOINTS> (nvbio/alignment/alignment_inl.h:478-517 -> :355-455 ->
+// gotoh/gotoh_inl.h:1573-1640); CHECKPOINTS = 64 as nvBowtie (FULL_DP_CHECKPOINTS, defs.h:96); M <= 256, N <= 1024
+template <aln::AlignmentType TYPE, typename scheme_type, typename qual_type>
+int full_tb_run(const scheme_type& scheme,
+                const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    typedef vector_view<const uint8*> string_type;
+    const aln::Alignment<int32> a = aln::alignment_traceback<256u,1024u,64u>(
+        aln::make_gotoh_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        quals,
+        string_type( N, txt ),
+        min_score,
+        bt );
+    *score = a.score; source[0] = a.source.x; source[1] = a.source.y; sink[0] = a.sink.x; sink[1] = a.sink.y;
+    return (int)bt.n_clips;
+}
+template <typename scheme_type, typename qual_type>
+int full_tb_type(int type, const scheme_type& scheme,
+                 const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                 int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    switch (type)
+    {
+    case 0: return full_tb_run<aln::GLOBAL>     ( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 1: return full_tb_run<aln::LOCAL>      ( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    case 2: return full_tb_run<aln::SEMI_GLOBAL>( scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt );
+    }
+    return -1;
+}
+
 extern "C" {
 
 // Build an FM-index over text[0,n) (one 2-bit symbol per byte) exactly as
@@ -479,6 +512,23 @@ int ref_banded_gotoh_traceback_ex(uint32_t band, int type, const int32_t* sc,
     const int r = quals ?
         banded_tb_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt ) :
         banded_tb_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, source, sink, bt );
+    *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
+    return r;
+}
+
+// full-matrix traceback through the reference (M <= 256, N <= 1024); outputs as ref_banded_gotoh_traceback_ex
+int ref_full_gotoh_traceback_ex(int type, const int32_t* sc,
+                                const uint8_t* pat, const uint8_t* quals, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                                int32_t* score, uint32_t* source, uint32_t* sink,
+                                uint8_t* ops, uint32_t cap, uint32_t* n_ops, uint32_t* clips)
+{
+    if (M > 256u || N > 1024u) return -1;
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    RecordingBacktracer bt; bt.ops = ops; bt.cap = cap; bt.n = 0; bt.n_clips = 0; bt.clips[0] = bt.clips[1] = 0;
+    const int r = quals ?
+        full_tb_type( type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt ) :
+        full_tb_type( type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, source, sink, bt );
     *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
     return r;
 }

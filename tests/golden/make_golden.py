@@ -16,6 +16,7 @@ Fixtures:
                   each scored by the reference with banded Gotoh (bands 3/7/15/31 x 3 types) and
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
   ed_golden.npz   the same pairs scored by the reference's banded edit-distance aligner.
+  ftb_golden.npz  the same pairs traced back through the full matrix (alignment_traceback).
   tb_golden.npz   the same pairs traced back by the reference (banded_alignment_traceback, bands
                   3/7/15/31 x 3 types): score, source, sink and the run-length CIGAR.
 """
@@ -234,6 +235,36 @@ def make_tb(R):
     print("tb_golden.npz: %d pairs, %d cigar elements" % (n, pos))
 
 
+def make_ftb(R):
+    """ftb_golden.npz: the reference's full-matrix alignment_traceback<256,1024,64> on every pair of dp_golden.npz,
+    3 types x {no, finite} min_score (scheme = case % S; known-answer pairs under their own schemes): Alignment and
+    the run-length CIGAR (x = text, y = pattern)"""
+    g = np.load(os.path.join(HERE, "dp_golden.npz"))
+    n = len(g["pat_off"]) - 1
+    S = len(g["schemes"]); nk = int(g["n_known"])
+    aln = np.zeros((n, 3, 2, 6), dtype=np.int64)
+    cig_off = np.zeros((n, 3, 2, 2), dtype=np.int64)
+    cigars = []; pos = 0
+    for i in range(n):
+        pat = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+        txt = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+        q = g["quals"][g["pat_off"][i]:g["pat_off"][i + 1]] if g["has_quals"][i] else None
+        sv = g["known_schemes"][i] if i < nk else g["schemes"][i % S]
+        sc = oracle.Scheme(*[int(x) for x in sv])
+        for typ in range(3):
+            for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                r, s_, src, snk, ops, clips = R.full_gotoh_traceback(typ, sc, pat, txt, q, ms)
+                traced = 1 if r == 2 else 0
+                assert r in (0, 2)
+                c = oracle.cigar_from_ops(ops, *clips) if traced else np.zeros(0, dtype=np.uint16)
+                aln[i, typ, v] = (traced, s_, np.int64(np.int32(np.uint32(src[0]))), np.int64(np.int32(np.uint32(src[1]))),
+                                  np.int64(np.int32(np.uint32(snk[0]))), np.int64(np.int32(np.uint32(snk[1]))))
+                cig_off[i, typ, v] = (pos, pos + len(c)); pos += len(c)
+                cigars.append(c)
+    np.savez_compressed(os.path.join(HERE, "ftb_golden.npz"), aln=aln, cig_off=cig_off, cigars=np.concatenate(cigars).astype(np.uint16))
+    print("ftb_golden.npz: %d pairs, %d cigar elements" % (n, pos))
+
+
 def make_ed(R):
     """ed_golden.npz: the reference's banded edit-distance aligner (EditDistanceAligner<TYPE>, the aligner of
     examples/fmmap and of nvBowtie --scoring ed) on every pair of dp_golden.npz, bands 3/7/15/31 x 3 types"""
@@ -263,3 +294,4 @@ if __name__ == "__main__":
     make_dp(R)
     make_tb(R)
     make_ed(R)
+    make_ftb(R)

@@ -225,6 +225,39 @@ def test_banded_edit_distance_golden(orc, dp_golden, ed_golden):
         assert orc.banded_gotoh(7, oracle.SEMI_GLOBAL, sc, enc(pat), enc(txt))[1] == want
 
 
+def test_full_traceback_golden(orc, dp_golden, ftb_golden):
+    """score, source, sink and run-length CIGAR of the reference's full-matrix alignment_traceback"""
+    g, t = dp_golden, ftb_golden
+    n = len(g["pat_off"]) - 1
+    u = lambda v: int(np.uint32(np.int64(v) & 0xFFFFFFFF))
+    traced = 0
+    for i in range(n):
+        sc = _tb_scheme(g, i)
+        p, x, q = _case(g, i)
+        for typ in range(3):
+            for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                want = t["aln"][i, typ, v]
+                ok, s, src, snk, cig = orc.full_gotoh_traceback(typ, sc, p, x, q, ms)
+                assert (ok, s) == (int(want[0]), int(want[1])), (i, typ, v)
+                assert src == (u(want[2]), u(want[3])) and snk == (u(want[4]), u(want[5])), (i, typ, v)
+                lo, hi = t["cig_off"][i, typ, v]
+                assert np.array_equal(cig, t["cigars"][lo:hi]), (i, typ, v, oracle.cigar_string(cig))
+                if ok:      # the CIGAR spans the pattern and the source/sink text interval
+                    ln = cig >> 2; ty = cig & 3
+                    assert int(ln[(ty == 0) | (ty == 1) | (ty == 3)].sum()) == len(p)
+                    assert int(ln[(ty == 0) | (ty == 2)].sum()) == snk[0] - src[0]
+                traced += ok
+    assert traced > 1500
+    # the reference's functional tests (alignment_test.cu:741-755,816-828)
+    p, x, _ = _case(g, 0)
+    sc = oracle.Scheme.simple(2, -1, -1, -1)
+    assert oracle.cigar_string(orc.full_gotoh_traceback(oracle.GLOBAL, sc, p, x)[4]) == "1M2D3M1D3M10D"
+    assert oracle.cigar_string(orc.full_gotoh_traceback(oracle.LOCAL, sc, p, x)[4]) == "4M1D3M"
+    assert oracle.cigar_string(orc.full_gotoh_traceback(oracle.SEMI_GLOBAL, sc, p, x)[4]) == "4M1D3M"
+    p, x, _ = _case(g, 2)
+    assert oracle.cigar_string(orc.full_gotoh_traceback(oracle.SEMI_GLOBAL, oracle.Scheme.simple(0, -5, -8, -3), p, x)[4]) == "6I138M"
+
+
 def test_full_gotoh_golden(orc, dp_golden):
     g = dp_golden
     S = len(g["schemes"])

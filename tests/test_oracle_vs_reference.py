@@ -70,6 +70,11 @@ def test_gotoh_fuzz(orc, ref):
             assert np.array_equal(ops, rops), (it, typ)
             assert np.array_equal(cig, oracle.cigar_from_ops(rops, *rclips) if r == 2 else np.zeros(0, dtype=np.uint16)), (it, typ)
             ms = oracle.SCORE_MIN if it % 3 else int(rng.integers(-50, 200))
+            # full-matrix traceback (alignment_inl.h:355-455)
+            r, rs, rsrc, rsnk, rops, rclips = ref.full_gotoh_traceback(typ, sc, pat, txt, quals, ms)
+            ok, s, src, snk, cig = orc.full_gotoh_traceback(typ, sc, pat, txt, quals, ms)
+            assert (ok, s, src, snk) == (1 if r == 2 else 0, rs, rsrc, rsnk), (it, typ)
+            assert np.array_equal(cig, oracle.cigar_from_ops(rops, *rclips) if r == 2 else np.zeros(0, dtype=np.uint16)), (it, typ)
             for blk in range(2):
                 assert ref.full_gotoh(typ, blk, sc, pat, txt, quals, ms) == orc.full_gotoh(typ, blk, sc, pat, txt, quals, ms)
 
