@@ -371,6 +371,24 @@ nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_align
                                           uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
                                           uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* Full-matrix Gotoh traceback: aln::alignment_traceback<..,CHECKPOINTS> / BatchedAlignmentTraceback
+ * (nvbio/alignment/alignment_inl.h:355-517, gotoh/gotoh_inl.h:458-538,1573-1640; nvBowtie traceback_best,
+ * traceback_inl.h:249-275) with nvBowtie's run-length Backtracker: outputs as nvbio_banded_gotoh_traceback, with
+ * x = text and y = pattern coordinates and INSERTION = pattern symbol without text, DELETION = text symbol without
+ * pattern.  The scoring is the pattern-blocking pass (the one alignment_traceback itself runs), min_scores_dev
+ * (optional) its stripe early exit.  max_pattern_len / max_text_len must bound every job (they size the scratch: a
+ * boundary column plus 4 bits per DP cell); a longer job is skipped and flagged with cigar_lens = 0xFFFFFFFF.
+ * flags: NVBIO_TRACEBACK_SINKS_GIVEN as above (scores / sinks from nvbio_full_gotoh_score with text_blocking = 0 and
+ * the same min_scores).  NVBIO_ERR_UNSUPPORTED when scores could leave the reference's int16 checkpoints. */
+nvbio_status nvbio_full_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t max_pattern_len,
+                                                   uint32_t max_text_len, uint64_t* bytes);
+nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, const nvbio_gotoh_scheme* scheme,
+                                        const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                        const int32_t* min_scores_dev,
+                                        int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                        uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                        uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
+
 /* full-matrix Gotoh: aln::alignment_score / BatchedAlignmentScore (nvbio/alignment/gotoh/gotoh_inl.h:444-1256,
  * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default
  * PatternBlockingTag; min_scores_dev (optional) enables the reference's stripe early exit.

@@ -534,6 +534,40 @@ class BatchedBandedAlignmentTraceback:
         return scores, sources, sinks, cigars, lens
 
 
+class BatchedAlignmentTraceback:
+    """aln::BatchedAlignmentTraceback<CHECKPOINTS,stream> (full-matrix DP; nvbio/alignment/batched.h:395-411) with
+    nvBowtie's run-length Backtracker: Alignment {score, source, sink} (x = text, y = pattern) and io::Cigar runs"""
+
+    def __init__(self, aligner):
+        self.aligner = aligner
+
+    def min_temp_storage(self, batch, max_pattern_len, max_text_len):
+        out = ctypes.c_uint64(0)
+        bs = batch.c_struct()
+        _check(lib().nvbio_full_gotoh_traceback_temp_bytes(ctypes.byref(bs), ctypes.c_uint32(max_pattern_len),
+                                                           ctypes.c_uint32(max_text_len), ctypes.byref(out)))
+        return int(out.value)
+
+    def enact(self, batch, max_pattern_len, max_text_len, min_scores=None, cigar_stride=64, temp=None, scores=None, sinks=None):
+        torch = _torch()
+        n, dev = batch.n, batch.device
+        given = scores is not None and sinks is not None
+        if not given:
+            scores = torch.empty(n, dtype=torch.int32, device=dev)
+            sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        sources = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        cigars = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev)
+        lens = torch.empty(n, dtype=torch.int32, device=dev)
+        ms = _dev_tensor(min_scores, torch.int32, dev)
+        bs = batch.c_struct()
+        _check(lib().nvbio_full_gotoh_traceback(
+            FMIndex._dev_index(dev), ctypes.c_int(self.aligner.type), ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs),
+            ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms), _ptr(scores), _ptr(sources), _ptr(sinks),
+            _ptr(cigars), ctypes.c_uint32(cigar_stride), _ptr(lens), ctypes.c_uint32(TRACEBACK_SINKS_GIVEN if given else 0),
+            _ptr(temp), ctypes.c_uint64(0 if temp is None else temp.numel() * temp.element_size()), _stream_ptr(dev)))
+        return scores, sources, sinks, cigars, lens
+
+
 def cigar_string(cigar_row, length, forward=True):
     """render one alignment's io::Cigar elements ('3M2D147M'); forward=True reverses the backtracking order"""
     els = [int(c) & 0xFFFF for c in cigar_row[:length]]

@@ -1,0 +1,429 @@
+// gotoh_full_traceback.hip -- batched full-matrix Gotoh traceback (score + CIGAR) for gfx950: the opposite mates of
+// a paired-end batch, sw-benchmark-style alignments.
+//
+// Reference behaviour reproduced (file:line relative to the reference tree):
+//   alignment_traceback (driver: score pass, clip, walk, first row/column, clip)   nvbio/alignment/alignment_inl.h:355-455
+//   direction vectors per cell (hdir | edir | fdir), pattern blocking             nvbio/alignment/gotoh/gotoh_inl.h:458-538, :423-436
+//   priv::alignment_traceback (the H/E/F state walk)                              gotoh_inl.h:1573-1640
+//   nvBowtie's run-length Backtracker and io::Cigar                               nvBowtie/bowtie2/cuda/alignment_utils.h:115-157
+//   nvBowtie traceback_best (full DP, FULL_DP_CHECKPOINTS)                        nvBowtie/bowtie2/cuda/traceback_inl.h:249-275
+//
+// Same design as gotoh_traceback.hip: the reference checkpoints every 64 pattern columns as int16 and recomputes each
+// block's direction vectors on the way back; here one forward pass (the pattern-blocking DP of gotoh_full.hip, 8-column
+// stripes) writes every cell's direction nibble to HBM scratch -- one 32-bit word per (text row, stripe), job-interleaved
+// -- and the walk reads them back.  A 150 x 500 job takes 38 KB; launches are chunked to the scratch granted.  Jobs
+// whose optimum is reached by the diagonal through the sink alone are traced without a DP (the tie rule of
+// gotoh_inl.h:529-531 resolves the diagonal's ties to SUBSTITUTION, as in the banded case).  Identical to the reference
+// while scores fit its int16 checkpoints (host check).
+#include "gotoh_common.h"
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
+
+namespace nvbio_amd {
+namespace {
+
+enum : uint32_t { D_SUB = 0u, D_INS = 1u, D_DEL = 2u, D_SINK = 3u, D_INS_EXT = 4u, D_DEL_EXT = 8u };
+constexpr int STRIPE = 8;
+
+struct Sink
+{
+    int32_t score; uint32_t x, y;
+    __device__ __forceinline__ void init() { score = NVBIO_SCORE_MIN; x = y = 0xFFFFFFFFu; }
+    __device__ __forceinline__ void report(const int32_t s, const uint32_t sx, const uint32_t sy)
+    {
+        if (score <= s) { score = s; x = sx; y = sy; }
+    }
+};
+__device__ __forceinline__ uint32_t pack_cell(const int32_t h, const int32_t e) { return ((uint32_t)h & 0xFFFFu) | ((uint32_t)e << 16); }
+__device__ __forceinline__ int32_t  cell_h(const uint32_t c) { return (int32_t)(int16_t)(c & 0xFFFFu); }
+__device__ __forceinline__ int32_t  cell_e(const uint32_t c) { return (int32_t)(int16_t)(c >> 16); }
+
+struct JobInfo
+{
+    uint32_t first, M, tb, N; bool rev, comp;
+};
+__device__ __forceinline__ JobInfo load_job(const BatchDev& b, const uint32_t job)
+{
+    JobInfo j;
+    const uint32_t rid = b.read_id ? b.read_id[job] : job;
+    j.first = b.read_offsets[rid];
+    j.M     = b.read_offsets[rid + 1] - j.first;
+    const uint32_t fl = b.flags ? b.flags[job] : 0u;
+    j.rev  = (fl & NVBIO_READ_REVERSE) != 0;
+    j.comp = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    j.tb   = b.win_begin[job];
+    j.N    = b.win_end[job] - j.tb;
+    return j;
+}
+
+// ---- forward DP with direction vectors + walk back ------------------------------------------------------------------
+template <int TYPE, int RBITS, int TBITS>
+__global__ void __launch_bounds__(128)
+full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t max_M, const uint32_t max_N,
+                            const uint32_t job_begin, const uint32_t jobs, const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
+                            const int32_t* __restrict__ min_scores, uint32_t* __restrict__ column, uint32_t* __restrict__ dirs,
+                            int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
+                            uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens)
+{
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= jobs) return;
+    if (job_list && job_begin + t >= *job_count) return;
+    const uint32_t job = job_list ? job_list[job_begin + t] : job_begin + t;
+    const JobInfo J = load_job( b, job );
+    const uint32_t M = J.M, N = J.N;
+    const int32_t min_score = min_scores ? min_scores[job] : NVBIO_SCORE_MIN;
+
+    if (M > max_M || N > max_N)                                  // would overrun the scratch: skipped, flagged
+    {
+        scores[job] = NVBIO_SCORE_MIN; sinks[job] = sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu );
+        cigar_lens[job] = 0xFFFFFFFFu;
+        return;
+    }
+
+    SymbolReader<TBITS> trd( b.text );
+    SymbolReader<RBITS> prd( b.reads );
+    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    const int32_t V = sc.match;
+    const uint32_t nst = (max_M + STRIPE - 1u) / STRIPE;        // direction words per text row
+
+    uint32_t* col = column + t;                                 // element i at col[i * jobs]
+    for (uint32_t i = 0; i < N; ++i)
+    {
+        const int32_t x = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + sc.txt_ge * (int32_t)i : 0;
+        const int32_t y = (TYPE == NVBIO_LOCAL) ? 0 : infimum;
+        col[(size_t)i * jobs] = pack_cell( x, y );
+    }
+
+    Sink sink; sink.init();
+    const uint32_t nb        = (M + STRIPE - 1u) / STRIPE;
+    const uint32_t end_block = (STRIPE * nb > (uint32_t)STRIPE) ? STRIPE * nb : (uint32_t)STRIPE;
+    const uint32_t jm = ((M - 1u) & (STRIPE - 1u)) + 1u;
+    uint32_t c_sym[STRIPE]; int32_t c_mm[STRIPE];
+    #pragma unroll
+    for (int j = 0; j < STRIPE; ++j) { c_sym[j] = 0; c_mm[j] = 0; }
+    int32_t H[STRIPE + 1], F[STRIPE + 1];
+    bool ok = true;
+
+    for (uint32_t block = 0; block < end_block && ok; block += STRIPE)
+    {
+        const bool last = (block + STRIPE >= end_block);
+        #pragma unroll
+        for (int j = 0; j < STRIPE; ++j)
+            if (block + j < M)
+            {
+                const uint32_t idx = J.rev ? J.first + M - 1u - (block + j) : J.first + block + j;
+                uint32_t q = prd.get( idx );
+                if (J.comp && q < 4u) q = 3u - q;
+                const uint32_t qq = b.quals ? b.quals[idx] : 0u;
+                c_sym[j] = q; c_mm[j] = s_mm[qq < 63u ? qq : 63u];
+            }
+        #pragma unroll
+        for (int j = 0; j <= STRIPE; ++j)
+        {
+            H[j] = (TYPE != NVBIO_LOCAL) ? ((block + j > 0) ? G_o + G_e * (int32_t)(block + j - 1u) : 0) : 0;
+            F[j] = infimum;
+        }
+        int32_t max_score = NVBIO_SCORE_MIN;
+        int32_t temp_i    = H[0];
+        uint32_t* drow = dirs + (size_t)(block / STRIPE) * jobs + t;          // word of row i at drow[i * nst * jobs]
+
+        for (uint32_t i = 0; i < N; ++i)
+        {
+            const uint32_t r_sym = trd.get( J.tb + i );
+            int32_t H_diag = temp_i;
+            const uint32_t cell = col[(size_t)i * jobs];
+            H[0] = temp_i = cell_h( cell );
+            int32_t E = cell_e( cell );
+            uint32_t dw = 0;
+            int32_t key = -1;
+            #pragma unroll
+            for (int j = 1; j <= STRIPE; ++j)
+            {
+                const int32_t ftop = F[j] + G_e, htop = H[j] + G_o;
+                F[j] = max2( ftop, htop );
+                const int32_t eleft = E + G_e, hleft = H[j - 1] + G_o;
+                E = max2( eleft, hleft );
+                const int32_t d = H_diag + ((c_sym[j - 1] == r_sym) ? V : c_mm[j - 1]);
+                const int32_t top = F[j], left = E;
+                int32_t hi = max3( left, top, d );
+                uint32_t hdir = top > left ? (top > d ? D_DEL : D_SUB) : (left > d ? D_INS : D_SUB);   // gotoh_inl.h:529-531
+                if (TYPE == NVBIO_LOCAL) { hi = max2( hi, 0 ); if (hi == 0) hdir = D_SINK; }
+                H_diag = H[j];
+                H[j]   = hi;
+                dw |= (hdir | (eleft > hleft ? D_INS_EXT : 0u) | (ftop > htop ? D_DEL_EXT : 0u)) << (4 * (j - 1));
+                if (TYPE == NVBIO_LOCAL && (!last || block + j <= M)) key = max2( key, (hi << 4) | j );
+            }
+            col[(size_t)i * jobs] = pack_cell( H[STRIPE], E );
+            drow[(size_t)i * nst * jobs] = dw;
+            max_score = max2( max_score, H[STRIPE] );
+            if (TYPE == NVBIO_LOCAL)
+            {
+                if (key >= 0) sink.report( key >> 4, i + 1u, block + (uint32_t)(key & 15) );
+            }
+            else if (last && TYPE == NVBIO_SEMI_GLOBAL)
+            {
+                int32_t v = 0;
+                #pragma unroll
+                for (int j = 1; j <= STRIPE; ++j) if ((uint32_t)j == jm) v = H[j];
+                sink.report( v, i + 1u, M );
+            }
+        }
+        if (!last)
+        {
+            const int32_t missing = (int32_t)(M - block - STRIPE);
+            if (max_score + missing * V < min_score) ok = false;
+        }
+    }
+    if (ok && TYPE == NVBIO_GLOBAL)
+    {
+        int32_t v = 0;
+        #pragma unroll
+        for (int j = 1; j <= STRIPE; ++j) if ((uint32_t)j == jm) v = H[j];
+        sink.report( v, N, M );
+    }
+
+    scores[job] = sink.score;
+    sinks[job]  = make_uint2( sink.x, sink.y );
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu)
+    {
+        sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0;
+        return;
+    }
+
+    // ---- the walk (gotoh_inl.h:1599-1638), the implicit first row / column (alignment_inl.h:437-452) --------------
+    uint16_t* cig = cigars + (size_t)job * cigar_stride;
+    uint32_t  clen = 0, prev = 255u, run = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) { if (clen < cigar_stride) cig[clen] = (uint16_t)(type | (len << 2)); ++clen; };
+    auto push = [&](const uint32_t op) { if (op == prev) ++run; else { if (run) emit( prev, run ); prev = op; run = 1u; } };
+    if (M - sink.y) emit( 3u, M - sink.y );
+
+    int32_t row = (int32_t)sink.x, ccol = (int32_t)sink.y - 1;
+    uint32_t state = 0;
+    int32_t  w_row = -1, w_st = -1; uint32_t word = 0;
+    while (row > 0 && ccol >= 0)
+    {
+        if (row != w_row || (ccol >> 3) != w_st)
+        {
+            w_row = row; w_st = ccol >> 3;
+            word = dirs[((size_t)(row - 1) * nst + (uint32_t)w_st) * jobs + t];
+        }
+        const uint32_t op = (word >> (4 * (ccol & 7))) & 15u, h_op = op & 3u;
+        if (TYPE == NVBIO_LOCAL && state == 0u && h_op == D_SINK) break;
+        if (state == 1u)      { if ((op & D_INS_EXT) == 0u) state = 0u; --ccol; push( D_INS ); }
+        else if (state == 2u) { if ((op & D_DEL_EXT) == 0u) state = 0u; --row;  push( D_DEL ); }
+        else
+        {
+            if (h_op == D_INS)      state = 1u;
+            else if (h_op == D_DEL) state = 2u;
+            else { --ccol; --row; push( D_SUB ); }
+        }
+    }
+    uint32_t sx = (uint32_t)row, sy = (uint32_t)(ccol + 1);
+    if (TYPE == NVBIO_SEMI_GLOBAL || TYPE == NVBIO_GLOBAL)
+        if (sx == 0u) for (; sy > 0u; --sy) push( D_INS );
+    if (TYPE == NVBIO_GLOBAL)
+        if (sy == 0u) for (; sx > 0u; --sx) push( D_DEL );
+    if (run) emit( prev, run );
+    if (sy) emit( 3u, sy );
+    sources[job]    = make_uint2( sx, sy );
+    cigar_lens[job] = clen;
+}
+
+// ---- ungapped shortcut: the diagonal through the sink ---------------------------------------------------------------
+// Given S* and the sink (x = text end, y = pattern end) of the scoring pass: if the k diagonal steps ending in the sink
+// alone score S* -- LOCAL: the smallest such k; SEMI_GLOBAL: k = y, which needs x >= y -- every cell on the diagonal
+// holds its prefix score, the diagonal ties for the maximum, ties resolve to SUBSTITUTION, a LOCAL walk stops at the
+// first prefix score 0: the traceback is k substitutions.  GLOBAL always takes the DP (its first column is not free).
+template <int TYPE, int RBITS, int TBITS>
+__global__ void __launch_bounds__(256)
+ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t max_M, const uint32_t max_N,
+                               const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                               uint2* __restrict__ sources, uint16_t* __restrict__ cigars, const uint32_t cigar_stride,
+                               uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp)
+{
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const JobInfo J = load_job( b, job );
+    const uint2   sink = sinks[job];
+    const int32_t best = scores[job];
+    need_dp[job] = 0;
+    if (J.M > max_M || J.N > max_N) { sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0xFFFFFFFFu; return; }
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu) { sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0; return; }
+    if (TYPE == NVBIO_GLOBAL || (TYPE == NVBIO_SEMI_GLOBAL && sink.x < sink.y)) { need_dp[job] = 1; return; }
+
+    SymbolReader<TBITS> trd( b.text );
+    SymbolReader<RBITS> prd( b.reads );
+    int32_t Q = 0; uint32_t k = 0;
+    bool found = (TYPE == NVBIO_LOCAL) && (best == 0);
+    const uint32_t kmax = sink.x < sink.y ? sink.x : sink.y;
+    while (k < kmax && !found)
+    {
+        const uint32_t pc  = sink.y - 1u - k;                    // pattern column, text row sink.x - 1 - k
+        const uint32_t idx = J.rev ? J.first + J.M - 1u - pc : J.first + pc;
+        uint32_t q = prd.get( idx );
+        if (J.comp && q < 4u) q = 3u - q;
+        const uint32_t qq = b.quals ? b.quals[idx] : 0u;
+        const uint32_t g  = trd.get( J.tb + sink.x - 1u - k );
+        Q += (g == q) ? sc.match : s_mm[qq < 63u ? qq : 63u];
+        ++k;
+        if (TYPE == NVBIO_LOCAL && Q == best) found = true;
+    }
+    if (TYPE == NVBIO_SEMI_GLOBAL) found = (k == sink.y && Q == best);
+    if (!found) { need_dp[job] = 1; return; }
+
+    uint16_t* cig = cigars + (size_t)job * cigar_stride;
+    uint32_t  clen = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) { if (clen < cigar_stride) cig[clen] = (uint16_t)(type | (len << 2)); ++clen; };
+    if (J.M - sink.y) emit( 3u, J.M - sink.y );
+    if (k)            emit( D_SUB, k );
+    if (sink.y - k)   emit( 3u, sink.y - k );
+    sources[job]    = make_uint2( sink.x - k, sink.y - k );
+    cigar_lens[job] = clen;
+}
+
+} // anonymous namespace
+} // namespace nvbio_amd
+
+using namespace nvbio_amd;
+
+static inline uint64_t full_tb_bytes_per_job(const uint32_t max_M, const uint32_t max_N)
+{
+    return (uint64_t)max_N * sizeof(uint32_t) * (1u + (max_M + 7u) / 8u);       // boundary column + direction words
+}
+
+extern "C" nvbio_status nvbio_full_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch, uint32_t max_pattern_len,
+                                                              uint32_t max_text_len, uint64_t* bytes)
+{
+    NVB_REQUIRE( batch && bytes, "batch/bytes is NULL" );
+    NVB_REQUIRE( max_pattern_len > 0 && max_text_len > 0, "max_pattern_len / max_text_len must be positive" );
+    *bytes = (uint64_t)batch->n * full_tb_bytes_per_job( max_pattern_len, max_text_len );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, const nvbio_gotoh_scheme* scheme,
+                                                   const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                                   const int32_t* min_scores_dev,
+                                                   int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                   uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                   uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( type == NVBIO_GLOBAL || type == NVBIO_LOCAL || type == NVBIO_SEMI_GLOBAL, "invalid alignment type" );
+    NVB_REQUIRE( scores_dev && sources_dev && sinks_dev && cigar_lens_dev, "NULL output pointer" );
+    NVB_REQUIRE( cigars_dev != nullptr || cigar_stride == 0, "cigars_dev is NULL" );
+    NVB_REQUIRE( max_pattern_len > 0 && max_text_len > 0, "max_pattern_len / max_text_len must bound the jobs (they size the scratch)" );
+    {
+        int64_t step = scheme->match < 0 ? -(int64_t)scheme->match : scheme->match;
+        const int64_t c[] = { scheme->mm_min, scheme->mm_max, -(int64_t)scheme->pat_gap_open, -(int64_t)scheme->pat_gap_ext,
+                              -(int64_t)scheme->txt_gap_open, -(int64_t)scheme->txt_gap_ext };
+        for (int64_t v : c) { if (v < 0) v = -v; if (v > step) step = v; }
+        if (((int64_t)max_pattern_len + max_text_len + 1) * step > 30000)
+        {
+            set_error( "full traceback: scores of %u x %u jobs under this scheme can overflow the reference's int16 checkpoints", max_pattern_len, max_text_len );
+            return NVBIO_ERR_UNSUPPORTED;
+        }
+    }
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
+                           scheme->txt_gap_open, scheme->txt_gap_ext };
+    const uint32_t rb = batch->read_bits, tbits = batch->text_bits;
+
+    // ---- 1. scoring pass (pattern blocking) unless handed over; 2. the ungapped shortcut; 3. job list ----
+    const bool shortcut = !getenv( "NVBIO_AMD_NO_UNGAPPED_TRACEBACK" );
+    uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
+    if (shortcut)
+    {
+        if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
+            NVB_CHECK( nvbio_full_gotoh_score( device, type, 0, scheme, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sinks_dev,
+                                               nullptr, 0, stream ) );
+        size_t sel_bytes = 0;
+        hipcub::CountingInputIterator<uint32_t> ids( 0u );
+        NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
+        const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
+        const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        {
+            set_error( "full traceback: out of device memory for the job list" );
+            return NVBIO_ERR_NOMEM;
+        }
+        uint8_t* need_dp = (uint8_t*)aux;
+        job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
+        job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
+        void* sel_temp = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
+#define NVB_UNG(TYPE_, RB, TB) hipLaunchKernelGGL( (ungapped_full_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, \
+                                                   (const int32_t*)scores_dev, (const uint2*)sinks_dev, (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp )
+#define NVB_UNG_BITS(TYPE_) \
+        if      (rb == 4 && tbits == 2) NVB_UNG( TYPE_, 4, 2 ); else if (rb == 2 && tbits == 2) NVB_UNG( TYPE_, 2, 2 ); \
+        else if (rb == 8 && tbits == 2) NVB_UNG( TYPE_, 8, 2 ); else if (rb == 8 && tbits == 8) NVB_UNG( TYPE_, 8, 8 ); \
+        else if (rb == 4 && tbits == 8) NVB_UNG( TYPE_, 4, 8 ); else NVB_UNG( TYPE_, 2, 8 )
+        if (type == NVBIO_GLOBAL) { NVB_UNG_BITS( NVBIO_GLOBAL ); } else if (type == NVBIO_LOCAL) { NVB_UNG_BITS( NVBIO_LOCAL ); } else { NVB_UNG_BITS( NVBIO_SEMI_GLOBAL ); }
+#undef NVB_UNG_BITS
+#undef NVB_UNG
+        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    }
+
+    // ---- 4. the DP with direction vectors + walk, over the job list (or every job) ----
+    const uint64_t per_job = full_tb_bytes_per_job( max_pattern_len, max_text_len );
+    void* owned = nullptr; uint8_t* scratch = (uint8_t*)temp_dev; uint64_t cap_jobs;
+    if (scratch)
+    {
+        cap_jobs = temp_bytes / per_job;
+        if (!(cap_jobs >= 64 || cap_jobs >= b.n))
+        {
+            if (aux) (void)hipFreeAsync( aux, s );
+            set_error( "invalid argument: temp_bytes too small (see nvbio_full_gotoh_traceback_temp_bytes)" );
+            return NVBIO_ERR_INVALID;
+        }
+    }
+    else
+    {
+        cap_jobs = shortcut ? ((uint64_t)b.n + 3u) / 4u : b.n;
+        if (cap_jobs < 16384u) cap_jobs = b.n < 16384u ? b.n : 16384u;
+        const uint64_t budget = 16ull << 30;
+        if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
+        if (cap_jobs < 64) cap_jobs = 64;
+        if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
+        {
+            if (aux) (void)hipFreeAsync( aux, s );
+            set_error( "full traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
+            return NVBIO_ERR_NOMEM;
+        }
+        scratch = (uint8_t*)owned;
+    }
+    if (cap_jobs > b.n) cap_jobs = b.n;
+    nvbio_status st = NVBIO_OK;
+    for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
+    {
+        const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
+        uint32_t* column = (uint32_t*)scratch;
+        uint32_t* dirs   = column + (size_t)jobs * max_text_len;
+        const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
+#define NVB_TB(TYPE_, RB, TB) hipLaunchKernelGGL( (full_gotoh_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)begin, jobs, \
+                                                  (const uint32_t*)job_list, (const uint32_t*)job_count, min_scores_dev, column, dirs, scores_dev, (uint2*)sources_dev, \
+                                                  (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev )
+#define NVB_TB_BITS(TYPE_) \
+        if      (rb == 4 && tbits == 2) NVB_TB( TYPE_, 4, 2 ); else if (rb == 2 && tbits == 2) NVB_TB( TYPE_, 2, 2 ); \
+        else if (rb == 8 && tbits == 2) NVB_TB( TYPE_, 8, 2 ); else if (rb == 8 && tbits == 8) NVB_TB( TYPE_, 8, 8 ); \
+        else if (rb == 4 && tbits == 8) NVB_TB( TYPE_, 4, 8 ); else NVB_TB( TYPE_, 2, 8 )
+        if (type == NVBIO_GLOBAL) { NVB_TB_BITS( NVBIO_GLOBAL ); } else if (type == NVBIO_LOCAL) { NVB_TB_BITS( NVBIO_LOCAL ); } else { NVB_TB_BITS( NVBIO_SEMI_GLOBAL ); }
+#undef NVB_TB_BITS
+#undef NVB_TB
+        if (hipGetLastError() != hipSuccess) { set_error( "full traceback launch failed" ); st = NVBIO_ERR_HIP; }
+    }
+    if (owned) (void)hipFreeAsync( owned, s );
+    if (aux)   (void)hipFreeAsync( aux, s );
+    return st;
+}

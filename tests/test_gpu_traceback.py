@@ -153,3 +153,94 @@ def test_traceback_argument_errors(amd, orc):
     ln = amd.u32(out[4])
     assert ln[1] == 0xFFFFFFFF and ln[0] == 1 and int(out[0][0]) == 60
     assert amd.cigar_string(out[3][0].cpu().numpy(), 1) == "30M"
+
+
+def test_full_traceback_golden(amd, dp_golden, ftb_golden, tb_mode):
+    """full-matrix traceback through the C-ABI vs the reference's alignment_traceback (ftb_golden.npz): every pair,
+    3 types, with and without min_score, shortcut on and off"""
+    g, t = dp_golden, ftb_golden
+    S = len(g["schemes"]); nk = int(g["n_known"])
+    n = len(g["pat_off"]) - 1
+    max_p = int(np.diff(g["pat_off"]).max()); max_t = int(np.diff(g["txt_off"]).max())
+    groups = {}
+    for i in range(n):
+        key = ("k", i) if i < nk else ("s", i % S, int(g["has_quals"][i]))
+        groups.setdefault(key, []).append(i)
+    STRIDE = 160
+    checked = traced = 0
+    for key, cases in groups.items():
+        cases = np.array(cases, dtype=np.uint32)
+        sv = g["known_schemes"][cases[0]] if key[0] == "k" else g["schemes"][key[1]]
+        hq = bool(g["has_quals"][cases[0]])
+        batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1],
+                                   quals=g["quals"] if hq else None, read_id=cases)
+        for typ in range(3):
+            for v in (0, 1):
+                ms = g["min_scores"][cases] if v else None
+                sc, src, snk, cig, ln = amd.BatchedAlignmentTraceback(amd.make_gotoh_aligner(typ, _scheme(amd, sv))).enact(
+                    batch, max_p, max_t, min_scores=ms, cigar_stride=STRIDE)
+                sc, src, snk, ln = _i64(sc), _i64(src), _i64(snk), _i64(ln)
+                cig = cig.cpu().numpy().view(np.uint16)
+                for k, i in enumerate(cases):
+                    want = t["aln"][i, typ, v]
+                    lo, hi = t["cig_off"][i, typ, v]
+                    assert sc[k] == want[1], (i, typ, v)
+                    assert tuple(src[k]) == (want[2], want[3]) and tuple(snk[k]) == (want[4], want[5]), (i, typ, v)
+                    assert ln[k] == hi - lo, (i, typ, v)
+                    m = min(int(ln[k]), STRIDE)
+                    assert np.array_equal(cig[k, :m], t["cigars"][lo:lo + m]), (i, typ, v)
+                    checked += 1; traced += int(want[0])
+    assert checked == n * 6 and traced > 1500
+
+
+@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
+def test_full_traceback_opposite_mate_shape(amd, orc, typ, tb_mode):
+    """4-bit reads (reversed / complemented, qualities) in 2-bit genome windows of 150-500 symbols, chunked scratch,
+    scores handed over from the scoring pass: equal to the oracle job by job"""
+    import torch
+    typ = getattr(oracle, typ)
+    rng = np.random.default_rng(19)
+    G = 200000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R, M = 900, 150
+    starts = rng.integers(0, G - 600, R)
+    off = rng.integers(0, 300, R)
+    reads = []
+    for j in range(R):
+        r = text[starts[j] + off[j]:starts[j] + off[j] + M].copy()
+        k = int(rng.integers(0, 4)); pos = rng.integers(0, M, k); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        if j % 4 == 0:
+            c = int(rng.integers(3, M - 3)); gsz = int(rng.integers(1, 4))
+            r = np.concatenate([r[:c], r[c + gsz:], rng.integers(0, 4, gsz, dtype=np.uint8)]) if j % 8 else \
+                np.concatenate([r[:c], rng.integers(0, 4, gsz, dtype=np.uint8), r[c:M - gsz]])
+        reads.append(r.astype(np.uint8))
+    flags = rng.integers(0, 4, R).astype(np.uint8)
+    stored = []
+    for j, r in enumerate(reads):
+        v = np.where(r < 4, 3 - r, r).astype(np.uint8) if flags[j] & 2 else r.copy()
+        stored.append(v[::-1] if flags[j] & 1 else v)
+    flat = np.concatenate(stored)
+    quals = rng.integers(0, 64, len(flat), dtype=np.uint8)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    wb = starts.astype(np.uint32); we = (starts + rng.integers(460, 501, R)).astype(np.uint32)
+    we[::9] = wb[::9] + rng.integers(100, 200, len(we[::9])).astype(np.uint32)
+    sv = (2, 2, 6, -8, -3, -8, -3) if typ == oracle.LOCAL else (0, 6, 6, -8, -3, -8, -3)
+    ms = np.full(R, 60 if typ == oracle.LOCAL else -60, dtype=np.int32); ms[::3] = oracle.SCORE_MIN
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, flags=flags)
+    al = amd.make_gotoh_aligner(typ, _scheme(amd, sv))
+    op = amd.BatchedAlignmentTraceback(al)
+    need = op.min_temp_storage(batch, M, 500)
+    assert need == R * 500 * 4 * (1 + 19)
+    temp = torch.empty(need // 3 + 64, dtype=torch.uint8, device="cuda:0")
+    s0, k0 = amd.BatchedAlignmentScore(al, text_blocking=False).enact(batch, M, 500, min_scores=ms)
+    for kw in (dict(), dict(temp=temp), dict(scores=s0, sinks=k0)):
+        sc, src, snk, cig, ln = op.enact(batch, M, 500, min_scores=ms, cigar_stride=40, **kw)
+        sc, src, snk, ln = sc.cpu().numpy(), amd.u32(src), amd.u32(snk), amd.u32(ln)
+        cig = cig.cpu().numpy().view(np.uint16)
+        for j in range(R):
+            q = quals[roffs[j]:roffs[j + 1]]
+            ok, s_, wsrc, wsnk, wc = orc.full_gotoh_traceback(typ, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]],
+                                                             q[::-1] if flags[j] & 1 else q, int(ms[j]))
+            assert sc[j] == s_ and tuple(snk[j]) == wsnk and tuple(src[j]) == wsrc and ln[j] == len(wc), (j, kw.keys())
+            m = min(int(ln[j]), 40)                                 # elements beyond the stride are dropped, the count is not
+            assert np.array_equal(cig[j, :m], wc[:m]), j
