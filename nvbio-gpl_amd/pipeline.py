@@ -251,16 +251,21 @@ class PairedEndParams:
         self.min_frag_len, self.max_frag_len, self.overlap = min_frag_len, max_frag_len, overlap
 
 
-def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers=None):
+def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers=None, cigar_stride=0):
     """A paired-end composition of the path's operators in nvBowtie's shape: each mate in turn is the anchor --
     seed-and-extend as a single end, best candidate per read -- and the other mate is scored by full-matrix DP inside the
     window the fragment-length constraints allow around the anchor (BestOppositeScoreStream, score_inl.h:283-456), with
     min_score = the opposite mate's own worst admissible score.  The pair with the higher anchor + opposite score wins
     (ties: mate 1 as anchor).  Returns a dict of per-pair tensors: anchor (0/1, -1 if no pair), score1/2, pos1/2 (end
     positions), rc1/2.  (nvBowtie additionally iterates over several anchor candidates and tightens min_score with the
-    pairs found so far; that policy is not part of this path.)"""
+    pairs found so far; that policy is not part of this path.)
+    cigar_stride > 0: also trace the chosen pair back -- the anchor mate through the banded traceback in its candidate
+    window, the opposite mate through the full-matrix traceback in its window (nvBowtie's banded_traceback_best /
+    traceback_best) -- adding begin1/2 (text position where each mate's alignment starts), cigars1/2 [R, cigar_stride]
+    (io::Cigar runs, backtracking order) and cigar_lens1/2 (0 for unpaired reads)."""
     import torch
-    from . import BatchedAlignmentScore, max_text_gaps, opposite_mate_windows
+    from . import (BatchedAlignmentScore, BatchedAlignmentTraceback, BatchedBandedAlignmentTraceback, max_text_gaps,
+                   opposite_mate_windows)
     pe = pe or PairedEndParams()
     dev = fmi.device
     R = mates1.n
@@ -268,6 +273,7 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
     worst = -(1 << 30)
     out = {}
     cand = []
+    trace_state = []
     for anchor, (a, o) in enumerate(((mates1, mates2), (mates2, mates1))):
         tag = "_a%d" % anchor
         sub = None if timers is None else {}
@@ -304,6 +310,11 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
         o_pos[sel] = (wb[ok].to(torch.int64) & 0xFFFFFFFF) + (osk[ok][:, 0].to(torch.int64) & 0xFFFFFFFF)
         o_rc[sel] = (flags[ok] != 0).to(torch.uint8)
         cand.append((bs.to(torch.int64), bp, brc, o_score, o_pos, o_rc))
+        if cigar_stride:
+            o_wb = torch.full((R,), -1, dtype=torch.int64, device=dev); o_we = o_wb.clone()
+            o_wb[sel] = wb[ok].to(torch.int64) & 0xFFFFFFFF; o_we[sel] = we[ok].to(torch.int64) & 0xFFFFFFFF
+            o_sx = torch.zeros((R,), dtype=torch.int32, device=dev); o_sx[sel] = osk[ok][:, 0]
+            trace_state.append((bwb, o_wb, o_we, o_sx))
     (s1a, p1a, r1a, s2a, p2a, r2a), (s2b, p2b, r2b, s1b, p1b, r1b) = cand
     pair_a = torch.where(s2a > worst, s1a + s2a, torch.full_like(s1a, worst))
     pair_b = torch.where(s1b > worst, s2b + s1b, torch.full_like(s1b, worst))
@@ -313,4 +324,56 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
     out["score1"] = torch.where(use_b, s1b, s1a); out["pos1"] = torch.where(use_b, p1b, p1a); out["rc1"] = torch.where(use_b, r1b, r1a)
     out["score2"] = torch.where(use_b, s2b, s2a); out["pos2"] = torch.where(use_b, p2b, p2a); out["rc2"] = torch.where(use_b, r2b, r2a)
     out["pair_score"] = torch.maximum(pair_a, pair_b)
+    if not cigar_stride:
+        return out
+
+    # ---- traceback of the chosen pairs ------------------------------------------------------------------------------
+    def i32(t):
+        return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32)
+
+    for m in (1, 2):
+        out["begin%d" % m] = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        out["cigars%d" % m] = torch.zeros((R, cigar_stride), dtype=torch.int16, device=dev)
+        out["cigar_lens%d" % m] = torch.zeros((R,), dtype=torch.int32, device=dev)
+    aligner = GotohAligner(params.aln_type, params.scheme)
+    for anchor, (a, o) in enumerate(((mates1, mates2), (mates2, mates1))):
+        bwb, o_wb, o_we, o_sx = trace_state[anchor]
+        ids = torch.nonzero(out["anchor"] == anchor).view(-1)
+        if ids.numel() == 0:
+            continue
+        am, om = (1, 2) if anchor == 0 else (2, 1)
+        a_rc = out["rc%d" % am][ids]; o_rc = out["rc%d" % om][ids]
+        rid32 = ids.to(torch.int32)
+        e = None
+        if timers is not None:
+            s_ev, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            timers.setdefault("traceback_a%d" % anchor, []).append((s_ev, e)); s_ev.record()
+        # anchor mate: banded, in the window of its best candidate
+        wb = bwb[ids]; we = torch.clamp(wb + params.band + a.read_len, max=genome_len)
+        a_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * a.read_len
+        batch = AlignmentBatch(a.reads4, 4, a_off, genome2, 2, i32(wb), i32(we), quals=a.quals, read_id=rid32,
+                               flags=(a_rc.to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8), device=dev,
+                               max_read_len=a.read_len)
+        _, src, _, cig, ln = BatchedBandedAlignmentTraceback(params.band, aligner).enact(batch, cigar_stride=cigar_stride)
+        out["begin%d" % am][ids] = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        out["cigars%d" % am][ids] = cig; out["cigar_lens%d" % am][ids] = ln
+        # opposite mate: full matrix, in the opposite-mate window; its score and sink are known from the scoring pass
+        wb = o_wb[ids]; we = o_we[ids]
+        o_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * o.read_len
+        batch = AlignmentBatch(o.reads4, 4, o_off, genome2, 2, i32(wb), i32(we), quals=o.quals, read_id=rid32,
+                               flags=(o_rc.to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8), device=dev,
+                               max_read_len=o.read_len)
+        o_min = params.min_score_for(o.read_len)
+        ms = torch.full((ids.numel(),), o_min, dtype=torch.int32, device=dev)
+        known = {}
+        if params.aln_type != LOCAL:
+            sx = o_sx[ids]
+            known = dict(scores=out["score%d" % om][ids].to(torch.int32).contiguous(),
+                         sinks=torch.stack([sx, torch.full_like(sx, o.read_len)], dim=1).contiguous())
+        _, src, _, cig, ln = BatchedAlignmentTraceback(aligner).enact(batch, o.read_len, pe.max_frag_len, min_scores=ms,
+                                                                     cigar_stride=cigar_stride, **known)
+        out["begin%d" % om][ids] = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        out["cigars%d" % om][ids] = cig; out["cigar_lens%d" % om][ids] = ln
+        if e is not None:
+            e.record()
     return out

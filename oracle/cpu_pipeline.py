@@ -236,14 +236,16 @@ def opposite_window(g, anchor_fw, a_len, o_gapped_len, anchor, genome_len, polic
     return begin, end, fw, (begin < genome_len and begin < end)
 
 
-def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_of, aln_type, max_frag=500):
+def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_of, aln_type, max_frag=500, cigar_stride=0, band=31):
     """the composition of nvbio-gpl_amd/pipeline.py:paired_end on the oracle's functions"""
     R = len(mates1)
     worst = -(1 << 30)
     cand = []
+    state = []
     for anchor, (a, o) in enumerate(((mates1, mates2), (mates2, mates1))):
         a_len, o_len = a.shape[1], o.shape[1]
         bs, bp, brc, nc, bg = seed_and_extend_cpu(O, hidx, text, genome_len, a, aln_type=aln_type, scheme=scheme, want_loci=True)
+        o_win = np.full((R, 2), -1, dtype=np.int64)
         o_min = min_score_of(o_len)
         gaps = max_text_gaps(scheme, o_min, o_len)
         o_score = np.full(R, worst, dtype=np.int64); o_pos = np.full(R, -1, dtype=np.int64); o_rc = np.zeros(R, dtype=np.uint8)
@@ -257,13 +259,46 @@ def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_
             ok, s_, k_ = O.full_gotoh(aln_type, 0, scheme, p, text[begin:end], None, o_min)
             if s_ >= o_min:
                 o_score[r] = s_; o_pos[r] = begin + k_[0]; o_rc[r] = 0 if fw else 1
+                o_win[r] = (begin, end)
         cand.append((bs.astype(np.int64), bp, brc, o_score, o_pos, o_rc))
+        state.append((bg, o_win))
     (s1a, p1a, r1a, s2a, p2a, r2a), (s2b, p2b, r2b, s1b, p1b, r1b) = cand
     pair_a = np.where(s2a > worst, s1a + s2a, worst)
     pair_b = np.where(s1b > worst, s2b + s1b, worst)
     use_b = pair_b > pair_a
     paired = (pair_a > worst) | (pair_b > worst)
-    return dict(anchor=np.where(paired, use_b.astype(np.int64), -1),
-                score1=np.where(use_b, s1b, s1a), pos1=np.where(use_b, p1b, p1a), rc1=np.where(use_b, r1b, r1a),
-                score2=np.where(use_b, s2b, s2a), pos2=np.where(use_b, p2b, p2a), rc2=np.where(use_b, r2b, r2a),
-                pair_score=np.maximum(pair_a, pair_b))
+    out = dict(anchor=np.where(paired, use_b.astype(np.int64), -1),
+               score1=np.where(use_b, s1b, s1a), pos1=np.where(use_b, p1b, p1a), rc1=np.where(use_b, r1b, r1a),
+               score2=np.where(use_b, s2b, s2a), pos2=np.where(use_b, p2b, p2a), rc2=np.where(use_b, r2b, r2a),
+               pair_score=np.maximum(pair_a, pair_b))
+    if not cigar_stride:
+        return out
+    for m in (1, 2):
+        out["begin%d" % m] = np.full(R, -1, dtype=np.int64)
+        out["cigars%d" % m] = np.zeros((R, cigar_stride), dtype=np.uint16)
+        out["cigar_lens%d" % m] = np.zeros(R, dtype=np.uint32)
+
+    def oriented(read, rc):
+        return np.where(read[::-1] < 4, 3 - read[::-1], read[::-1]).astype(np.uint8) if rc else read
+
+    def put(m, r, begin, cig):
+        out["begin%d" % m][r] = begin
+        k = min(len(cig), cigar_stride)
+        out["cigars%d" % m][r, :k] = cig[:k]; out["cigar_lens%d" % m][r] = len(cig)
+
+    half = band // 2
+    for r in range(R):
+        anchor = int(out["anchor"][r])
+        if anchor < 0:
+            continue
+        (a, o) = (mates1, mates2) if anchor == 0 else (mates2, mates1)
+        am, om = (1, 2) if anchor == 0 else (2, 1)
+        bg, o_win = state[anchor]
+        g = int(bg[r]); wb = g - half if g > half else 0; we = min(wb + band + a.shape[1], genome_len)
+        _, _, src, _, cig, _ = O.banded_gotoh_traceback(band, aln_type, scheme, oriented(a[r], out["rc%d" % am][r]), text[wb:we])
+        put(am, r, wb + src[0], cig)
+        begin, end = int(o_win[r, 0]), int(o_win[r, 1])
+        _, _, src, _, cig = O.full_gotoh_traceback(aln_type, scheme, oriented(o[r], out["rc%d" % om][r]), text[begin:end], None,
+                                                   min_score_of(o.shape[1]))
+        put(om, r, begin + src[0], cig)
+    return out

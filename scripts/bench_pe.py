@@ -2,7 +2,7 @@
 """scripts/bench_pe.py -- BASELINE.json configs[4] shape on one GPU: P pairs of 2 x 150 bp (FR, insert N(350,50)
 clipped to [160,500], 1 % substitutions, 0.1 %/base indels) against the 3 Gbp index; each mate anchored in turn
 (seed-and-extend), the other scored by full-matrix DP inside nvBowtie's opposite-mate window, best pair per read
-(nvbio-gpl_amd/pipeline.py:paired_end).  Not a bench.py line; numbers go into DESIGN.md.
+(nvbio-gpl_amd/pipeline.py:paired_end), both mates of the chosen pair traced back to CIGARs.  Not a bench.py line; numbers go into DESIGN.md.
 
     python scripts/bench_pe.py [pairs] [ref_len]
 """
@@ -67,7 +67,7 @@ def main():
     for it in range(3):
         timers = {}
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = pipeline.paired_end(fmi, genome, n, b1, b2, params, timers=timers)
+        out = pipeline.paired_end(fmi, genome, n, b1, b2, params, timers=timers, cigar_stride=16)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         stage = {}
         for k, v in timers.items():
@@ -79,11 +79,14 @@ def main():
     true1 = torch.where(swap, left + ins, left + M)                    # end position of mate 1's true alignment
     near = (out["pos1"] - true1).abs() <= 40
     opp_ms = stage.get("opposite_a0", 0.0) + stage.get("opposite_a1", 0.0)
+    tb_ms = stage.get("traceback_a0", 0.0) + stage.get("traceback_a1", 0.0)
     cells = 2.0 * P * M * 500
     print(json.dumps({"config": "5 paired-end 2 x 150 bp vs 3 Gbp, FR, insert N(350,50), 1 GPU", "pairs": P, "ms": dt * 1e3,
                       "pairs_per_s": P / dt, "paired_fraction": float(paired.float().mean()),
                       "concordant_fraction": float(conc.float().mean()), "mate1_at_true_locus": float((paired & near).float().mean()),
-                      "opposite_mate_full_dp_ms": opp_ms,
+                      "opposite_mate_full_dp_ms": opp_ms, "traceback_both_mates_ms": tb_ms,
+                      "mean_cigar_runs": [float((out["cigar_lens1"].to(torch.int64) & 0xFFFFFFFF).float().mean()),
+                                          float((out["cigar_lens2"].to(torch.int64) & 0xFFFFFFFF).float().mean())],
                       "opposite_mate_effective_gcups": cells / (opp_ms * 1e-3) / 1e9 if opp_ms else None,
                       "stage_ms": stage}), flush=True)
 

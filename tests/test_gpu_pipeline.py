@@ -135,13 +135,17 @@ def test_paired_end_equals_cpu_path(amd, orc):
     m2[-30:] = rng.integers(0, 4, (30, M))                                                    # mates that belong nowhere
     params = pipeline.SeedExtendParams.end_to_end()
     want = cpu_pipeline.paired_end_cpu(orc, hidx, text, G, m1, m2, oracle.Scheme(0, 6, 6, -8, -3, -8, -3), params.min_score_for,
-                                       oracle.SEMI_GLOBAL)
+                                       oracle.SEMI_GLOBAL, cigar_stride=24)
     g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
     b1 = pipeline.ReadBatch(torch.from_numpy(orc.pack4(m1.reshape(-1)).view(np.int32)).cuda(), R, M)
     b2 = pipeline.ReadBatch(torch.from_numpy(orc.pack4(m2.reshape(-1)).view(np.int32)).cuda(), R, M)
-    got = pipeline.paired_end(fmi, g_dev, G, b1, b2, params)
-    for k in ("anchor", "pair_score", "score1", "score2", "pos1", "pos2", "rc1", "rc2"):
+    got = pipeline.paired_end(fmi, g_dev, G, b1, b2, params, cigar_stride=24)
+    for k in ("anchor", "pair_score", "score1", "score2", "pos1", "pos2", "rc1", "rc2", "begin1", "begin2"):
         assert np.array_equal(got[k].cpu().numpy().astype(np.int64), want[k].astype(np.int64)), k
+    for m in (1, 2):        # CIGARs of both mates of every chosen pair (anchor: banded traceback, opposite: full matrix)
+        assert np.array_equal(amd.u32(got["cigar_lens%d" % m]), want["cigar_lens%d" % m]), m
+        assert np.array_equal(got["cigars%d" % m].cpu().numpy().view(np.uint16), want["cigars%d" % m]), m
+    assert int(want["cigar_lens1"].max()) <= 24 and (want["cigar_lens2"][want["anchor"] >= 0] >= 1).all()
     paired = want["anchor"] >= 0
     assert paired[:-30].mean() > 0.97 and not paired[-30:].any()
     # concordant FR pairs: opposite strands, ends within the fragment
