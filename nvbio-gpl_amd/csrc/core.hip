@@ -45,14 +45,15 @@ nvbio_status use_device(int device)
     }
     // Scratch (boundary columns, direction vectors, scan temporaries) comes from the device's stream-ordered
     // pool.  By default the pool hands freed blocks back to the driver at every synchronisation, which makes
-    // each call pay for mapping gigabytes again (measured: 1.4 s per 16 GiB); let it keep up to 24 GiB.
+    // each call pay for mapping gigabytes again (measured: 1.4 s per 16 GiB); let it keep up to 48 GiB (a paired-end
+    // step holds a scoring column, a banded and a full-matrix direction scratch at once).
     static bool pool_ready[64] = { false };
     if (device < 64 && !pool_ready[device])
     {
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool( &pool, device ) == hipSuccess)
         {
-            uint64_t keep = 24ull << 30;
+            uint64_t keep = 48ull << 30;
             (void)hipMemPoolSetAttribute( pool, hipMemPoolAttrReleaseThreshold, &keep );
         }
         pool_ready[device] = true;

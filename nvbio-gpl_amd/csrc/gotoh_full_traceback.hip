@@ -392,7 +392,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     {
         cap_jobs = shortcut ? ((uint64_t)b.n + 3u) / 4u : b.n;
         if (cap_jobs < 16384u) cap_jobs = b.n < 16384u ? b.n : 16384u;
-        const uint64_t budget = 16ull << 30;
+        const uint64_t budget = 8ull << 30;
         if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
         if (cap_jobs < 64) cap_jobs = 64;
         if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
