@@ -353,6 +353,30 @@ struct BatchedBandedAlignmentTraceback
     }
 };
 
+// aln::BatchedAlignmentTraceback<CHECKPOINTS,stream,scheduler> (nvbio/alignment/batched.h:395-411): full-matrix traceback
+// of a FlatTracebackStream (x = text, y = pattern); CHECKPOINTS accepted and ignored as for the banded class
+template <uint32_t CHECKPOINTS, typename stream_type, typename scheduler = AmdDeviceScheduler>
+struct BatchedAlignmentTraceback
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64_t min_temp_storage(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t stream_size)
+    {
+        uint64_t bytes = 0; nvbio_alignment_batch b = {}; b.n = stream_size;
+        check( nvbio_full_gotoh_traceback_temp_bytes( &b, max_pattern_len, max_text_len, &bytes ) );
+        return bytes;
+    }
+    static uint64_t max_temp_storage(uint32_t p, uint32_t t, uint32_t n) { return min_temp_storage( p, t, n ); }
+    void enact(stream_type stream, uint32_t max_pattern_len, uint32_t max_text_len, uint64_t temp_size = 0u, uint8_t* temp = nullptr,
+               int device = 0, hipStream_t s = 0, const int32_t* min_scores_dev = nullptr)
+    {
+        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
+        check( nvbio_full_gotoh_traceback( device, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(), max_pattern_len, max_text_len,
+                                           min_scores_dev, stream.scores(), stream.sources(), stream.sinks(), stream.cigars(),
+                                           stream.cigar_stride(), stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
+                                           temp, temp_size, s ) );
+    }
+};
+
 // convenience function (nvbio/alignment/batched.h:185): banded scores of a flat batch
 template <uint32_t BAND_LEN, typename aligner_type>
 void batch_banded_alignment_score(const aligner_type& aligner, const nvbio_alignment_batch& batch,
