@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-direct", action="store_true", help="plain match() + locate() instead of the fused direct-position seed pass")
+    ap.add_argument("--no-plain-ab", action="store_true", help="skip the (untimed) run through the plain operators without the two exact shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
@@ -260,6 +261,27 @@ def main():
         torch.cuda.synchronize()
         nt.append(a_ev.elapsed_time(b_ev))
     no_table_ms = float(np.mean(nt))
+
+    # ---- the same step through the plain operators (outside the timed region): match() + locate() without the fused
+    #      direct-position seed pass, and the banded DP for every candidate without the ungapped shortcut.  Results are
+    #      identical by construction (and by test); the stage times show what the two exact shortcuts buy. ----
+    plain = {}
+    if not args.no_plain_ab:
+        prev_direct = params.direct
+        params.direct = False
+        os.environ["NVBIO_AMD_NO_UNGAPPED_SCORE"] = "1"
+        pipeline.seed_and_extend(fmi, genome, n, batch, params, None)                 # warm
+        pt = {}
+        torch.cuda.synchronize(); p0 = time.perf_counter()
+        pbs, pbp, pbrc, pnc = pipeline.seed_and_extend(fmi, genome, n, batch, params, pt)
+        torch.cuda.synchronize(); pdt = time.perf_counter() - p0
+        del os.environ["NVBIO_AMD_NO_UNGAPPED_SCORE"]
+        params.direct = prev_direct
+        pst = {k: float(np.mean(event_ms(v))) for k, v in pt.items()}
+        plain = {"ms_per_step": pdt * 1e3, "match_ms_per_launch": 0.5 * (pst.get("match_fw", 0.0) + pst.get("match_rc", 0.0)),
+                 "locate_ms_per_launch": pst.get("locate", 0.0), "extend_ms": pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0),
+                 "extend_gcups": float(pnc) * params.band * M / ((pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0)) * 1e-3) / 1e9,
+                 "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
     match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
     achieved = alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
     use_direct = bool(params.direct and fmi.supports_direct())
@@ -311,6 +333,7 @@ def main():
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
         "traceback": tb_info,
+        "plain_operators": plain or None,
     }
 
     # ---- CPU baseline on a bounded sample of the same reads, all host cores ------------------------
