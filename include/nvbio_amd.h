@@ -389,6 +389,20 @@ nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, c
                                         uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
                                         uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* nvBowtie finish_alignment (nvBowtie/bowtie2/cuda/traceback_inl.h:536-705) for a batch that has been traced back by
+ * either traceback call: from each job's CIGAR (as written by the traceback: backtracking order), its read as aligned and
+ * its text window,
+ *   ed_dev[i]   = edit distance (mismatches + inserted + deleted symbols; soft clips not counted), the NM of the alignment
+ *                 (0 when nothing was traced, 0xFFFFFFFF when the CIGAR had been truncated to cigar_stride);
+ *   mds_dev     (optional) = the MDS byte stream nvBowtie keeps per read (nvbio/io/alignments.h:37-43): 2 length bytes, then
+ *                 [MDS_MATCH, run <= 255] / [MDS_MISMATCH, read symbol] / [MDS_INSERTION | MDS_DELETION, length, symbols...]
+ *                 (soft clips are recorded as insertions, as the reference does); mds_lens_dev[i] = its length (bytes beyond
+ *                 mds_stride are dropped, the count is not).
+ * sources_dev = Alignment::source of the traceback (source.x = where the alignment starts in the text window). */
+nvbio_status nvbio_finish_alignment(int device, const nvbio_alignment_batch* batch, const nvbio_uint2* sources_dev,
+                                    const uint16_t* cigars_dev, uint32_t cigar_stride, const uint32_t* cigar_lens_dev,
+                                    uint32_t* ed_dev, uint8_t* mds_dev, uint32_t mds_stride, uint32_t* mds_lens_dev, void* stream);
+
 /* full-matrix Gotoh: aln::alignment_score / BatchedAlignmentScore (nvbio/alignment/gotoh/gotoh_inl.h:444-1256,
  * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default
  * PatternBlockingTag; min_scores_dev (optional) enables the reference's stripe early exit.

@@ -568,6 +568,20 @@ class BatchedAlignmentTraceback:
         return scores, sources, sinks, cigars, lens
 
 
+def finish_alignment(batch, sources, cigars, cigar_lens, mds_stride=0):
+    """nvBowtie finish_alignment (traceback_inl.h:536-705) on the outputs of a traceback: (ed, mds, mds_lens) --
+    edit distance per job and, with mds_stride > 0, the MDS byte streams [n, mds_stride]"""
+    torch = _torch()
+    n, dev = batch.n, batch.device
+    ed = torch.empty(n, dtype=torch.int32, device=dev)
+    mds = torch.zeros((n, mds_stride), dtype=torch.uint8, device=dev) if mds_stride else None
+    ml = torch.empty(n, dtype=torch.int32, device=dev) if mds_stride else None
+    bs = batch.c_struct()
+    _check(lib().nvbio_finish_alignment(FMIndex._dev_index(dev), ctypes.byref(bs), _ptr(sources), _ptr(cigars), ctypes.c_uint32(cigars.shape[1]),
+                                        _ptr(cigar_lens), _ptr(ed), _ptr(mds), ctypes.c_uint32(mds_stride), _ptr(ml), _stream_ptr(dev)))
+    return ed, mds, ml
+
+
 def cigar_string(cigar_row, length, forward=True):
     """render one alignment's io::Cigar elements ('3M2D147M'); forward=True reverses the backtracking order"""
     els = [int(c) & 0xFFFF for c in cigar_row[:length]]

@@ -289,10 +289,98 @@ ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint3
     cigar_lens[job] = clen;
 }
 
+// ---- finish_alignment: edit distance + MDS byte stream of a traced alignment (nvBowtie traceback_inl.h:536-705) --------
+template <int RBITS, int TBITS>
+__global__ void __launch_bounds__(256)
+finish_alignment_kernel(const BatchDev b, const uint2* __restrict__ sources, const uint16_t* __restrict__ cigars, const uint32_t cigar_stride,
+                        const uint32_t* __restrict__ cigar_lens, uint32_t* __restrict__ ed_out,
+                        uint8_t* __restrict__ mds, const uint32_t mds_stride, uint32_t* __restrict__ mds_lens)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t clen = cigar_lens[job];
+    if (clen == 0u || clen > cigar_stride || sources[job].x == 0xFFFFFFFFu)     // nothing traced, or a truncated CIGAR
+    {
+        ed_out[job] = (clen > cigar_stride && clen != 0u) ? 0xFFFFFFFFu : 0u;
+        if (mds_lens) mds_lens[job] = 0u;
+        return;
+    }
+    const JobInfo J = load_job( b, job );
+    SymbolReader<TBITS> trd( b.text );
+    SymbolReader<RBITS> prd( b.reads );
+    const uint16_t* cig = cigars + (size_t)job * cigar_stride;
+    uint8_t* out = mds ? mds + (size_t)job * mds_stride : nullptr;
+
+    uint32_t mds_len = 2u, ed = 0u, mds_op = 4u;                 // MDS_INVALID
+    uint32_t last_run = 0u, last_run_at = 0u;                    // the open MDS_MATCH run lives in a register, written when it closes
+    auto put = [&](const uint32_t v) { if (out && mds_len < mds_stride) out[mds_len] = (uint8_t)v; ++mds_len; };
+    auto close_run = [&]() { if (last_run && out && last_run_at < mds_stride) out[last_run_at] = (uint8_t)last_run; last_run = 0u; };
+
+    uint32_t j = 0u, k = sources[job].x;
+    for (uint32_t i = 0; i < clen; ++i)
+    {
+        const uint32_t el = cig[clen - i - 1u];
+        const uint32_t l = el >> 2, t = el & 3u;
+        if (t != 0u) { close_run(); mds_op = (t == 2u) ? 3u : 2u; put( mds_op ); put( l ); }
+        for (uint32_t n = 0; n < l; ++n)
+        {
+            if (t != 2u) ++j;
+            if (t == 0u || t == 2u) ++k;
+            uint32_t readc = 255u, refc = 255u;
+            if (t != 2u && j <= J.M)
+            {
+                readc = prd.get( J.rev ? J.first + J.M - j : J.first + j - 1u );
+                if (J.comp && readc < 4u) readc = 3u - readc;
+            }
+            if ((t == 0u || t == 2u) && k <= J.N) refc = trd.get( J.tb + k - 1u );
+            if (t == 0u)
+            {
+                if (readc == refc)
+                {
+                    if (mds_op == 0u && last_run < 255u) ++last_run;
+                    else { close_run(); mds_op = 0u; put( 0u ); last_run_at = mds_len; last_run = 1u; put( 1u ); }
+                }
+                else { close_run(); mds_op = 1u; put( 1u ); put( readc ); ++ed; }
+            }
+            else
+            {
+                put( t == 2u ? refc : readc );
+                if (t != 3u) ++ed;
+            }
+        }
+    }
+    close_run();
+    if (out && mds_stride >= 2u) { out[0] = (uint8_t)(mds_len & 0xFFu); out[1] = (uint8_t)(mds_len >> 8); }
+    ed_out[job] = ed;
+    if (mds_lens) mds_lens[job] = mds_len;
+}
+
 } // anonymous namespace
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_finish_alignment(int device, const nvbio_alignment_batch* batch, const nvbio_uint2* sources_dev,
+                                               const uint16_t* cigars_dev, uint32_t cigar_stride, const uint32_t* cigar_lens_dev,
+                                               uint32_t* ed_dev, uint8_t* mds_dev, uint32_t mds_stride, uint32_t* mds_lens_dev, void* stream)
+{
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( sources_dev && cigars_dev && cigar_lens_dev && ed_dev, "NULL device pointer" );
+    NVB_REQUIRE( mds_dev == nullptr || (mds_stride >= 2 && mds_lens_dev != nullptr), "mds_dev needs mds_stride >= 2 and mds_lens_dev" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
+    const uint32_t rb = batch->read_bits, tbits = batch->text_bits;
+    hipStream_t s = (hipStream_t)stream;
+#define NVB_FIN(RB, TB) hipLaunchKernelGGL( (finish_alignment_kernel<RB,TB>), grid, block, 0, s, b, (const uint2*)sources_dev, cigars_dev, cigar_stride, \
+                                            cigar_lens_dev, ed_dev, mds_dev, mds_stride, mds_lens_dev )
+    if      (rb == 4 && tbits == 2) NVB_FIN( 4, 2 ); else if (rb == 2 && tbits == 2) NVB_FIN( 2, 2 );
+    else if (rb == 8 && tbits == 2) NVB_FIN( 8, 2 ); else if (rb == 8 && tbits == 8) NVB_FIN( 8, 8 );
+    else if (rb == 4 && tbits == 8) NVB_FIN( 4, 8 ); else NVB_FIN( 2, 8 );
+#undef NVB_FIN
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
 
 static inline uint64_t full_tb_bytes_per_job(const uint32_t max_M, const uint32_t max_N)
 {

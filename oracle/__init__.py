@@ -296,6 +296,18 @@ class Oracle:
             _p(sinks, _u32p), cigars.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cigar_stride), _p(lens, _u32p))
         return scores, sources, sinks, cigars, lens
 
+    def finish_alignment(self, pat, txt, cigar, cigar_offset, cap=1024):
+        """nvBowtie finish_alignment: (edit distance, MDS bytes) of a traced alignment"""
+        pat, txt = _c8(pat), _c8(txt)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint16)
+        ed = ctypes.c_uint32(); ml = ctypes.c_uint32()
+        mds = np.zeros(cap, dtype=np.uint8)
+        self.lib.orc_finish_alignment(_p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)),
+                                      cigar.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(cigar)), ctypes.c_uint32(cigar_offset),
+                                      ctypes.byref(ed), _p(mds, _u8p), ctypes.c_uint32(cap), ctypes.byref(ml))
+        assert ml.value <= cap
+        return ed.value, mds[:ml.value].copy()
+
     def full_gotoh_traceback(self, typ, scheme, pat, txt, quals=None, min_score=SCORE_MIN, cap=4096):
         """-> (traced, score, source, sink, cigar uint16[]) -- x = text, y = pattern; cigar in backtracking order"""
         pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)

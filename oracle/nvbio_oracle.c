@@ -857,6 +857,55 @@ int orc_full_gotoh_traceback(int type, const orc_gotoh_scheme* sc,
     return 1;
 }
 
+/* nvBowtie finish_alignment (nvBowtie/bowtie2/cuda/traceback_inl.h:536-705): from the CIGAR (stored backwards, as the
+ * Backtracker leaves it), the read as aligned and the text window, the edit distance (mismatches + inserted + deleted
+ * symbols; soft clips excluded) and the MDS byte stream: two length bytes, then tokens -- [MDS_MATCH 0, run <= 255],
+ * [MDS_MISMATCH 1, read symbol], [MDS_INSERTION 2 | MDS_DELETION 3, length, symbols...] (soft clips are recorded as
+ * insertions, :577-583).  cigar_offset = Alignment::source.x, where the alignment starts in the text window.
+ * nvBowtie's device code cannot be compiled here: this restatement is pinned by its definition only. */
+void orc_finish_alignment(const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                          const uint16_t* cigar, uint32_t cigar_len, uint32_t cigar_offset,
+                          uint32_t* ed_out, uint8_t* mds, uint32_t mds_cap, uint32_t* mds_len_out)
+{
+    uint32_t mds_len = 2, ed = 0; uint8_t mds_op = 4;                       /* MDS_INVALID */
+#define MDS_PUT(v_) do { if (mds && mds_len < mds_cap) mds[mds_len] = (uint8_t)(v_); ++mds_len; } while (0)
+    uint32_t j = 0, k = cigar_offset;
+    for (uint32_t i = 0; i < cigar_len; ++i)
+    {
+        const uint32_t l = cigar[cigar_len - i - 1u] >> 2, t = cigar[cigar_len - i - 1u] & 3u;
+        if (t != 0u)                                                        /* insertion 1, deletion 2, clip 3 */
+        {
+            mds_op = (t == 2u) ? 3 : 2;
+            MDS_PUT( mds_op ); MDS_PUT( l );
+        }
+        for (uint32_t n = 0; n < l; ++n)
+        {
+            if (t != 2u) ++j;                                               /* substitution, insertion, clip consume the read */
+            if (t == 0u || t == 2u) ++k;                                    /* substitution, deletion consume the text */
+            const uint8_t readc = (j > 0 && j <= M) ? pat[j-1] : 255u;
+            const uint8_t refc  = (k > 0 && k <= N) ? txt[k-1] : 255u;
+            if (t == 0u)
+            {
+                if (readc == refc)
+                {
+                    if (mds_op == 0 && mds && mds_len - 1u < mds_cap && mds[mds_len-1] < 255) mds[mds_len-1]++;
+                    else if (mds_op == 0 && !mds) { /* length-only pass: runs cannot be tracked without storage */ }
+                    else { mds_op = 0; MDS_PUT( 0 ); MDS_PUT( 1 ); }
+                }
+                else { mds_op = 1; MDS_PUT( 1 ); MDS_PUT( readc ); ++ed; }
+            }
+            else
+            {
+                MDS_PUT( t == 2u ? refc : readc );
+                if (t != 3u) ++ed;
+            }
+        }
+    }
+#undef MDS_PUT
+    if (mds && mds_cap >= 2) { mds[0] = (uint8_t)(mds_len & 0xFF); mds[1] = (uint8_t)(mds_len >> 8); }
+    *ed_out = ed; *mds_len_out = mds_len;
+}
+
 void orc_banded_gotoh_batch(uint32_t band, int type, const orc_gotoh_scheme* s,
                             const uint8_t* pats, const uint8_t* quals, const uint32_t* po,
                             const uint8_t* txts, const uint32_t* to, uint32_t n,

@@ -148,6 +148,13 @@ void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_
                                    uint32_t n, int32_t* scores, uint32_t* sources, uint32_t* sinks,
                                    uint16_t* cigars, uint32_t cigar_stride, uint32_t* cigar_lens);
 
+/* nvBowtie finish_alignment (traceback_inl.h:536-705): edit distance and MDS byte stream of a traced alignment;
+ * pat = the read as aligned, txt = the text window, cigar in backtracking order, cigar_offset = source.x.
+ * mds needs mds_cap >= the stream's length for exact output (match runs are extended in place). */
+void orc_finish_alignment(const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                          const uint16_t* cigar, uint32_t cigar_len, uint32_t cigar_offset,
+                          uint32_t* ed, uint8_t* mds, uint32_t mds_cap, uint32_t* mds_len);
+
 /* full-matrix Gotoh traceback: aln::alignment_traceback (nvbio/alignment/alignment_inl.h:355-455, walk
  * gotoh/gotoh_inl.h:1573-1640) through nvBowtie's run-length Backtracker; x = text, y = pattern; cigar as in
  * orc_banded_gotoh_traceback.  Returns 1 if an alignment was traced, 0 if nothing was reported. */

@@ -132,6 +132,28 @@ def test_traceback_packed_batch_vs_oracle(amd, orc, typ, tb_mode):
             assert np.array_equal(amd.u32(src), want[1]) and np.array_equal(amd.u32(ln), want[4])
             assert np.array_equal(cig.cpu().numpy().view(np.uint16), want[3]), (sv, use_q)
     assert (want[4] > 3).any() and (want[4] == 0).any()           # gapped alignments and untraceable jobs are both in
+    # finish_alignment on the last traceback: edit distance and MDS stream of every job (nvBowtie traceback_inl.h:536-705)
+    ed, mds, ml = amd.finish_alignment(batch, src, cig, ln, mds_stride=96)
+    ed, mds, ml = amd.u32(ed), mds.cpu().numpy(), amd.u32(ml)
+    lens_h = amd.u32(ln); src_h = amd.u32(src); cig_h = cig.cpu().numpy().view(np.uint16); sc_h = sc.cpu().numpy()
+    checked = 0
+    for k, j in enumerate(sel):
+        if lens_h[k] == 0:
+            assert ed[k] == 0 and ml[k] == 0
+            continue
+        r = rid[j]; p = flat[roffs[r]:roffs[r + 1]]
+        if flags[j] & 1:
+            p = p[::-1]
+        if flags[j] & 2:
+            p = np.where(p < 4, 3 - p, p).astype(np.uint8)
+        wed, wmds = orc.finish_alignment(p, text[wb[j]:we[j]], cig_h[k, :lens_h[k]], int(src_h[k, 0]))
+        assert ed[k] == wed and ml[k] == len(wmds), (k, j)
+        assert np.array_equal(mds[k, :min(ml[k], 96)], wmds[:96]), (k, j)
+        checked += 1
+        if typ == oracle.SEMI_GLOBAL and not use_q and sv == (1, 3, 3, -11, -4, -6, -2) and lens_h[k] == 1:
+            # an ungapped end-to-end alignment: score = matches - 3 mismatches
+            assert sc_h[k] == (len(p) - wed) * 1 - 3 * wed
+    assert checked > 5000
 
 
 def test_traceback_argument_errors(amd, orc):
