@@ -1,0 +1,38 @@
+"""GPU: bench.py keeps its output contract -- one JSON line with the driver's fields, the roofline of the seed-pass
+kernel, the CPU baseline (checked equal to the GPU results) and the untimed A/B through the plain operators -- on a
+small custom workload (the default one needs a 3 Gbp index)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ref-len", "4e6", "--reads", "40000", "--steps", "2",
+                          "--warmup", "1", "--kmer", "9", "--cpu-sample", "5000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "custom" and d["config"]["reads_per_gpu"] == 40000
+    assert abs(d["value"] - 40000 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["results_equal_gpu"] is True and c["cores"] >= 1
+    assert d["plain_operators"]["results_equal"] is True
+    assert d["traceback"]["scores_equal_scoring_pass"] is True
+    assert d["aligned_fraction"] > 0.99 and d["correct_locus_fraction"] > 0.98
