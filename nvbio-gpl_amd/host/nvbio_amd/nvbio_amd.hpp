@@ -128,6 +128,12 @@ public:
         const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u, 0u };
         check( nvbio_fm_index_build( text2_dev, length, device, &opts, stream, &m_h ) );
     }
+    // load the reference's on-disk index files (<prefix>.bwt / .sa as written by nvBWT, read by io::FMIndexDataHost::load,
+    // nvbio/io/fmindex/fmindex_impl.cu:111-252); sa_path may be NULL
+    fm_index(const char* bwt_path, const char* sa_path, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
+        : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_load( bwt_path, sa_path, device, kmer_len, stream, &m_h ) ); }
+    void save(const char* bwt_path, const char* sa_path = nullptr, hipStream_t stream = 0) const { check( nvbio_fm_index_save( m_h, bwt_path, sa_path, stream ) ); }
+    bool supports_direct() const { int yes = 0; check( nvbio_fm_index_supports_direct( m_h, &yes ) ); return yes != 0; }
     fm_index(const fm_index&) = delete;
     fm_index& operator=(const fm_index&) = delete;
     ~fm_index() { if (m_h) (void)nvbio_fm_index_destroy( m_h ); }
