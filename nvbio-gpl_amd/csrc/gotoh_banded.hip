@@ -166,13 +166,15 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 16-bit packed variant for the production case (band 31, LOCAL): one lane owns TWO alignments,
-// one in each half of every register, so H[31]/F[31] of both take the registers one alignment
-// took before and every add / max is a v_pk_*_i16 doing two cells.  Exactness conditions,
-// checked on the host (else the int32 kernel runs): all LOCAL scores fit 10 bits
-// (match * max_read_len <= 1000, so that (score << 5 | column) fits an int16) and penalties are
-// < 4096, so that the -16384 stand-in for the reference's infimum can never win a max against a
-// real score nor wrap.  The row-0 / column-30 infimum cells behave exactly as in the int32 kernel.
+// 16-bit packed variant for the production case (band 31, any alignment type): one lane owns TWO
+// alignments, one in each half of every register, so H[31]/F[31] of both take the registers one
+// alignment took before and every add / max is a v_pk_*_i16 doing two cells.  Exactness conditions,
+// checked on the host (packed_ok; else the int32 kernel runs): LOCAL scores fit 10 bits
+// (match * max_read_len <= 1000, so that (score << 5 | column) fits an int16), GLOBAL / SEMI_GLOBAL
+// scores stay within +-8000 ((max_read_len + 32) * largest step), and penalties are < 4096, so that
+// the -16384 stand-in for the reference's infimum can never win a max against a real score nor
+// wrap.  The row-0 / column-30 infimum cells behave exactly as in the int32 kernel.  With a job
+// list (the jobs the ungapped shortcut could not settle) lane p works on list entries 2p, 2p+1.
 // ---------------------------------------------------------------------------------------------
 typedef short    v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
