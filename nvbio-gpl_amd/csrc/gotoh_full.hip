@@ -512,8 +512,7 @@ full_gotoh_pb_pk_kernel(const BatchDev b, const SchemeDev sc, const uint32_t M, 
     const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
     const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
     const v2s GO = pk( G_o, G_o ), GE = pk( G_e, G_e );
-    const int gm = G_o > G_e ? G_o : G_e;
-    const v2s GM = pk( gm, gm ), INF = pk( infimum, infimum ), ZERO = pk( 0, 0 ), K16 = pk( 16, 16 );
+    const v2s INF = pk( infimum, infimum ), ZERO = pk( 0, 0 ), K16 = pk( 16, 16 );
     const int32_t V = sc.match;
 
     uint2* col = column + t;                                    // element i at col[i * pairs]: (cell of job 0, cell of job 1)
