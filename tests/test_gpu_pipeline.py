@@ -49,7 +49,7 @@ def test_pipeline_seed_hit_cap_on_repeats(amd, orc):
     fmi.close()
 
 
-@pytest.mark.parametrize("mode", ["local", "e2e", "fmmap-ed"])
+@pytest.mark.parametrize("mode", ["local", "e2e", "e2e-quals", "fmmap-ed"])
 def test_pipeline_equals_cpu_path(amd, orc, mode):
     import torch
     pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
@@ -73,6 +73,11 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     if mode == "local":
         params = pipeline.SeedExtendParams()
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, traceback_stride=24)
+    elif mode == "e2e-quals":                             # end-to-end with the quality ramp (mismatch -2..-6 by base quality)
+        quals = rng.integers(0, 50, R * M, dtype=np.uint8)
+        params = pipeline.SeedExtendParams.end_to_end(constant_quality=False)
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
+                                                scheme=oracle.Scheme(0, 2, 6, -8, -3, -8, -3), quals=quals, traceback_stride=24)
     elif mode == "fmmap-ed":                              # examples/fmmap: semi-global edit distance (fmmap.cu:346-359)
         params = pipeline.SeedExtendParams(aln_type=oracle.SEMI_GLOBAL, scheme=amd.EditDistanceScheme(), min_score=-15)
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
@@ -82,7 +87,8 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
                                                 scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3), traceback_stride=24)
         assert params.min_score_for(150) == -90
-    rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
+    rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M,
+                            quals=torch.from_numpy(quals).cuda() if mode == "e2e-quals" else None)
     g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
     bs, bp, brc, nc, bwb, bg = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, return_windows=True)
     assert want[3] <= nc <= want[3] * 1.10           # adjacent-duplicate removal may keep a few repeats
