@@ -316,6 +316,10 @@ enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };
 nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
                                          const uint32_t* win_begin_dev, uint64_t n, uint64_t* best_dev, void* stream);
 
+/* ... and back: scores_dev[r] (NVBIO_SCORE_MIN without a candidate), end_pos_dev[r] (-1 without), rc_dev[r] from best_dev[r] */
+nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* best_dev, uint32_t n_reads, int32_t* scores_dev,
+                                         int64_t* end_pos_dev, uint8_t* rc_dev, void* stream);
+
 /* Paired-end: the genome window in which the opposite mate of an anchored mate is aligned (full-matrix DP),
  * BestOppositeScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate
  * (alignment_utils.h:52-88).  g_pos = the anchor hit's locus (hit.loc), anchor_rc its strand, anchor = 0 if mate 1 is

@@ -632,6 +632,17 @@ def best_candidate_reduce(keys, scores, sinks, win_begin, best):
     return best
 
 
+def best_candidate_unpack(best):
+    """(score int32, end position int64 or -1, strand uint8) per read from the keys of best_candidate_reduce"""
+    torch = _torch()
+    n, dev = best.shape[0], best.device
+    score = torch.empty(n, dtype=torch.int32, device=dev); pos = torch.empty(n, dtype=torch.int64, device=dev)
+    rc = torch.empty(n, dtype=torch.uint8, device=dev)
+    _check(lib().nvbio_best_candidate_unpack(FMIndex._dev_index(dev), _ptr(best), ctypes.c_uint32(n), _ptr(score), _ptr(pos), _ptr(rc),
+                                             _stream_ptr(dev)))
+    return score, pos, rc
+
+
 PE_POLICY_FF, PE_POLICY_FR, PE_POLICY_RF, PE_POLICY_RR = 0, 1, 2, 3
 
 

@@ -63,6 +63,21 @@ best_candidate_kernel(const uint64_t* __restrict__ keys, const int32_t* __restri
     }
 }
 
+// the per-read selection keys of best_candidate_kernel back into (score, end position, strand); 0 = no candidate
+__global__ void __launch_bounds__(256)
+best_unpack_kernel(const unsigned long long* __restrict__ best, const uint32_t n, int32_t* __restrict__ score, int64_t* __restrict__ pos,
+                   uint8_t* __restrict__ rc)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const unsigned long long k = best[i];
+        const int64_t sv = (int64_t)(k >> 34);
+        score[i] = (k && sv > 0) ? (int32_t)(sv - (1ll << 20)) : NVBIO_SCORE_MIN;
+        pos[i]   = k ? (int64_t)(k & ((1ull << 33) - 1ull)) : -1ll;
+        rc[i]    = k ? (uint8_t)((k >> 33) & 1ull) : (uint8_t)0;
+    }
+}
+
 // opposite-mate window of a paired-end alignment: BestOppositeScoreStream::init_context
 // (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate (alignment_utils.h:52-88)
 __global__ void __launch_bounds__(256)
@@ -166,6 +181,18 @@ extern "C" nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* 
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipLaunchKernelGGL( best_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
                         keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (unsigned long long*)best_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* best_dev, uint32_t n_reads, int32_t* scores_dev,
+                                                    int64_t* end_pos_dev, uint8_t* rc_dev, void* stream)
+{
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( best_dev && scores_dev && end_pos_dev && rc_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( best_unpack_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream,
+                        (const unsigned long long*)best_dev, n_reads, scores_dev, end_pos_dev, rc_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

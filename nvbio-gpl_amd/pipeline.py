@@ -81,7 +81,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     and best_g[int64 R], that candidate's locus (hit.loc: the diagonal clamped at the genome start), the
     anchor position of paired-end opposite-mate windows."""
     import torch
-    from . import best_candidate_reduce, diagonals_to_windows
+    from . import best_candidate_reduce, best_candidate_unpack, diagonals_to_windows
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
@@ -173,23 +173,16 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         # memory-bound seed pass was measured: the two kernels serialise, 42-44 ms vs 36 ms per step)
         results.append(extend(keys, "_rc" if strand else "_fw"))
 
-    best_score = torch.full((R,), SCORE_MIN, dtype=torch.int32, device=dev)
-    best_pos = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    best_rc = torch.zeros((R,), dtype=torch.uint8, device=dev)
+    # 5. best candidate per read (already reduced into `top` by extend): unpack the keys
+    e = tick("unpack")
+    best_score, best_pos, best_rc = best_candidate_unpack(top)
+    tock(e)
     if n_cand == 0:
         if return_windows:
             none = torch.full((R,), -1, dtype=torch.int64, device=dev)
             return best_score, best_pos, best_rc, 0, none, none.clone()
         return best_score, best_pos, best_rc, 0
 
-    # 5. best candidate per read (already reduced into `top` by extend)
-    e = tick("unpack")
-    has = top > 0
-    sv = top >> 34
-    best_score = torch.where(has & (sv > 0), (sv - SCORE_BIAS).to(torch.int32), best_score)
-    best_pos = torch.where(has, top & ((1 << 33) - 1), best_pos)
-    best_rc = torch.where(has, ((top >> 33) & 1).to(torch.uint8), best_rc)
-    tock(e)
     if return_windows:
         best_wb = torch.full((R,), -1, dtype=torch.int64, device=dev)
         best_g = torch.full((R,), -1, dtype=torch.int64, device=dev)
