@@ -18,6 +18,7 @@
 // wins" rule exactly.  Reads and windows are consumed straight from the packed HBM streams
 // (one dword per 8 read symbols / 16 text symbols).
 #include "gotoh_common.h"
+#include "bitplanes.h"
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
@@ -504,112 +505,14 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     }
     if (M == 0u || M > 161u) { need_dp[job] = 1; return; }      // planes below hold 192 text symbols
 
-    // bit planes: bit i of r* = row i of the pattern (low bit, high bit, "is N"); bit k of t* = text symbol k.
-    // Built a packed word at a time: bit-reverse the big-endian word so that symbol 0 sits lowest, squeeze every
-    // BITS-th bit together (3-4 shift/mask steps), drop the 8 / 16 plane bits at their storage offset, then
-    // shift the 192-bit planes so that bit 0 is row 0 (reversed reads: mirror first).
-    uint64_t rlo[3] = { 0, 0, 0 }, rhi[3] = { 0, 0, 0 }, rn[3] = { 0, 0, 0 }, tlo[4] = { 0, 0, 0, 0 }, thi[4] = { 0, 0, 0, 0 };
+    // bit planes of the read and of the window (bitplanes.h); all loads first, then the bit work
+    uint64_t rlo[3], rhi[3], rn[3], tlo[4], thi[4];
     {
-        constexpr uint32_t RPW = 32u / RBITS;                                   // read symbols per word
-        const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
-        const uint32_t rbase = first & ~(RPW - 1u), roff = first - rbase;
-        const uint32_t rw0 = rbase / RPW, rw_last = (first + M - 1u) / RPW;
-        constexpr int RW = (161 + 15) * RBITS / 32 + 2;                         // words that can hold 161 symbols at any offset
-        // every word is loaded unconditionally (index clamped into the read, so always valid): no branches between the
-        // loads, they all issue back to back; plane bits outside the pattern are masked off below
-        uint32_t rw[RW];
-        #pragma unroll
-        for (int j = 0; j < RW; ++j) { const uint32_t widx = rw0 + (uint32_t)j; rw[j] = rwords[widx < rw_last ? widx : rw_last]; }
-        uint32_t tw[13];
-        {
-            const uint32_t* __restrict__ twords_ = (const uint32_t*)b.text;
-            const uint32_t T_ = N < 192u ? N : 192u;
-            const uint32_t tw0_ = (tb & ~15u) >> 4, tw_last_ = (tb + T_ - 1u) >> 4;
-            #pragma unroll
-            for (int j = 0; j < 13; ++j) { const uint32_t widx = tw0_ + (uint32_t)j; tw[j] = twords_[widx < tw_last_ ? widx : tw_last_]; }
-        }
-        #pragma unroll
-        for (int j = 0; j < RW; ++j)
-        {
-            {
-                const uint32_t w = __brev( rw[j] );
-                uint32_t lo, hi, nn;
-                if (RBITS == 4)
-                {
-                    // after the reversal symbol k holds value bits (b3,b2,b1,b0) at bit positions (4k, 4k+1, 4k+2, 4k+3)
-                    lo = (w >> 3) & 0x11111111u; hi = (w >> 2) & 0x11111111u; nn = ((w >> 1) | w) & 0x11111111u;
-                    lo = (lo | (lo >> 3)) & 0x03030303u; lo = (lo | (lo >> 6)) & 0x000F000Fu; lo = (lo | (lo >> 12)) & 0xFFu;
-                    hi = (hi | (hi >> 3)) & 0x03030303u; hi = (hi | (hi >> 6)) & 0x000F000Fu; hi = (hi | (hi >> 12)) & 0xFFu;
-                    nn = (nn | (nn >> 3)) & 0x03030303u; nn = (nn | (nn >> 6)) & 0x000F000Fu; nn = (nn | (nn >> 12)) & 0xFFu;
-                }
-                else
-                {
-                    lo = (w >> 1) & 0x55555555u; hi = w & 0x55555555u; nn = 0;
-                    lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
-                    hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
-                }
-                constexpr int PB = (int)RPW;                                    // plane bits per word
-                const int bitpos = j * PB;                                      // compile-time: no dynamic plane index
-                if (bitpos < 192)
-                {
-                    rlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
-                    rhi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
-                    rn [bitpos >> 6] |= (uint64_t)nn << (bitpos & 63);
-                }
-            }
-        }
-        // bit p of the planes = storage symbol rbase + p.  Forward: row i = p - roff.  Reversed: row i = roff + M-1 - p.
-        auto shr192 = [](uint64_t (&v)[3], const uint32_t sh) {
-            const uint32_t ws = sh >> 6, bs = sh & 63u;
-            uint64_t x[5] = { v[0], v[1], v[2], 0ull, 0ull };
-            uint64_t y[4];
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = ws == 0u ? x[k] : (ws == 1u ? x[k + 1 < 5 ? k + 1 : 4] : (ws == 2u ? (k + 2 < 5 ? x[k + 2] : 0ull) : 0ull));
-            #pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = bs ? ((y[k] >> bs) | (y[k + 1] << (64u - bs))) : y[k];
-        };
-        auto mirror192 = [](uint64_t (&v)[3]) {
-            const uint64_t a = __brevll( v[2] ), c = __brevll( v[0] );
-            v[1] = __brevll( v[1] ); v[0] = a; v[2] = c;
-        };
-        if (rev)
-        {
-            mirror192( rlo ); mirror192( rhi ); mirror192( rn );               // bit r now = storage symbol rbase + 191 - r
-            const uint32_t sh = 192u - roff - M;                                // row i = bit i + sh
-            shr192( rlo, sh ); shr192( rhi, sh ); shr192( rn, sh );
-        }
-        else { shr192( rlo, roff ); shr192( rhi, roff ); shr192( rn, roff ); }
-        if (comp)                                                               // 3 - q for q < 4: flip both bits of the non-N rows
-        {
-            #pragma unroll
-            for (int k = 0; k < 3; ++k) { rlo[k] ^= ~rn[k]; rhi[k] ^= ~rn[k]; }
-        }
-
-        const uint32_t toff = tb & 15u;
-        #pragma unroll
-        for (int j = 0; j < 13; ++j)
-        {
-            {
-                const uint32_t w = __brev( tw[j] );
-                uint32_t lo = (w >> 1) & 0x55555555u, hi = w & 0x55555555u;
-                lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
-                hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
-                const int bitpos = j * 16;
-                tlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
-                thi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
-            }
-        }
-        // 208 plane bits (13 words) shifted down by toff < 16: bit 0 = text symbol 0 of the window
-        if (toff)
-        {
-            #pragma unroll
-            for (int k = 0; k < 3; ++k)
-            {
-                tlo[k] = (tlo[k] >> toff) | (tlo[k + 1] << (64u - toff));
-                thi[k] = (thi[k] >> toff) | (thi[k + 1] << (64u - toff));
-            }
-            tlo[3] >>= toff; thi[3] >>= toff;
-        }
+        ReadWords<RBITS> rw; TextWords13 tw;
+        load_read_words<RBITS>( b.reads, first, M, rw );
+        load_text_words13( b.text, tb, N < 192u ? N : 192u, tw );
+        read_planes192<RBITS>( rw, first, M, rev, comp, rlo, rhi, rn );
+        text_planes208( tw, tb, tlo, thi );
     }
     uint64_t rmask[3];
     #pragma unroll

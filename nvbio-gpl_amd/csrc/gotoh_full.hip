@@ -15,6 +15,7 @@
 // job-interleaved in HBM (element i of job t at [i * jobs + t]) so that the 64 lanes of a wave
 // read and write 256 contiguous bytes per row.
 #include "gotoh_common.h"
+#include "bitplanes.h"
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
@@ -247,68 +248,12 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     const uint32_t N     = b.win_end[job] - tb;
     if (M == 0u || M > 161u || N < M || N > 528u) { need_dp[job] = 1; return; }
 
-    // ---- pattern planes (as in ungapped_e2e31_kernel): bit i = row i ----
-    uint64_t rlo[3] = { 0, 0, 0 }, rhi[3] = { 0, 0, 0 }, rn[3] = { 0, 0, 0 };
+    // ---- pattern planes (bitplanes.h): bit i = row i ----
+    uint64_t rlo[3], rhi[3], rn[3];
     {
-        constexpr uint32_t RPW = 32u / RBITS;
-        const uint32_t* __restrict__ rwords = (const uint32_t*)b.reads;
-        const uint32_t rbase = first & ~(RPW - 1u), roff = first - rbase;
-        const uint32_t rw0 = rbase / RPW, rw_last = (first + M - 1u) / RPW;
-        constexpr int RW = (161 + 15) * RBITS / 32 + 2;
-        uint32_t rw[RW];
-        #pragma unroll
-        for (int j = 0; j < RW; ++j) { const uint32_t widx = rw0 + (uint32_t)j; rw[j] = rwords[widx < rw_last ? widx : rw_last]; }
-        #pragma unroll
-        for (int j = 0; j < RW; ++j)
-        {
-            const uint32_t w = __brev( rw[j] );
-            uint32_t lo, hi, nn;
-            if (RBITS == 4)
-            {
-                lo = (w >> 3) & 0x11111111u; hi = (w >> 2) & 0x11111111u; nn = ((w >> 1) | w) & 0x11111111u;
-                lo = (lo | (lo >> 3)) & 0x03030303u; lo = (lo | (lo >> 6)) & 0x000F000Fu; lo = (lo | (lo >> 12)) & 0xFFu;
-                hi = (hi | (hi >> 3)) & 0x03030303u; hi = (hi | (hi >> 6)) & 0x000F000Fu; hi = (hi | (hi >> 12)) & 0xFFu;
-                nn = (nn | (nn >> 3)) & 0x03030303u; nn = (nn | (nn >> 6)) & 0x000F000Fu; nn = (nn | (nn >> 12)) & 0xFFu;
-            }
-            else
-            {
-                lo = (w >> 1) & 0x55555555u; hi = w & 0x55555555u; nn = 0;
-                lo = (lo | (lo >> 1)) & 0x33333333u; lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
-                hi = (hi | (hi >> 1)) & 0x33333333u; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
-            }
-            const int bitpos = j * (int)RPW;
-            if (bitpos < 192)
-            {
-                rlo[bitpos >> 6] |= (uint64_t)lo << (bitpos & 63);
-                rhi[bitpos >> 6] |= (uint64_t)hi << (bitpos & 63);
-                rn [bitpos >> 6] |= (uint64_t)nn << (bitpos & 63);
-            }
-        }
-        auto shr192 = [](uint64_t (&v)[3], const uint32_t sh) {
-            const uint32_t ws = sh >> 6, bs = sh & 63u;
-            uint64_t x[5] = { v[0], v[1], v[2], 0ull, 0ull };
-            uint64_t y[4];
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = ws == 0u ? x[k] : (ws == 1u ? x[k + 1 < 5 ? k + 1 : 4] : (ws == 2u ? (k + 2 < 5 ? x[k + 2] : 0ull) : 0ull));
-            #pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = bs ? ((y[k] >> bs) | (y[k + 1] << (64u - bs))) : y[k];
-        };
-        auto mirror192 = [](uint64_t (&v)[3]) {
-            const uint64_t a = __brevll( v[2] ), c = __brevll( v[0] );
-            v[1] = __brevll( v[1] ); v[0] = a; v[2] = c;
-        };
-        if (rev)
-        {
-            mirror192( rlo ); mirror192( rhi ); mirror192( rn );
-            const uint32_t sh = 192u - roff - M;
-            shr192( rlo, sh ); shr192( rhi, sh ); shr192( rn, sh );
-        }
-        else { shr192( rlo, roff ); shr192( rhi, roff ); shr192( rn, roff ); }
-        if (comp)
-        {
-            #pragma unroll
-            for (int k = 0; k < 3; ++k) { rlo[k] ^= ~rn[k]; rhi[k] ^= ~rn[k]; }
-        }
+        ReadWords<RBITS> rw;
+        load_read_words<RBITS>( b.reads, first, M, rw );
+        read_planes192<RBITS>( rw, first, M, rev, comp, rlo, rhi, rn );
     }
     uint32_t pl[6], ph[6], pn[6], pm[6];
     #pragma unroll

@@ -19,6 +19,7 @@
 // The two are identical as long as every score fits the reference's int16 checkpoints, which the
 // host checks from the scheme and the batch's max_read_len (else NVBIO_ERR_UNSUPPORTED).
 #include "gotoh_common.h"
+#include "bitplanes.h"
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
@@ -324,7 +325,37 @@ ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* _
     int32_t  Q = 0;
     uint32_t k = 0;
     bool found = (TYPE == NVBIO_LOCAL) && (best == 0);
-    for (int32_t row = (int32_t)sink.y - 1; row >= 0 && !found; --row)
+    bool counted = false;
+    if (BAND == 31 && TYPE != NVBIO_LOCAL && TBITS == 2 && (RBITS == 2 || RBITS == 4))
+    {
+        // one mismatch penalty for every row and the diagonal inside the text: its score is a popcount over bit planes
+        // (bitplanes.h) instead of a walk symbol by symbol -- the end-to-end case of a read batch
+        const bool const_pen = (b.quals == nullptr) || (sc.mm_min == sc.mm_max);
+        if (const_pen && M > 0u && M <= PLANE_MAX_READ && sink.y == M && (uint64_t)entry + M <= N)
+        {
+            constexpr int RB = (RBITS == 2 || RBITS == 4) ? RBITS : 4;
+            uint64_t rlo[3], rhi[3], rn[3], tlo[4], thi[4];
+            ReadWords<RB> rw; TextWords13 tw;
+            load_read_words<RB>( b.reads, first, M, rw );
+            load_text_words13( b.text, tb, N < 192u ? N : 192u, tw );
+            read_planes192<RB>( rw, first, M, rev, comp, rlo, rhi, rn );
+            text_planes208( tw, tb, tlo, thi );
+            uint32_t cnt = 0;
+            #pragma unroll
+            for (int w = 0; w < 3; ++w)
+            {
+                const int32_t left = (int32_t)M - 64 * w;
+                const uint64_t mask = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+                const uint64_t lo = entry ? ((tlo[w] >> entry) | (tlo[w + 1] << (64u - entry))) : tlo[w];
+                const uint64_t hi = entry ? ((thi[w] >> entry) | (thi[w + 1] << (64u - entry))) : thi[w];
+                cnt += (uint32_t)__popcll( ((rlo[w] ^ lo) | (rhi[w] ^ hi) | rn[w]) & mask );
+            }
+            Q = sc.match * (int32_t)(M - cnt) + s_mm[0] * (int32_t)cnt;          // s_mm[q] is the same for every q here
+            k = M;
+            counted = true;
+        }
+    }
+    for (int32_t row = (int32_t)sink.y - 1; row >= 0 && !found && !counted; --row)
     {
         const uint32_t pidx = rev ? first + M - 1u - (uint32_t)row : first + (uint32_t)row;
         uint32_t q = prd.get( pidx );
