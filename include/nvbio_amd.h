@@ -281,6 +281,15 @@ typedef struct
     int32_t txt_gap_open, txt_gap_ext;
 } nvbio_gotoh_scheme;
 
+/* The linear-gap Smith-Waterman scheme, aln::SimpleSmithWatermanScheme(match, mismatch, deletion, insertion)
+ * (nvbio/alignment/utils.h:81-98), all four as signed scores: `deletion` is charged for a text symbol aligned to no pattern
+ * symbol, `insertion` for a pattern symbol aligned to no text symbol (sw/sw_banded_inl.h:369-370,398-431).  The
+ * edit-distance aligner is this scheme with (0, -1, -1, -1) (EditDistanceSWScheme, ed/ed_utils.h). */
+typedef struct
+{
+    int32_t match, mismatch, deletion, insertion;
+} nvbio_sw_scheme;
+
 #define NVBIO_SCORE_MIN (-(1 << 30))     /* Field_traits<int32>::min(), BestSink's initial score (numbers.h:738-742) */
 
 /* A batch of alignment jobs: the stream concept of aln::Batched[Banded]AlignmentScore
@@ -419,6 +428,24 @@ nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int t
                                     uint32_t max_pattern_len, uint32_t max_text_len,
                                     const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
                                     void* temp_dev, uint64_t temp_bytes, void* stream);
+
+/* The other two aligner families of the reference behind the same batch interface:
+ * aln::SmithWatermanAligner<TYPE, scheme> and aln::EditDistanceAligner<TYPE> (nvbio/alignment/alignment.h:366-401,508-545).
+ *   banded : banded_alignment_score<BAND> -> sw/sw_banded_inl.h:281-520 (the edit-distance aligner runs the same code with
+ *            EditDistanceSWScheme, ed/ed_banded_inl.h:37-69: the aligner of examples/fmmap and of nvBowtie --scoring ed);
+ *   full   : alignment_score -> sw/sw_inl.h:396-1300, ed/ed_inl.h:60-168.  These two families sweep the matrix in stripes of
+ *            16 cells (sw_bandlen_selector, sw/sw_inl.h:1322-1325) where Gotoh uses 8, which decides LOCAL ties and where the
+ *            min-score early exit is tested; both are reproduced.
+ * Arguments, outputs and scratch exactly as nvbio_banded_gotoh_score / nvbio_full_gotoh_score
+ * (nvbio_full_gotoh_temp_bytes sizes the scratch for either).  Qualities are ignored (constant mismatch score). */
+nvbio_status nvbio_banded_sw_score(int device, uint32_t band, nvbio_alignment_type type,
+                                   const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                   int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
+nvbio_status nvbio_full_sw_score(int device, nvbio_alignment_type type, int text_blocking,
+                                 const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                 uint32_t max_pattern_len, uint32_t max_text_len,
+                                 const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                 void* temp_dev, uint64_t temp_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,11 @@ class _Scheme(ctypes.Structure):
                 ("txt_gap_open", ctypes.c_int32), ("txt_gap_ext", ctypes.c_int32)]
 
 
+class _SWScheme(ctypes.Structure):
+    _fields_ = [("match", ctypes.c_int32), ("mismatch", ctypes.c_int32), ("deletion", ctypes.c_int32),
+                ("insertion", ctypes.c_int32)]
+
+
 class _Batch(ctypes.Structure):
     _fields_ = [("reads_dev", ctypes.c_void_p), ("read_bits", ctypes.c_uint32),
                 ("read_offsets_dev", ctypes.c_void_p), ("quals_dev", ctypes.c_void_p),
@@ -423,10 +428,35 @@ def EditDistanceScheme():
     return GotohScheme(0, 1, 1, -1, -1, -1, -1)
 
 
+class SimpleSmithWatermanScheme:
+    """aln::SimpleSmithWatermanScheme(match, mismatch, deletion, insertion) (nvbio/alignment/utils.h:81-98), signed scores"""
+
+    def __init__(self, match, mismatch, deletion, insertion):
+        self.c = _SWScheme(match, mismatch, deletion, insertion)
+
+
+class SmithWatermanAligner:
+    """aln::SmithWatermanAligner<TYPE, scheme> (nvbio/alignment/alignment.h:508-545): linear gaps.  `.sw` is what the
+    scoring entry points take (nvbio_banded_sw_score / nvbio_full_sw_score); `.scheme` is the Gotoh form with open =
+    extension, which exists when deletion == insertion and is what the banded traceback takes."""
+
+    def __init__(self, type, scheme):
+        self.type, self.sw = type, scheme
+        c = scheme.c
+        self.scheme = (GotohScheme(c.match, -c.mismatch, -c.mismatch, c.deletion, c.deletion, c.deletion, c.deletion)
+                       if c.deletion == c.insertion else None)
+
+
+def make_smith_waterman_aligner(type, scheme):
+    """aln::make_smith_waterman_aligner<TYPE>(scheme) (nvbio/alignment/alignment.h:529)"""
+    return SmithWatermanAligner(type, scheme)
+
+
 def make_edit_distance_aligner(type):
-    """aln::make_edit_distance_aligner<TYPE>() (nvbio/alignment/alignment.h:382) for the BANDED scoring / traceback
-    entry points (the aligner of examples/fmmap/fmmap.cu:346-359 and of nvBowtie --scoring ed)"""
-    return GotohAligner(type, EditDistanceScheme())
+    """aln::make_edit_distance_aligner<TYPE>() (nvbio/alignment/alignment.h:382): the Smith-Waterman aligner with
+    EditDistanceSWScheme (0, -1, -1, -1) (ed/ed_utils.h:36-43) -- the aligner of examples/fmmap/fmmap.cu:346-359 and of
+    nvBowtie --scoring ed (banded), and the full-matrix one of ed/ed_inl.h"""
+    return SmithWatermanAligner(type, SimpleSmithWatermanScheme(0, -1, -1, -1))
 
 
 class GotohAligner:
@@ -488,9 +518,11 @@ class BatchedBandedAlignmentScore:
         if sinks is None:
             sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
         bs = batch.c_struct()
-        _check(lib().nvbio_banded_gotoh_score(FMIndex._dev_index(batch.device), ctypes.c_uint32(self.band_len),
-                                              ctypes.c_int(self.aligner.type), ctypes.byref(self.aligner.scheme.c),
-                                              ctypes.byref(bs), _ptr(scores), _ptr(sinks), _stream_ptr(batch.device)))
+        sw = getattr(self.aligner, "sw", None)
+        fn = lib().nvbio_banded_sw_score if sw is not None else lib().nvbio_banded_gotoh_score
+        _check(fn(FMIndex._dev_index(batch.device), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
+                  ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c),
+                  ctypes.byref(bs), _ptr(scores), _ptr(sinks), _stream_ptr(batch.device)))
         return scores, sinks
 
 
@@ -604,12 +636,13 @@ class BatchedAlignmentScore:
             sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
         ms = _dev_tensor(min_scores, torch.int32, batch.device)
         bs = batch.c_struct()
-        _check(lib().nvbio_full_gotoh_score(FMIndex._dev_index(batch.device), ctypes.c_int(self.aligner.type),
-                                            ctypes.c_int(1 if self.text_blocking else 0),
-                                            ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs),
-                                            ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms),
-                                            _ptr(scores), _ptr(sinks), None, ctypes.c_uint64(0),
-                                            _stream_ptr(batch.device)))
+        sw = getattr(self.aligner, "sw", None)
+        fn = lib().nvbio_full_sw_score if sw is not None else lib().nvbio_full_gotoh_score
+        _check(fn(FMIndex._dev_index(batch.device), ctypes.c_int(self.aligner.type),
+                  ctypes.c_int(1 if self.text_blocking else 0),
+                  ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c), ctypes.byref(bs),
+                  ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms),
+                  _ptr(scores), _ptr(sinks), None, ctypes.c_uint64(0), _stream_ptr(batch.device)))
         return scores, sinks
 
 

@@ -71,7 +71,8 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
         else        cache_raw[j] = g;
     }
 
-    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;             // F: the text advances alone
+    const int32_t I_o = sc.ins_go, I_e = sc.ins_ge;             // E: the pattern advances alone (= G for the Gotoh aligner)
     const int32_t infimum = -32768 - max2( max2( G_o, G_e ), max2( sc.txt_go, sc.txt_ge ) );
     const int32_t V = sc.match;
 
@@ -129,7 +130,7 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
                 row_key = max2( row_key, (h << 5) | j );
             }
             H[j] = h;
-            E = (j == 0) ? h + G_o : max2( h + G_o, E + G_e );   // :507,562-565
+            E = (j == 0) ? h + I_o : max2( h + I_o, E + I_e );   // :507,562-565
         }
 
         // shift the cache by one column and append the new symbol (:532,570)
@@ -704,7 +705,7 @@ template <int BAND, int TYPE>
 static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
                                 int32_t* scores, uint2* sinks, hipStream_t s)
 {
-    if (BAND == 31 && packed_ok( TYPE, sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
+    if (BAND == 31 && plain_gotoh( sc ) && packed_ok( TYPE, sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
     {
         if      (rbits == 4 && tbits == 2) return launch_pk<TYPE,4>( b, sc, scores, sinks, s );
         else if (rbits == 2 && tbits == 2) return launch_pk<TYPE,2>( b, sc, scores, sinks, s );
@@ -757,6 +758,20 @@ nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
 
 using namespace nvbio_amd;
 
+static nvbio_status banded_score(int device, uint32_t band, int type, const SchemeDev sc, const BatchDev& b, const nvbio_alignment_batch* batch,
+                                 int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)
+{
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    switch (band)
+    {
+    case 3:  return launch_type<3> ( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
+    case 7:  return launch_type<7> ( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
+    case 15: return launch_type<15>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
+    default: return launch_type<31>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
+    }
+}
+
 extern "C" nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbio_alignment_type type,
                                                  const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
                                                  int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)
@@ -770,15 +785,25 @@ extern "C" nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbi
     }
     if (b.n == 0) return NVBIO_OK;
     NVB_REQUIRE( scores_dev && sinks_dev, "NULL output pointer" );
-    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
-                     scheme->txt_gap_open, scheme->txt_gap_ext };
-    hipStream_t s = (hipStream_t)stream;
-    switch (band)
+    return banded_score( device, band, type, scheme_dev( scheme ), b, batch, scores_dev, sinks_dev, stream );
+}
+
+extern "C" nvbio_status nvbio_banded_sw_score(int device, uint32_t band, nvbio_alignment_type type,
+                                              const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                              int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (band != 3 && band != 7 && band != 15 && band != 31)
     {
-    case 3:  return launch_type<3> ( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
-    case 7:  return launch_type<7> ( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
-    case 15: return launch_type<15>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
-    default: return launch_type<31>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (uint2*)sinks_dev, s );
+        set_error( "band %u is not instantiated (3, 7, 15, 31)", band );
+        return NVBIO_ERR_UNSUPPORTED;
     }
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( scores_dev && sinks_dev, "NULL output pointer" );
+    // in the band the boundary row runs over the text; with deletion == insertion this is Gotoh(open = extension) and takes
+    // the packed kernel and the ungapped shortcut like any other Gotoh scheme
+    SchemeDev sc = scheme_dev( scheme, false );
+    sc.wide = 0;
+    return banded_score( device, band, type, sc, b, batch, scores_dev, sinks_dev, stream );
 }

@@ -77,9 +77,13 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
         qq = b.quals ? b.quals[idx] : 0u;
     };
 
-    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
-    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);   // gotoh_inl.h:634,1038
+    // F runs down the rows of a stripe, E along it: with pattern blocking the rows are text positions (F = the text advancing
+    // alone), with text blocking they are pattern positions.  The Gotoh aligner charges the same terms to both (SchemeDev).
+    const int32_t F_o = TEXT_BLOCKING ? sc.ins_go : sc.pat_go, F_e = TEXT_BLOCKING ? sc.ins_ge : sc.pat_ge;
+    const int32_t E_o = TEXT_BLOCKING ? sc.pat_go : sc.ins_go, E_e = TEXT_BLOCKING ? sc.pat_ge : sc.ins_ge;
+    const int32_t infimum = -32768 - (sc.pat_go < sc.pat_ge ? sc.pat_go : sc.pat_ge);   // gotoh_inl.h:634,1038
     const int32_t V = sc.match;
+    const bool    wide = sc.wide != 0;                          // logical stripes of 16 (the SW / edit-distance aligners)
 
     const uint32_t rows = TEXT_BLOCKING ? M : N;                // length of the boundary column
     const uint32_t cols = TEXT_BLOCKING ? N : M;                // extent the stripes cover
@@ -121,7 +125,7 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
         for (int j = 0; j <= STRIPE; ++j)
         {
             const bool penal = TEXT_BLOCKING ? (TYPE == NVBIO_GLOBAL) : (TYPE != NVBIO_LOCAL);      // :1061-1066 / :676-681
-            H[j] = penal ? ((block + j > 0) ? G_o + G_e * (int32_t)(block + j - 1u) : 0) : 0;
+            H[j] = penal ? ((block + j > 0) ? sc.top_go + sc.top_ge * (int32_t)(block + j - 1u) : 0) : 0;
             F[j] = infimum;
         }
         int32_t max_score = NVBIO_SCORE_MIN;
@@ -141,8 +145,8 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
             #pragma unroll
             for (int j = 1; j <= STRIPE; ++j)
             {
-                F[j] = max2( F[j] + G_e, H[j] + G_o );
-                E    = max2( E + G_e, H[j - 1] + G_o );
+                F[j] = max2( F[j] + F_e, H[j] + F_o );
+                E    = max2( E + E_e, H[j - 1] + E_o );
                 const int32_t S = (c_sym[j - 1] == r_sym) ? V : (TEXT_BLOCKING ? r_mm : c_mm[j - 1]);
                 int32_t hi = max3( E, F[j], H_diag + S );
                 if (TYPE == NVBIO_LOCAL) hi = max2( hi, 0 );
@@ -163,8 +167,16 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
                 if (key >= 0)
                 {
                     const uint32_t j = (uint32_t)(key & 15);
-                    if (TEXT_BLOCKING) sink.report( key >> 4, block + j, i + 1u );
-                    else               sink.report( key >> 4, i + 1u, block + j );
+                    const int32_t  v = key >> 4;
+                    // 16-wide logical stripes report (stripe, row, column)-major while this sweep is 8 wide: a tie with a cell of
+                    // the same logical stripe is won by the later ROW (the column is then larger too), any other tie by the newcomer
+                    const uint32_t b_col = TEXT_BLOCKING ? sink.x : sink.y, b_row = TEXT_BLOCKING ? sink.y : sink.x;
+                    const bool take = !wide || v != sink.score || ((b_col - 1u) >> 4) != (block >> 4) || i + 1u >= b_row;
+                    if (take)
+                    {
+                        if (TEXT_BLOCKING) sink.report( v, block + j, i + 1u );
+                        else               sink.report( v, i + 1u, block + j );
+                    }
                 }
             }
             else if (!TEXT_BLOCKING && last && TYPE == NVBIO_SEMI_GLOBAL)
@@ -186,7 +198,10 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
                 for (int j = 1; j <= STRIPE; ++j) sink.report( H[j], block + j, M );
             }
             const int32_t missing = (int32_t)(cols - block - STRIPE);
-            if (max_score + missing * V < min_score) ok = false;                     // stripe early exit
+            // stripe early exit: after every 8-wide Gotoh stripe; after every 16-wide one for the SW family with pattern
+            // blocking (sw/sw_inl.h:676-680), whose text-blocking sweep has no such test at all (:1063-1115)
+            const bool test = !wide || (!TEXT_BLOCKING && (block & STRIPE));
+            if (test && max_score + missing * V < min_score) ok = false;
         }
         else if (TEXT_BLOCKING)
         {
@@ -668,13 +683,11 @@ extern "C" nvbio_status nvbio_full_gotoh_temp_bytes(const nvbio_alignment_batch*
     return NVBIO_OK;
 }
 
-extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int text_blocking,
-                                               const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
-                                               uint32_t max_pattern_len, uint32_t max_text_len,
-                                               const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
-                                               void* temp_dev, uint64_t temp_bytes, void* stream)
+static nvbio_status full_score(int device, int type, int text_blocking, const SchemeDev sc, const nvbio_alignment_batch* batch,
+                               uint32_t max_pattern_len, uint32_t max_text_len,
+                               const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                               void* temp_dev, uint64_t temp_bytes, void* stream)
 {
-    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
     BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
     if (b.n == 0) return NVBIO_OK;
     NVB_REQUIRE( scores_dev && sinks_dev, "NULL output pointer" );
@@ -682,8 +695,6 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     NVB_REQUIRE( rows > 0, "max_pattern_len / max_text_len must bound the boundary column" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
-                     scheme->txt_gap_open, scheme->txt_gap_ext };
 
     // ---- which jobs need which kernel --------------------------------------------------------------------------
     //  1. end-to-end shortcut (ungapped_full_e2e_kernel): settles the jobs whose best diagonal beats every gapped
@@ -695,8 +706,8 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     uint32_t *list_a = nullptr, *count_a = nullptr, *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
     int32_t P = 0;
     const bool packable_bits = batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2);
-    const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" );
-    const bool packed   = !text_blocking && packable_bits && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
+    const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && plain_gotoh( sc ) && full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" );
+    const bool packed   = !text_blocking && packable_bits && plain_gotoh( sc ) && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
                           !getenv( "NVBIO_AMD_NO_PACKED_DP" );
     if (shortcut || packed)
     {
@@ -805,4 +816,27 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     if (owned) (void)hipFreeAsync( owned, s );
     if (aux)   (void)hipFreeAsync( aux, s );
     return st;
+}
+
+extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int text_blocking,
+                                               const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                               uint32_t max_pattern_len, uint32_t max_text_len,
+                                               const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                               void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    return full_score( device, type, text_blocking, scheme_dev( scheme ), batch, max_pattern_len, max_text_len, min_scores_dev,
+                       scores_dev, sinks_dev, temp_dev, temp_bytes, stream );
+}
+
+extern "C" nvbio_status nvbio_full_sw_score(int device, nvbio_alignment_type type, int text_blocking,
+                                            const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                            uint32_t max_pattern_len, uint32_t max_text_len,
+                                            const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                            void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    // the boundary column runs over the pattern with text blocking, over the text otherwise
+    return full_score( device, type, text_blocking, scheme_dev( scheme, text_blocking != 0 ), batch, max_pattern_len, max_text_len,
+                       min_scores_dev, scores_dev, sinks_dev, temp_dev, temp_bytes, stream );
 }

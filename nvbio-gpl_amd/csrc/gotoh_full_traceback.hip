@@ -423,8 +423,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     }
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    const SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
-                           scheme->txt_gap_open, scheme->txt_gap_ext };
+    const SchemeDev sc = scheme_dev( scheme );
     const uint32_t rb = batch->read_bits, tbits = batch->text_bits;
 
     // ---- 1. scoring pass (pattern blocking) unless handed over; 2. the ungapped shortcut; 3. job list ----

@@ -497,8 +497,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    SchemeDev sc = { scheme->match, scheme->mm_min, scheme->mm_max, scheme->pat_gap_open, scheme->pat_gap_ext,
-                     scheme->txt_gap_open, scheme->txt_gap_ext };
+    SchemeDev sc = scheme_dev( scheme );
 
     // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
     const bool shortcut = !getenv( "NVBIO_AMD_NO_UNGAPPED_TRACEBACK" );

@@ -249,15 +249,55 @@ struct GotohAligner
 template <AlignmentType T, typename scheme_type>
 GotohAligner<T,scheme_type> make_gotoh_aligner(const scheme_type& s) { return GotohAligner<T,scheme_type>( s ); }
 
-// the reference's edit-distance aligner on the banded entry points: EditDistanceSWScheme (match 0, mismatch -1,
-// insertion = deletion = -1; nvbio/alignment/ed/ed_banded_inl.h:37-69) -- with equal open and extension costs the
-// Gotoh recurrences give the same scores and sinks (pinned against the reference: tests/golden/ed_golden.npz)
-struct EditDistanceScheme
+// aln::SimpleSmithWatermanScheme / SmithWatermanAligner (nvbio/alignment/utils.h:81-98, alignment.h:508-545): linear gaps
+struct SimpleSmithWatermanScheme
 {
-    nvbio_gotoh_scheme flat() const { const nvbio_gotoh_scheme s = { 0, 1, 1, -1, -1, -1, -1 }; return s; }
+    SimpleSmithWatermanScheme() {}
+    SimpleSmithWatermanScheme(int32_t match, int32_t mm, int32_t del, int32_t ins)
+        : m_match( match ), m_mismatch( mm ), m_deletion( del ), m_insertion( ins ) {}
+    nvbio_sw_scheme flat_sw() const { return { m_match, m_mismatch, m_deletion, m_insertion }; }
+    // the Gotoh form (open = extension), defined when deletion == insertion: what the banded traceback takes
+    nvbio_gotoh_scheme flat() const { return { m_match, -m_mismatch, -m_mismatch, m_deletion, m_deletion, m_deletion, m_deletion }; }
+    int32_t m_match, m_mismatch, m_deletion, m_insertion;
+};
+template <AlignmentType T, typename scheme_type>
+struct SmithWatermanAligner
+{
+    static const AlignmentType TYPE = T;
+    SmithWatermanAligner() {}
+    SmithWatermanAligner(const scheme_type& s) : scheme( s ) {}
+    scheme_type scheme;
+};
+template <AlignmentType T, typename scheme_type>
+SmithWatermanAligner<T,scheme_type> make_smith_waterman_aligner(const scheme_type& s) { return SmithWatermanAligner<T,scheme_type>( s ); }
+
+// the reference's edit-distance aligner: the Smith-Waterman kernels with EditDistanceSWScheme (match 0, mismatch -1,
+// insertion = deletion = -1; ed/ed_utils.h:36-43, ed/ed_banded_inl.h:37-69, ed/ed_inl.h:60-168) -- pinned against the
+// reference in tests/golden/ed_golden.npz (banded) and sw_golden.npz (full matrix)
+struct EditDistanceScheme : SimpleSmithWatermanScheme
+{
+    EditDistanceScheme() : SimpleSmithWatermanScheme( 0, -1, -1, -1 ) {}
 };
 template <AlignmentType T>
-GotohAligner<T,EditDistanceScheme> make_edit_distance_aligner() { return GotohAligner<T,EditDistanceScheme>( EditDistanceScheme() ); }
+SmithWatermanAligner<T,EditDistanceScheme> make_edit_distance_aligner() { return SmithWatermanAligner<T,EditDistanceScheme>( EditDistanceScheme() ); }
+
+namespace detail {
+// scoring entry points by aligner family
+template <AlignmentType T, typename S>
+nvbio_status banded_score(const GotohAligner<T,S>& a, int device, uint32_t band, const nvbio_alignment_batch* b, int32_t* sc, nvbio_uint2* sk, hipStream_t s)
+{ const nvbio_gotoh_scheme f = a.scheme.flat(); return nvbio_banded_gotoh_score( device, band, (nvbio_alignment_type)T, &f, b, sc, sk, s ); }
+template <AlignmentType T, typename S>
+nvbio_status banded_score(const SmithWatermanAligner<T,S>& a, int device, uint32_t band, const nvbio_alignment_batch* b, int32_t* sc, nvbio_uint2* sk, hipStream_t s)
+{ const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_banded_sw_score( device, band, (nvbio_alignment_type)T, &f, b, sc, sk, s ); }
+template <AlignmentType T, typename S>
+nvbio_status full_score(const GotohAligner<T,S>& a, int device, int tb, const nvbio_alignment_batch* b, uint32_t mp, uint32_t mt, const int32_t* ms,
+                        int32_t* sc, nvbio_uint2* sk, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_gotoh_scheme f = a.scheme.flat(); return nvbio_full_gotoh_score( device, (nvbio_alignment_type)T, tb, &f, b, mp, mt, ms, sc, sk, temp, temp_size, s ); }
+template <AlignmentType T, typename S>
+nvbio_status full_score(const SmithWatermanAligner<T,S>& a, int device, int tb, const nvbio_alignment_batch* b, uint32_t mp, uint32_t mt, const int32_t* ms,
+                        int32_t* sc, nvbio_uint2* sk, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_full_sw_score( device, (nvbio_alignment_type)T, tb, &f, b, mp, mt, ms, sc, sk, temp, temp_size, s ); }
+} // namespace detail
 
 struct AmdDeviceScheduler {};
 
@@ -289,9 +329,7 @@ struct BatchedBandedAlignmentScore
     void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0)
     {
         (void)temp_size; (void)temp;
-        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
-        check( nvbio_banded_gotoh_score( device, BAND_LEN, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(),
-                                         stream.scores(), stream.sinks(), s ) );
+        check( detail::banded_score( stream.aligner(), device, BAND_LEN, &stream.batch(), stream.scores(), stream.sinks(), s ) );
     }
 };
 
@@ -309,10 +347,9 @@ struct BatchedAlignmentScore
     void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0,
                bool text_blocking = true, const int32_t* min_scores_dev = nullptr)
     {
-        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
-        check( nvbio_full_gotoh_score( device, (nvbio_alignment_type)aligner_type::TYPE, text_blocking ? 1 : 0, &sc, &stream.batch(),
-                                       stream.max_pattern_length(), stream.max_text_length(), min_scores_dev,
-                                       stream.scores(), stream.sinks(), temp, temp_size, s ) );
+        check( detail::full_score( stream.aligner(), device, text_blocking ? 1 : 0, &stream.batch(),
+                                   stream.max_pattern_length(), stream.max_text_length(), min_scores_dev,
+                                   stream.scores(), stream.sinks(), temp, temp_size, s ) );
     }
 };
 

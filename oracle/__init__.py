@@ -42,6 +42,7 @@ def _c32(a):
 # produce the same H in every cell (F <= H and E <= H make "extend" never better than "open"), hence the same
 # scores and sinks -- checked against the reference in tests/test_oracle_vs_reference.py and pinned in ed_golden.npz
 ED_SCHEME = (0, 1, 1, -1, -1, -1, -1)
+ED_SW = (0, -1, -1, -1)      # EditDistanceSWScheme (ed/ed_utils.h:36-43) as (match, mismatch, deletion, insertion)
 
 
 def cigar_from_ops(ops, clip_before, clip_after):
@@ -331,6 +332,26 @@ class Oracle:
                                      _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def banded_sw(self, band, typ, sw, pat, txt):
+        """linear-gap Smith-Waterman in a band; sw = (match, mismatch, deletion, insertion), signed"""
+        pat, txt = _c8(pat), _c8(txt)
+        arr = np.array(sw, dtype=np.int32)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_banded_sw(ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                    _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def full_sw(self, typ, blocking, sw, pat, txt, min_score=SCORE_MIN):
+        """full-matrix linear-gap Smith-Waterman (16-wide stripes); the edit-distance aligner is sw = ED_SW"""
+        pat, txt = _c8(pat), _c8(txt)
+        arr = np.array(sw, dtype=np.int32)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_full_sw(ctypes.c_int(typ), ctypes.c_int(blocking), _p(arr, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                  _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
     def banded_gotoh_batch(self, band, typ, scheme, pats, pat_off, txts, txt_off, quals=None):
         pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)
         pat_off, txt_off = _c32(pat_off), _c32(txt_off)
@@ -487,6 +508,37 @@ class Reference:
         sk = np.zeros(2, dtype=np.uint32)
         ok = self.lib.ref_banded_ed(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
                                     _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_sw(self, band, typ, sw, pat, txt, min_score=SCORE_MIN):
+        """aln::banded_alignment_score<BAND>( SmithWatermanAligner<TYPE,SimpleSmithWatermanScheme> ), sw = (match,
+        mismatch, deletion, insertion) as signed scores (sw/sw_banded_inl.h:281-520)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_banded_sw(ctypes.c_uint32(band), ctypes.c_int(typ), *[ctypes.c_int(int(v)) for v in sw],
+                                    _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)),
+                                    ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def full_sw(self, typ, blocking, sw, pat, txt, min_score=SCORE_MIN):
+        """aln::alignment_score( SmithWatermanAligner<TYPE,SimpleSmithWatermanScheme,blocking tag> ) (sw/sw_inl.h)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_full_sw(ctypes.c_int(typ), ctypes.c_int(blocking), *[ctypes.c_int(int(v)) for v in sw],
+                                  _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)),
+                                  ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def full_ed(self, typ, blocking, pat, txt, min_score=SCORE_MIN):
+        """aln::alignment_score( EditDistanceAligner<TYPE,blocking tag> ) (ed/ed_inl.h)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_full_ed(ctypes.c_int(typ), ctypes.c_int(blocking), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                  _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc),
+                                  _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
     def banded_gotoh_traceback(self, band, typ, scheme, pat, txt, quals=None, cap=4096):

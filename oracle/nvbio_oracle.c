@@ -789,6 +789,137 @@ static int full_pattern_blocking(int type, const orc_gotoh_scheme* sc,
     return ok;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The linear-gap Smith-Waterman family (SmithWatermanAligner, EditDistanceAligner), restated on its own from
+ * sw/sw_banded_inl.h:339-512 (banded) and sw/sw_inl.h:396-1215 (full matrix, stripes of 16: sw_bandlen_selector
+ * :1322-1325; an int16 column of H; pattern blocking tests min_score after every stripe, :676-680, text blocking never).
+ * sw = { match, mismatch, deletion, insertion } as signed scores; qualities play no part (SimpleSmithWatermanScheme).
+ * ------------------------------------------------------------------------------------------ */
+int orc_banded_sw(uint32_t B, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                  int32_t* score, uint32_t sink_out[2])
+{
+    best_sink sink; sink_init( &sink );
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    if (N < M) return 0;                                                    /* :357-358 */
+    const int32_t V = sw[0], S = sw[1], G = sw[2], I = sw[3];
+    uint8_t cache[64];
+    int32_t band[64];
+    /* Reference_cache<31> keeps two bits per symbol (alignment/utils.h): what goes through it comes back as symbol & 3 */
+    const uint8_t cmask = (B == 31u) ? 3u : 255u;
+    for (uint32_t j = 0; j + 1u < B; ++j) cache[j] = (uint8_t)((j < N ? txt[j] : 255u) & cmask); /* :365-367 (undefined in the reference for N < B-1) */
+    for (uint32_t j = 0; j < B; ++j) band[j] = (type == ORC_GLOBAL) ? (int32_t)j * G : 0;    /* init_row_zero :36-45 */
+    for (uint32_t i = 0; i < M; ++i)
+    {
+        const uint8_t q = pat[i];
+        int32_t hi;
+        {
+            const uint8_t g = cache[0];
+            hi = imax( band[1] + G, band[0] + (g == q ? V : S) );
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + 1u, i + 1u ); }
+            band[0] = hi;
+        }
+        for (uint32_t j = 1; j + 1u < B; ++j)
+        {
+            const uint8_t g = cache[j]; cache[j-1] = g;
+            hi = imax( imax( band[j+1] + G, band[j-1] + I ), band[j] + (g == q ? V : S) );
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + j + 1u, i + 1u ); }
+            band[j] = hi;
+        }
+        const uint8_t g = (i + B - 1u < N) ? txt[i + B - 1u] : 255u;        /* :452-453 */
+        cache[B-2u] = (uint8_t)(g & cmask);
+        hi = imax( band[B-2u] + I, band[B-1u] + (g == q ? V : S) );
+        if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + B, i + 1u ); }
+        band[B-1u] = hi;
+    }
+    if (type == ORC_GLOBAL) sink_report( &sink, band[B-1u], M + B - 1u, M );
+    else if (type == ORC_SEMI_GLOBAL)
+    {
+        const uint32_t m = (M + B - 1u < N ? M + B - 1u : N) - (M - 1u);
+        sink_report( &sink, band[0], M, M );
+        for (uint32_t j = 1; j < B; ++j) if (j < m) sink_report( &sink, band[j], M + j, M );
+    }
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    return 1;
+}
+
+#define SW_STRIPE 16u
+int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                int32_t min_score, int32_t* score, uint32_t sink_out[2])
+{
+    best_sink sink; sink_init( &sink );
+    const int32_t V = sw[0], S = sw[1], G = sw[2], I = sw[3];
+    /* the stripes run over `cols` symbols of one string, the int16 column over `rows` symbols of the other */
+    const uint32_t rows = blocking ? M : N, cols = blocking ? N : M;
+    const uint8_t* rstr = blocking ? pat : txt;
+    const uint8_t* cstr = blocking ? txt : pat;
+    const int32_t top_c  = blocking ? I : G;        /* from the previous row: that string advances alone          */
+    const int32_t left_c = blocking ? G : I;
+    int16_t* temp = (int16_t*)malloc( sizeof(int16_t) * ((size_t)rows + 1u) );
+    for (uint32_t i = 0; i < rows; ++i)                                     /* SWScoringContext::init :56-71 */
+        temp[i] = (int16_t)(blocking ? (type != ORC_LOCAL  ? I * (int32_t)(i + 1u) : 0)
+                                     : (type == ORC_GLOBAL ? G * (int32_t)(i + 1u) : 0));
+    const uint32_t nb        = (cols + SW_STRIPE - 1u) / SW_STRIPE;
+    const uint32_t end_block = (SW_STRIPE*nb > SW_STRIPE) ? SW_STRIPE*nb : SW_STRIPE;
+    uint8_t c_cache[SW_STRIPE]; memset( c_cache, 0, sizeof(c_cache) );
+    int32_t band[SW_STRIPE+1];
+    int     ok = 1;
+    for (uint32_t block = 0; block < end_block; block += SW_STRIPE)
+    {
+        const int last = (block + SW_STRIPE >= end_block);
+        for (uint32_t t = 0; t < SW_STRIPE; ++t) if (block + t < cols) c_cache[t] = cstr[block + t];
+        for (uint32_t j = 0; j <= SW_STRIPE; ++j)                           /* :650 / :1083 */
+            band[j] = blocking ? (type == ORC_GLOBAL ? G * (int32_t)(block + j) : 0)
+                               : (type != ORC_LOCAL  ? I * (int32_t)(block + j) : 0);
+        int32_t max_score = ORC_SCORE_MIN;
+        int32_t temp_i    = band[0];
+        for (uint32_t i = 0; i < rows; ++i)
+        {
+            const uint8_t r = rstr[i];
+            int32_t prev = temp_i;
+            band[0] = temp_i = temp[i];
+            for (uint32_t j = 1; j <= SW_STRIPE; ++j)
+            {
+                const int32_t d  = prev + (c_cache[j-1] == r ? V : S);
+                int32_t       hi = imax( imax( band[j] + top_c, band[j-1] + left_c ), d );
+                if (type == ORC_LOCAL) hi = imax( hi, 0 );
+                prev = band[j]; band[j] = hi;
+            }
+            temp[i] = (int16_t)band[SW_STRIPE];
+            max_score = imax( max_score, band[SW_STRIPE] );
+            if (type == ORC_LOCAL)
+            {
+                for (uint32_t j = 1; j <= SW_STRIPE; ++j)
+                    if (!last || block + j <= cols)
+                    {
+                        if (blocking) sink_report( &sink, band[j], block + j, i + 1u );
+                        else          sink_report( &sink, band[j], i + 1u, block + j );
+                    }
+            }
+            else if (!blocking && last && type == ORC_SEMI_GLOBAL)          /* save_boundary: the M-th column */
+                sink_report( &sink, band[ ((M - 1u) & (SW_STRIPE - 1u)) + 1u ], i + 1u, M );
+        }
+        if (blocking)
+        {
+            if (type == ORC_SEMI_GLOBAL)
+            {
+                for (uint32_t j = 1; j <= SW_STRIPE; ++j) if (!last || block + j <= N) sink_report( &sink, band[j], block + j, M );
+            }
+            else if (type == ORC_GLOBAL && last)
+                for (uint32_t j = 1; j <= SW_STRIPE; ++j) if (block + j == N) sink_report( &sink, band[j], block + j, M );
+        }
+        else if (!last)
+        {
+            const int32_t missing = (int32_t)(M - block - SW_STRIPE);       /* :676-680 */
+            if (max_score + missing * V < min_score) { ok = 0; break; }
+        }
+    }
+    if (!blocking && ok && type == ORC_GLOBAL)                              /* save_Mth :745-746 */
+        sink_report( &sink, band[ ((M - 1u) & (SW_STRIPE - 1u)) + 1u ], N, M );
+    free( temp );
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    return ok;
+}
+
 int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* sc,
                    const uint8_t* pat, const uint8_t* quals, uint32_t M,
                    const uint8_t* txt, uint32_t N, int32_t min_score,

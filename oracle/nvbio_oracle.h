@@ -168,6 +168,11 @@ int orc_full_gotoh_traceback(int type, const orc_gotoh_scheme* s,
  * (gotoh_inl.h:444-841 pattern blocking, :847-1256 text blocking; alignment_score_dispatch :1283-1330).
  * blocking: 0 = PatternBlockingTag (alignment_score default), 1 = TextBlockingTag (sw-benchmark).
  * Returns 0 when the stripe early-exit fires (max_score + missing*match < min_score), else 1. */
+/* linear-gap Smith-Waterman / edit-distance aligners (sw/sw_banded_inl.h, sw/sw_inl.h); sw = {match, mismatch, deletion, insertion} */
+int orc_banded_sw(uint32_t band, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                  int32_t* score, uint32_t sink[2]);
+int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                int32_t min_score, int32_t* score, uint32_t sink[2]);
 int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* s,
                    const uint8_t* pat, const uint8_t* quals, uint32_t M,
                    const uint8_t* txt, uint32_t N, int32_t min_score,

@@ -282,6 +282,81 @@ int banded_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint3
     return -1;
 }
 
+// the other two aligner families through the same entry points: SmithWatermanAligner<TYPE,SimpleSmithWatermanScheme>
+// (linear gaps; sw/sw_banded_inl.h:281-520, sw/sw_inl.h) and the full-matrix EditDistanceAligner (ed/ed_inl.h -> sw/sw_inl.h
+// with EditDistanceSWScheme); column cells are int16 (nvbio/alignment/utils.h:55-56)
+template <uint32 BAND, aln::AlignmentType TYPE>
+int banded_sw_run(const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                  int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::BestSink<int32> best;
+    const bool ok = aln::banded_alignment_score<BAND>(
+        aln::make_smith_waterman_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        min_score,
+        best );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+template <uint32 BAND>
+int banded_sw_type(int type, const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N,
+                   int32 min_score, int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return banded_sw_run<BAND,aln::GLOBAL>     ( scheme, pat, M, txt, N, min_score, score, sink );
+    case 1: return banded_sw_run<BAND,aln::LOCAL>      ( scheme, pat, M, txt, N, min_score, score, sink );
+    case 2: return banded_sw_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+template <typename aligner_type>
+int full_aligner_run(const aligner_type& aligner, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                     int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    typedef typename aln::column_storage_type<aligner_type>::type cell_type;
+    std::vector<cell_type> column( (M > N ? M : N) + 16u );
+    aln::BestSink<int32> best;
+    const bool ok = aln::alignment_score(
+        aligner,
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        min_score,
+        best,
+        &column[0] );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+template <typename tag>
+int full_sw_type(int type, const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N,
+                 int32 min_score, int32* score, uint32* sink)
+{
+    typedef aln::SimpleSmithWatermanScheme S;
+    switch (type)
+    {
+    case 0: return full_aligner_run( aln::SmithWatermanAligner<aln::GLOBAL,S,tag>( scheme ),      pat, M, txt, N, min_score, score, sink );
+    case 1: return full_aligner_run( aln::SmithWatermanAligner<aln::LOCAL,S,tag>( scheme ),       pat, M, txt, N, min_score, score, sink );
+    case 2: return full_aligner_run( aln::SmithWatermanAligner<aln::SEMI_GLOBAL,S,tag>( scheme ), pat, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+template <typename tag>
+int full_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score, int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return full_aligner_run( aln::EditDistanceAligner<aln::GLOBAL,tag>(),      pat, M, txt, N, min_score, score, sink );
+    case 1: return full_aligner_run( aln::EditDistanceAligner<aln::LOCAL,tag>(),       pat, M, txt, N, min_score, score, sink );
+    case 2: return full_aligner_run( aln::EditDistanceAligner<aln::SEMI_GLOBAL,tag>(), pat, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
 // aln::alignment_traceback<MAX_PATTERN_LEN,MAX_TEXT_LEN,CHECKPOINTS> (nvbio/alignment/alignment_inl.h:478-517 -> :355-455 ->
 // gotoh/gotoh_inl.h:1573-1640); CHECKPOINTS = 64 as nvBowtie (FULL_DP_CHECKPOINTS, defs.h:96); M <= 256, N <= 1024
 template <aln::AlignmentType TYPE, typename scheme_type, typename qual_type>
@@ -494,6 +569,36 @@ int ref_banded_ed(uint32_t band, int type, const uint8_t* pat, uint32_t M, const
     case 31: return banded_ed_type<31>( type, pat, M, txt, N, score, sink );
     }
     return -1;
+}
+
+int ref_banded_sw(uint32_t band, int type, int match, int mm, int del, int ins,
+                  const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score, int32_t* score, uint32_t* sink)
+{
+    const aln::SimpleSmithWatermanScheme scheme( match, mm, del, ins );
+    switch (band)
+    {
+    case 3:  return banded_sw_type<3> ( type, scheme, pat, M, txt, N, min_score, score, sink );
+    case 7:  return banded_sw_type<7> ( type, scheme, pat, M, txt, N, min_score, score, sink );
+    case 15: return banded_sw_type<15>( type, scheme, pat, M, txt, N, min_score, score, sink );
+    case 31: return banded_sw_type<31>( type, scheme, pat, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
+// blocking: 0 = PatternBlockingTag, 1 = TextBlockingTag
+int ref_full_sw(int type, int blocking, int match, int mm, int del, int ins,
+                const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score, int32_t* score, uint32_t* sink)
+{
+    const aln::SimpleSmithWatermanScheme scheme( match, mm, del, ins );
+    return blocking ? full_sw_type<aln::TextBlockingTag>   ( type, scheme, pat, M, txt, N, min_score, score, sink )
+                    : full_sw_type<aln::PatternBlockingTag>( type, scheme, pat, M, txt, N, min_score, score, sink );
+}
+
+int ref_full_ed(int type, int blocking, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                int32_t* score, uint32_t* sink)
+{
+    return blocking ? full_ed_type<aln::TextBlockingTag>   ( type, pat, M, txt, N, min_score, score, sink )
+                    : full_ed_type<aln::PatternBlockingTag>( type, pat, M, txt, N, min_score, score, sink );
 }
 
 // banded traceback through the reference (M <= 1024).  ops: one byte per op in BACKTRACKING order

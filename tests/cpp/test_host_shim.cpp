@@ -104,6 +104,37 @@ int main()
             REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
         }
     }
+    // the linear-gap Smith-Waterman aligner (unequal deletion / insertion) and the edit-distance aligner through the same class
+    {
+        const aln::SimpleSmithWatermanScheme sws( 2, -3, -5, -2 );
+        const int32_t sw[4] = { 2, -3, -5, -2 }, ed[4] = { 0, -1, -1, -1 };
+        for (int pass = 0; pass < 2; ++pass)
+        {
+            if (pass == 0) aln::batch_banded_alignment_score<31>( aln::make_smith_waterman_aligner<aln::LOCAL>( sws ), batch, d_scores.data(), d_sinks.data() );
+            else           aln::batch_banded_alignment_score<31>( aln::make_edit_distance_aligner<aln::SEMI_GLOBAL>(), batch, d_scores.data(), d_sinks.data() );
+            check_hip( hipDeviceSynchronize(), "sync" );
+            std::vector<int32_t> sc = d_scores.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host();
+            for (uint32_t j = 0; j < J; ++j)
+            {
+                int32_t ws; uint32_t wk[2];
+                orc_banded_sw( 31, pass == 0 ? 1 : 2, pass == 0 ? sw : ed, &pats[j*M], M, &text[wb[j]], we[j] - wb[j], &ws, wk );
+                REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
+            }
+        }
+        // full matrix, pattern blocking, local: 16-wide logical stripes
+        typedef aln::SmithWatermanAligner<aln::LOCAL,aln::SimpleSmithWatermanScheme> aligner_t;
+        typedef aln::FlatAlignmentStream<aligner_t> stream_t;
+        aln::BatchedAlignmentScore<stream_t> full;
+        full.enact( stream_t( aligner_t( sws ), batch, d_scores.data(), d_sinks.data(), M, M + 31 ), 0u, nullptr, 0, 0, false );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<int32_t> sc = d_scores.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host();
+        for (uint32_t j = 0; j < J; ++j)
+        {
+            int32_t ws; uint32_t wk[2];
+            orc_full_sw( 1, 0, sw, &pats[j*M], M, &text[wb[j]], we[j] - wb[j], -(1 << 30), &ws, wk );
+            REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
+        }
+    }
     // banded traceback through BatchedBandedAlignmentTraceback (semi-global): Alignment + CIGAR runs equal to the oracle
     {
         const uint32_t STRIDE = 32;

@@ -17,6 +17,8 @@ Fixtures:
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
   ed_golden.npz   the same pairs scored by the reference's banded edit-distance aligner.
   ftb_golden.npz  the same pairs traced back through the full matrix (alignment_traceback).
+  sw_golden.npz   the same pairs scored by the reference's linear-gap Smith-Waterman aligner (banded and full
+                  matrix) and by its full-matrix edit-distance aligner.
   tb_golden.npz   the same pairs traced back by the reference (banded_alignment_traceback, bands
                   3/7/15/31 x 3 types): score, source, sink and the run-length CIGAR.
 """
@@ -286,6 +288,47 @@ def make_ed(R):
     print("ed_golden.npz: %d pairs" % n)
 
 
+SW_SCHEMES = ((2, -1, -2, -2), (1, -3, -4, -4), (2, -3, -5, -2), (1, -2, -1, -4))     # SimpleSmithWatermanScheme(match, mismatch, deletion, insertion)
+
+
+def make_sw(R):
+    """sw_golden.npz: the reference's linear-gap SmithWatermanAligner (banded: bands 3/7/15/31 x 3 types; full matrix: both
+    blockings x 3 types x {no min score, the pair's min score}) and its full-matrix EditDistanceAligner on every pair of
+    dp_golden.npz.  These two families stripe the full matrix 16 cells wide (sw_bandlen_selector, sw/sw_inl.h:1322-1325)
+    where Gotoh uses 8: LOCAL ties and the early exit are resolved per stripe, so the outputs pin that as well."""
+    g = np.load(os.path.join(HERE, "dp_golden.npz"))
+    n = len(g["pat_off"]) - 1
+    bands = [int(b) for b in g["bands"]]
+    u = lambda v: np.int64(np.int32(np.uint32(v)))
+    bsw = np.zeros((n, len(SW_SCHEMES), len(bands), 3, 4), dtype=np.int64)   # ok, score, sink.x, sink.y  (ok = -1: not pinned)
+    fsw = np.zeros((n, len(SW_SCHEMES), 2, 3, 2, 4), dtype=np.int64)         # [case, scheme, blocking, type, min-score variant]
+    fed = np.zeros((n, 2, 3, 2, 4), dtype=np.int64)
+    for i in range(n):
+        pat = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+        txt = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+        for si, sw in enumerate(SW_SCHEMES):
+            for bi, b in enumerate(bands):
+                for typ in range(3):
+                    if len(txt) < b - 1:
+                        bsw[i, si, bi, typ, 0] = -1
+                        continue
+                    ok, s_, sk = R.banded_sw(b, typ, sw, pat, txt)
+                    bsw[i, si, bi, typ] = (ok, s_, u(sk[0]), u(sk[1]))
+            for blk in range(2):
+                for typ in range(3):
+                    for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                        ok, s_, sk = R.full_sw(typ, blk, sw, pat, txt, ms)
+                        fsw[i, si, blk, typ, v] = (ok, s_, u(sk[0]), u(sk[1]))
+        for blk in range(2):
+            for typ in range(3):
+                for v, ms in enumerate((oracle.SCORE_MIN, max(int(g["min_scores"][i]), -(len(pat) // 4) - 1))):
+                    ok, s_, sk = R.full_ed(typ, blk, pat, txt, ms)
+                    fed[i, blk, typ, v] = (ok, s_, u(sk[0]), u(sk[1]))
+    np.savez_compressed(os.path.join(HERE, "sw_golden.npz"), bsw=bsw, fsw=fsw, fed=fed, bands=np.array(bands),
+                        schemes=np.array(SW_SCHEMES, dtype=np.int32))
+    print("sw_golden.npz: %d pairs" % n)
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -295,3 +338,4 @@ if __name__ == "__main__":
     make_tb(R)
     make_ed(R)
     make_ftb(R)
+    make_sw(R)

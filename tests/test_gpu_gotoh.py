@@ -187,6 +187,45 @@ def test_banded_edit_distance_golden(amd, dp_golden, ed_golden):
     assert checked > 4000
 
 
+def test_banded_smith_waterman_golden(amd, orc, dp_golden, sw_golden):
+    """SmithWatermanAligner through nvbio_banded_sw_score == the reference's, every band and type, on the reference's own
+    outputs; then unequal deletion / insertion costs (the int32 kernel with separate E and F terms) and the packed 16-bit
+    route (deletion == insertion on 4-bit reads / 2-bit text) against the oracle's own restatement of sw_banded_inl.h"""
+    g, w = dp_golden, sw_golden
+    n = len(g["pat_off"]) - 1
+    cases = np.arange(n, dtype=np.uint32)
+    batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1], read_id=cases)
+    checked = 0
+    for si, sw in enumerate(w["schemes"]):
+        for bi, band in enumerate(w["bands"]):
+            for typ in range(3):
+                al = amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*[int(v) for v in sw]))
+                sc, sk = amd.batch_banded_alignment_score(int(band), al, batch)
+                sc, sk = sc.cpu().numpy().astype(np.int64), sk.cpu().numpy().astype(np.int64)
+                want = w["bsw"][:, si, bi, typ]
+                pin = want[:, 0] >= 0
+                assert np.array_equal(sc[pin], want[pin, 1]) and np.array_equal(sk[pin], want[pin, 2:4]), (si, band, typ)
+                checked += int(pin.sum())
+    assert checked > 8000
+    rng = np.random.default_rng(5)
+    G = 200000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    R, M = 4000, 120
+    starts = rng.integers(20, G - M - 40, R)
+    reads = mutate_reads(rng, text, starts, M)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    for band in (31, 15):
+        wb = (starts - band // 2).astype(np.uint32); we = (wb + band + M).astype(np.uint32)
+        batch = amd.AlignmentBatch(orc.pack4(reads.reshape(-1)), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M)
+        for sw in ((2, -3, -5, -2), (1, -2, -1, -4), (0, -1, -1, -1), (2, -6, -4, -4)):
+            for typ in range(3):
+                sc, sk = amd.batch_banded_alignment_score(band, amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*sw)), batch)
+                sc, sk = sc.cpu().numpy(), amd.u32(sk)
+                for k in range(0, R, 7):
+                    ok, s, snk = orc.banded_sw(band, typ, sw, reads[k], text[wb[k]:we[k]])
+                    assert (int(sc[k]), int(sk[k, 0]), int(sk[k, 1])) == (s, snk[0], snk[1]), (band, sw, typ, k)
+
+
 def test_end_to_end_shortcut_edge_cases(amd, orc):
     """the ungapped shortcut and its second chance (U* <= G but only single-gap, mismatch-free alignments could reach
     it): reads with 0-3 substitutions, and reads whose only difference is a 1-4 bp indel a few bases from either end --

@@ -36,6 +36,54 @@ def test_full_golden(amd, dp_golden, blocking):
                     assert np.array_equal(amd.u32(sk).astype(np.int64), want[:, 2:4]), (blocking, si, hq, typ, v)
 
 
+@pytest.mark.parametrize("blocking", [0, 1])
+def test_full_smith_waterman_and_edit_distance_golden(amd, orc, dp_golden, sw_golden, blocking):
+    """the full-matrix SmithWatermanAligner and EditDistanceAligner (nvbio_full_sw_score): logical stripes of 16 -- LOCAL
+    ties, the pattern-blocking early exit, none with text blocking -- on the reference's own outputs; then unequal
+    deletion / insertion costs and tie-rich repetitive texts against the oracle's restatement of sw/sw_inl.h"""
+    g, w = dp_golden, sw_golden
+    n = len(g["pat_off"]) - 1
+    lens_p = np.diff(g["pat_off"]); lens_t = np.diff(g["txt_off"])
+    cases = np.arange(n, dtype=np.uint32)
+    batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1], read_id=cases)
+    ed_ms = np.maximum(g["min_scores"].astype(np.int64), -(lens_p.astype(np.int64) // 4) - 1).astype(np.int32)
+    for typ in range(3):
+        for v in (0, 1):
+            for si, sw in enumerate(w["schemes"]):
+                al = amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*[int(x) for x in sw]))
+                sc, sk = amd.BatchedAlignmentScore(al, text_blocking=bool(blocking)).enact(
+                    batch, int(lens_p.max()), int(lens_t.max()), min_scores=g["min_scores"] if v else None)
+                want = w["fsw"][:, si, blocking, typ, v]
+                assert np.array_equal(sc.cpu().numpy().astype(np.int64), want[:, 1]), (blocking, si, typ, v)
+                assert np.array_equal(amd.u32(sk).astype(np.int64), want[:, 2:4] & 0xFFFFFFFF), (blocking, si, typ, v)
+            sc, sk = amd.BatchedAlignmentScore(amd.make_edit_distance_aligner(typ), text_blocking=bool(blocking)).enact(
+                batch, int(lens_p.max()), int(lens_t.max()), min_scores=ed_ms if v else None)
+            want = w["fed"][:, blocking, typ, v]
+            assert np.array_equal(sc.cpu().numpy().astype(np.int64), want[:, 1]), (blocking, "ed", typ, v)
+            assert np.array_equal(amd.u32(sk).astype(np.int64), want[:, 2:4] & 0xFFFFFFFF), (blocking, "ed", typ, v)
+    rng = np.random.default_rng(23)
+    G = 60000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    text[10000:30000] = np.tile(rng.integers(0, 4, 7, dtype=np.uint8), 20000 // 7 + 1)[:20000]      # period 7: ties everywhere
+    R = 1200
+    lens = rng.integers(20, 140, R)
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(100, G - 700, R)
+    flat = np.concatenate([text[s + 40:s + 40 + l] for s, l in zip(starts, lens)]).copy()
+    flat[rng.random(len(flat)) < 0.04] = rng.integers(0, 4)
+    wb = starts.astype(np.uint32); we = (starts + rng.integers(150, 420, R)).astype(np.uint32)
+    ms = rng.integers(-60, 120, R).astype(np.int32)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we)
+    for sw in ((2, -3, -5, -2), (1, -2, -1, -4), (0, -1, -1, -1), (3, -2, -3, -3)):
+        for typ in range(3):
+            al = amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*sw))
+            sc, sk = amd.BatchedAlignmentScore(al, text_blocking=bool(blocking)).enact(batch, int(lens.max()), 420, min_scores=ms)
+            sc, sk = sc.cpu().numpy(), amd.u32(sk)
+            for k in range(R):
+                ok, s, snk = orc.full_sw(typ, blocking, sw, flat[roffs[k]:roffs[k + 1]], text[wb[k]:we[k]], int(ms[k]))
+                assert (int(sc[k]), int(sk[k, 0]), int(sk[k, 1])) == (s, snk[0], snk[1]), (blocking, sw, typ, k)
+
+
 def test_sw_benchmark_shape(amd, orc):
     """many reads against ONE reference text (sw-benchmark/sw-benchmark.cu:152-197): LCG-random
     100 bp patterns (alignment_test.cu:879-881), global/semi-global/local Gotoh (2,-1,-2,-1), text blocking"""

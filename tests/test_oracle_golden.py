@@ -225,6 +225,39 @@ def test_banded_edit_distance_golden(orc, dp_golden, ed_golden):
         assert orc.banded_gotoh(7, oracle.SEMI_GLOBAL, sc, enc(pat), enc(txt))[1] == want
 
 
+def test_smith_waterman_family_golden(orc, dp_golden, sw_golden):
+    """the reference's linear-gap SmithWatermanAligner (banded and full matrix, both blockings, with and without a minimum
+    score) and its full-matrix EditDistanceAligner, on the reference's own outputs: the restatement sweeps the full matrix
+    in stripes of 16 like sw/sw_inl.h, which decides LOCAL ties and the early exit"""
+    g, w = dp_golden, sw_golden
+    u = lambda v: int(np.int64(np.int32(np.uint32(v))))
+    checked = 0
+    for i in range(len(g["pat_off"]) - 1):
+        p, t, _ = _case(g, i)
+        for si, sw in enumerate(w["schemes"]):
+            for bi, b in enumerate(w["bands"]):
+                for typ in range(3):
+                    want = tuple(int(v) for v in w["bsw"][i, si, bi, typ])
+                    if want[0] < 0:
+                        continue
+                    ok, s, sk = orc.banded_sw(int(b), typ, sw, p, t)
+                    assert (ok, s, u(sk[0]), u(sk[1])) == want, (i, si, b, typ)
+                    checked += 1
+            for blk in range(2):
+                for typ in range(3):
+                    for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                        ok, s, sk = orc.full_sw(typ, blk, sw, p, t, ms)
+                        assert (ok, s, u(sk[0]), u(sk[1])) == tuple(int(x) for x in w["fsw"][i, si, blk, typ, v]), (i, si, blk, typ, v)
+                        checked += 1
+        for blk in range(2):
+            for typ in range(3):
+                for v, ms in enumerate((oracle.SCORE_MIN, max(int(g["min_scores"][i]), -(len(p) // 4) - 1))):
+                    ok, s, sk = orc.full_sw(typ, blk, oracle.ED_SW, p, t, ms)
+                    assert (ok, s, u(sk[0]), u(sk[1])) == tuple(int(x) for x in w["fed"][i, blk, typ, v]), (i, blk, typ, v)
+                    checked += 1
+    assert checked > 20000
+
+
 def test_full_traceback_golden(orc, dp_golden, ftb_golden):
     """score, source, sink and run-length CIGAR of the reference's full-matrix alignment_traceback"""
     g, t = dp_golden, ftb_golden
