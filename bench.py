@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
+    ap.add_argument("--no-mapq", action="store_true", help="leave nvBowtie's second-best bookkeeping and the mapping quality out of the step")
     ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
     args = ap.parse_args()
 
@@ -171,6 +172,7 @@ def main():
     batch = pipeline.ReadBatch(reads4, R, M)
     params = pipeline.SeedExtendParams.end_to_end() if args.mode == "e2e" else pipeline.SeedExtendParams()
     params.direct = not args.no_direct
+    params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c
     scheme_t = tuple(int(getattr(sv, f)) for f, _ in sv._fields_)
     min_score = params.min_score_for(M)
@@ -179,8 +181,10 @@ def main():
     # rank 0 over RCCL -- enqueued asynchronously after the batch's kernels so that it overlaps the next batch
     gatherer = sharding.ResultGatherer(dist, world, rank, R, device, dst=0) if dist is not None else None
 
+    extras = {}
+
     def step(timers=None):
-        bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers)
+        bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras)
         if gatherer is not None:
             gatherer.submit(sharding.pack_result64(bs, bp, brc))
         return bs, bp, brc, nc
@@ -333,6 +337,10 @@ def main():
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
         "traceback": tb_info,
+        "mapq": ({"evaluator": "BowtieMapq2 over (best, second best) of nvBowtie's score_reduce; inside the timed step (stage_ms.mapq)",
+                  "second_alignment_fraction": float((extras["second"] != 0).float().mean()),
+                  "mean": float(extras["mapq"].float().mean()), "fraction_ge_30": float((extras["mapq"] >= 30).float().mean())}
+                 if params.mapq and "mapq" in extras else None),
         "plain_operators": plain or None,
     }
 

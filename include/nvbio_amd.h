@@ -329,6 +329,36 @@ nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, c
 nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* best_dev, uint32_t n_reads, int32_t* scores_dev,
                                          int64_t* end_pos_dev, uint8_t* rc_dev, void* stream);
 
+/* The second-best alignment per read, as nvBowtie's score_reduce keeps it (nvBowtie/bowtie2/cuda/reduce_inl.h:65-140:
+ * best a1 and a second a2 that must be `distinct` from a1 -- io::distinct_alignments, nvbio/io/alignments_inl.h:26-38: the other
+ * strand, or more than distinct_dist = read_len / 2 positions away -- and score above the read's threshold; candidates at a
+ * location already held are skipped).  The reference's loop depends on the order the extension results arrive in; this is
+ * that loop applied to the candidates in descending order of the selection key, in two order-free passes: run
+ * nvbio_best_candidate_reduce over ALL candidates first, then this call over the same arrays:
+ *   second_dev[read] = max over the read's candidates with scores[i] > worst_score, sel != best_dev[read] and
+ *                      distinct( best end position / strand, candidate end position / strand, distinct_dist ) of sel.
+ * (Positions are end positions, hit.sink, where the reference compares hit.loc, the diagonal's start: the two differ by
+ * read_len +- band.)  The caller zero-initialises second_dev; 0 = no second alignment (BestAlignments::has_second()). */
+nvbio_status nvbio_second_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                           const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev,
+                                           uint32_t distinct_dist, int32_t worst_score, uint64_t* second_dev, void* stream);
+
+/* Bowtie2's mapping quality of every read from its best and second-best selection keys: BowtieMapq2 (version 2, the
+ * evaluator nvBowtie instantiates, bowtie2_cuda_driver.cu:277,600) or BowtieMapq3 (version 3), single-end form of
+ * nvBowtie/bowtie2/cuda/mapq.h:32-297.  perfect_score = scheme.perfect_score(read_len) (match * read_len, scoring.h:274),
+ * min_score = scheme.min_score(read_len) (MinScoreFunc, scoring.h:117-129), monotone = (match bonus == 0) (scoring.h:339).
+ * second_dev may be NULL (no second alignments); second_scores_dev (optional) receives the second-best scores
+ * (NVBIO_SCORE_MIN where there is none).  Reads without a candidate get 0. */
+typedef struct
+{
+    int32_t version;         /* 2 or 3 */
+    int32_t monotone;
+    int32_t perfect_score;
+    int32_t min_score;
+} nvbio_mapq_params;
+nvbio_status nvbio_mapq(int device, const uint64_t* best_dev, const uint64_t* second_dev, uint32_t n_reads,
+                        const nvbio_mapq_params* params, int32_t* second_scores_dev, uint8_t* mapq_dev, void* stream);
+
 /* Paired-end: the genome window in which the opposite mate of an anchored mate is aligned (full-matrix DP),
  * BestOppositeScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate
  * (alignment_utils.h:52-88).  g_pos = the anchor hit's locus (hit.loc), anchor_rc its strand, anchor = 0 if mate 1 is

@@ -694,6 +694,33 @@ def max_text_gaps(scheme, min_score, pattern_len):
     return (n - 1) & 0xFFFFFFFF
 
 
+class _MapqParams(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_int32), ("monotone", ctypes.c_int32), ("perfect_score", ctypes.c_int32),
+                ("min_score", ctypes.c_int32)]
+
+
+def second_candidate_reduce(keys, scores, sinks, wb, best, distinct_dist, worst_score, second):
+    """nvBowtie's second-best alignment per read (score_reduce, reduce_inl.h:65-140; see nvbio_second_candidate_reduce):
+    best must already hold the final per-read maxima over ALL candidates; second is zero-initialised by the caller"""
+    _check(lib().nvbio_second_candidate_reduce(FMIndex._dev_index(keys.device), _ptr(keys), _ptr(scores), _ptr(sinks), _ptr(wb),
+                                               ctypes.c_uint64(keys.shape[0]), _ptr(best), ctypes.c_uint32(distinct_dist),
+                                               ctypes.c_int32(worst_score), _ptr(second), _stream_ptr(keys.device)))
+    return second
+
+
+def mapq(best, second, perfect_score, min_score, monotone, version=2):
+    """Bowtie2's mapping quality per read from the best / second-best selection keys (BowtieMapq2 / BowtieMapq3,
+    nvBowtie/bowtie2/cuda/mapq.h) -> (mapq uint8 [R], second_score int32 [R])"""
+    torch = _torch()
+    R = best.shape[0]
+    q = torch.empty(R, dtype=torch.uint8, device=best.device)
+    ss = torch.empty(R, dtype=torch.int32, device=best.device)
+    prm = _MapqParams(int(version), 1 if monotone else 0, int(perfect_score), int(min_score))
+    _check(lib().nvbio_mapq(FMIndex._dev_index(best.device), _ptr(best), _ptr(second) if second is not None else None,
+                            ctypes.c_uint32(R), ctypes.byref(prm), _ptr(ss), _ptr(q), _stream_ptr(best.device)))
+    return q, ss
+
+
 def opposite_mate_windows(g_pos, anchor_rc, anchor_len, opposite_gapped_len, anchor, genome_len, policy=PE_POLICY_FR,
                           min_frag_len=0, max_frag_len=500, overlap=True):
     """BestOppositeScoreStream::init_context's window (nvBowtie score_inl.h:389-425): (win_begin, win_end, flags, valid)"""

@@ -78,6 +78,138 @@ best_unpack_kernel(const unsigned long long* __restrict__ best, const uint32_t n
     }
 }
 
+// second-best candidate per read: nvBowtie's score_reduce_kernel (nvBowtie/bowtie2/cuda/reduce_inl.h:65-140) keeps, beside the
+// best alignment a1, a second one a2 that must be `distinct` from a1 (io::distinct_alignments, nvbio/io/alignments_inl.h:26-38:
+// other strand, or more than read_len/2 away) and score above the read's threshold; it skips candidates at a location already
+// held (:104-107).  That loop depends on the order candidates arrive in; fed in descending order of the selection key it ends
+// with a1 = the largest key and a2 = the largest key among the candidates distinct from a1 -- which is what this pass computes
+// with one atomic max per candidate, given the final a1 of every read (best_candidate_kernel over ALL candidates first).
+__device__ __forceinline__ bool distinct_alignments(const uint64_t pos1, const uint32_t rc1, const uint64_t pos2, const uint32_t rc2, const uint64_t dist)
+{
+    if (rc1 != rc2) return true;
+    return !(pos1 >= pos2 - (pos2 < dist ? pos2 : dist) && pos1 <= pos2 + dist);
+}
+
+__global__ void __launch_bounds__(256)
+second_candidate_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                        const uint32_t* __restrict__ wb, const uint64_t n, const unsigned long long* __restrict__ best,
+                        const uint32_t dist, const int32_t worst_score, unsigned long long* __restrict__ second)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const int32_t sc = scores[i];
+        if (sc <= worst_score) continue;                          // `score > best.m_a2.score()` with a2 initialised to the threshold
+        const uint64_t k   = keys[i];
+        const int64_t  s   = (int64_t)sc + (1ll << 20);
+        const uint64_t pos = ((uint64_t)wb[i] + (uint64_t)sinks[i].x) & ((1ull << 33) - 1ull);
+        const uint64_t sel = ((uint64_t)(s > 0 ? s : 0) << 34) | (k & (1ull << 33)) | pos;
+        const unsigned long long b = best[k >> 34];
+        if (sel == b) continue;                                   // the best itself (or a copy of it): location already held
+        if (!distinct_alignments( b & ((1ull << 33) - 1ull), (uint32_t)((b >> 33) & 1ull), pos, (uint32_t)((k >> 33) & 1ull), dist )) continue;
+        atomicMax( &second[k >> 34], (unsigned long long)sel );
+    }
+}
+
+// Bowtie2's mapping quality from (best, second best, read length): BowtieMapq2 (the one nvBowtie instantiates,
+// bowtie2_cuda_driver.cu:277) and BowtieMapq3, nvBowtie/bowtie2/cuda/mapq.h:32-297, single-end form.  float arithmetic as
+// the reference's (no contraction); perfect = scheme.perfect_score(len), minimum = scheme.min_score(len).
+__device__ __forceinline__ int mapq_v3(const int32_t best_score, const bool has_second, const int32_t second_score, const float max_score, const float min_score)
+{
+    const int unpaired_one[11]         = { 43, 42, 41, 36, 32, 27, 20, 11, 4, 1, 0 };
+    const int unpaired_two_perfect[11] = { 2, 16, 23, 30, 31, 32, 34, 36, 38, 40, 42 };
+    const int unpaired_two[11][11] = {
+        {  2,  2,  2,  1,  1, 0, 0, 0, 0, 0, 0 }, { 20, 14,  7,  3,  2, 1, 0, 0, 0, 0, 0 }, { 20, 16, 10,  6,  3, 1, 0, 0, 0, 0, 0 },
+        { 20, 17, 13,  9,  3, 1, 1, 0, 0, 0, 0 }, { 21, 19, 15,  9,  5, 2, 2, 0, 0, 0, 0 }, { 22, 21, 16, 11, 10, 5, 0, 0, 0, 0, 0 },
+        { 23, 22, 19, 16, 11, 0, 0, 0, 0, 0, 0 }, { 24, 25, 21, 30,  0, 0, 0, 0, 0, 0, 0 }, { 30, 26, 29,  0,  0, 0, 0, 0, 0, 0, 0 },
+        { 30, 27,  0,  0,  0, 0, 0, 0, 0, 0, 0 }, { 30,  0,  0,  0,  0, 0, 0, 0, 0, 0, 0 } };
+    const float norm_factor = 10.0f / (max_score - min_score);
+    if ((float)best_score < min_score) return 0;
+    const int best     = ((int)max_score - best_score) > 0 ? ((int)max_score - best_score) : 0;     // negated best score
+    int       best_bin = (int)((float)best * norm_factor + 0.5f);
+    best_bin = best_bin < 0 ? 0 : (best_bin > 10 ? 10 : best_bin);
+    if (has_second)
+    {
+        const int diff     = best_score - second_score;
+        int       diff_bin = (int)((float)diff * norm_factor + 0.5f);
+        diff_bin = diff_bin < 0 ? 0 : (diff_bin > 10 ? 10 : diff_bin);
+        return ((float)best == max_score) ? unpaired_two_perfect[best_bin] : unpaired_two[diff_bin][best_bin];
+    }
+    return ((float)best == max_score) ? 44 : unpaired_one[best_bin];
+}
+
+__device__ __forceinline__ int mapq_v2(const int32_t best_score, const bool has_second, const int32_t second_score, const float max_score, const float min_score,
+                                       const bool monotone)
+{
+    const float diff = max_score - min_score;
+    const float best = (float)best_score;
+    if (best < min_score) return 0;
+    const float best_over = best - min_score;
+    if (monotone)
+    {
+        if (!has_second)
+        {
+            if      (best_over >= diff * 0.8f) return 42;
+            else if (best_over >= diff * 0.7f) return 40;
+            else if (best_over >= diff * 0.6f) return 24;
+            else if (best_over >= diff * 0.5f) return 23;
+            else if (best_over >= diff * 0.4f) return 8;
+            else if (best_over >= diff * 0.3f) return 3;
+            else                               return 0;
+        }
+        const float best_diff = fabsf( fabsf( best ) - fabsf( (float)second_score ) );
+        if      (best_diff >= diff * 0.9f) return (best_over == diff) ? 39 : 33;
+        else if (best_diff >= diff * 0.8f) return (best_over == diff) ? 38 : 27;
+        else if (best_diff >= diff * 0.7f) return (best_over == diff) ? 37 : 26;
+        else if (best_diff >= diff * 0.6f) return (best_over == diff) ? 36 : 22;
+        else if (best_diff >= diff * 0.5f) return (best_over == diff) ? 35 : (best_over >= diff * 0.84f) ? 25 : (best_over >= diff * 0.68f) ? 16 : 5;
+        else if (best_diff >= diff * 0.4f) return (best_over == diff) ? 34 : (best_over >= diff * 0.84f) ? 21 : (best_over >= diff * 0.68f) ? 14 : 4;
+        else if (best_diff >= diff * 0.3f) return (best_over == diff) ? 32 : (best_over >= diff * 0.88f) ? 18 : (best_over >= diff * 0.67f) ? 15 : 3;
+        else if (best_diff >= diff * 0.2f) return (best_over == diff) ? 31 : (best_over >= diff * 0.88f) ? 17 : (best_over >= diff * 0.67f) ? 11 : 0;
+        else if (best_diff >= diff * 0.1f) return (best_over == diff) ? 30 : (best_over >= diff * 0.88f) ? 12 : (best_over >= diff * 0.67f) ? 7 : 0;
+        else if (best_diff > 0)            return (best_over >= diff * 0.67f) ? 6 : 2;
+        else                               return (best_over >= diff * 0.67f) ? 1 : 0;
+    }
+    if (!has_second)
+    {
+        if      (best_over >= diff * 0.8f) return 44;
+        else if (best_over >= diff * 0.7f) return 42;
+        else if (best_over >= diff * 0.6f) return 41;
+        else if (best_over >= diff * 0.5f) return 36;
+        else if (best_over >= diff * 0.4f) return 28;
+        else if (best_over >= diff * 0.3f) return 24;
+        else                               return 22;
+    }
+    const float best_diff = fabsf( fabsf( best ) - fabsf( (float)second_score ) );
+    if      (best_diff >= diff * 0.9f) return 40;
+    else if (best_diff >= diff * 0.8f) return 39;
+    else if (best_diff >= diff * 0.7f) return 38;
+    else if (best_diff >= diff * 0.6f) return 37;
+    else if (best_diff >= diff * 0.5f) return (best_over == diff) ? 35 : (best_over >= diff * 0.50f) ? 25 : 20;
+    else if (best_diff >= diff * 0.4f) return (best_over == diff) ? 34 : (best_over >= diff * 0.50f) ? 21 : 19;
+    else if (best_diff >= diff * 0.3f) return (best_over == diff) ? 33 : (best_over >= diff * 0.5f) ? 18 : 16;
+    else if (best_diff >= diff * 0.2f) return (best_over == diff) ? 32 : (best_over >= diff * 0.5f) ? 17 : 12;
+    else if (best_diff >= diff * 0.1f) return (best_over == diff) ? 31 : (best_over >= diff * 0.5f) ? 14 : 9;
+    else if (best_diff > 0)            return (best_over >= diff * 0.5f) ? 11 : 2;
+    else                               return (best_over >= diff * 0.5f) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+mapq_kernel(const unsigned long long* __restrict__ best, const unsigned long long* __restrict__ second, const uint32_t n,
+            const int version, const bool monotone, const float max_score, const float min_score,
+            int32_t* __restrict__ second_score, uint8_t* __restrict__ mapq)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const unsigned long long b = best[i], s2 = second ? second[i] : 0ull;
+        const int32_t bs = b  ? (int32_t)((int64_t)(b  >> 34) - (1ll << 20)) : NVBIO_SCORE_MIN;
+        const int32_t ss = s2 ? (int32_t)((int64_t)(s2 >> 34) - (1ll << 20)) : NVBIO_SCORE_MIN;
+        int q = 0;
+        if (b) q = (version == 3) ? mapq_v3( bs, s2 != 0ull, ss, max_score, min_score ) : mapq_v2( bs, s2 != 0ull, ss, max_score, min_score, monotone );
+        if (second_score) second_score[i] = ss;
+        mapq[i] = (uint8_t)q;
+    }
+}
+
 // opposite-mate window of a paired-end alignment: BestOppositeScoreStream::init_context
 // (nvBowtie/bowtie2/cuda/score_inl.h:389-425) with frame_opposite_mate (alignment_utils.h:52-88)
 __global__ void __launch_bounds__(256)
@@ -193,6 +325,35 @@ extern "C" nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* 
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipLaunchKernelGGL( best_unpack_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream,
                         (const unsigned long long*)best_dev, n_reads, scores_dev, end_pos_dev, rc_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_second_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                      const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev,
+                                                      uint32_t distinct_dist, int32_t worst_score, uint64_t* second_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && scores_dev && sinks_dev && win_begin_dev && best_dev && second_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( second_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (const unsigned long long*)best_dev,
+                        distinct_dist, worst_score, (unsigned long long*)second_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_mapq(int device, const uint64_t* best_dev, const uint64_t* second_dev, uint32_t n_reads,
+                                   const nvbio_mapq_params* params, int32_t* second_scores_dev, uint8_t* mapq_dev, void* stream)
+{
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( best_dev && mapq_dev && params, "NULL pointer" );
+    NVB_REQUIRE( params->version == 2 || params->version == 3, "mapq version must be 2 or 3" );
+    NVB_REQUIRE( params->perfect_score > params->min_score, "perfect_score must exceed min_score" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( mapq_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream,
+                        (const unsigned long long*)best_dev, (const unsigned long long*)second_dev, n_reads, (int)params->version,
+                        params->monotone != 0, (float)params->perfect_score, (float)params->min_score, second_scores_dev, mapq_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

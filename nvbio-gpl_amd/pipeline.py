@@ -33,6 +33,9 @@ class SeedExtendParams:
                                                     # the first k rows of a seed's SA range (a deterministic stand-in for
                                                     # nvBowtie's max_hits cap, which guards against repeat seeds)
         self.direct = True                          # use match_direct when the index holds the full SA and the text
+        self.mapq = False                           # also keep nvBowtie's second-best alignment per read and compute the
+                                                    # mapping quality (score_reduce + BowtieMapq2); results go to `extras`
+        self.mapq_version = 2
 
     @classmethod
     def end_to_end(cls, constant_quality=True, **kw):
@@ -73,15 +76,18 @@ def pack_best_key(torch, scores, rc, pos):
     return (s << 34) | (rc.to(torch.int64) << 33) | pos.to(torch.int64)
 
 
-def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return_windows=False):
+def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return_windows=False, extras=None):
     """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end, or -1),
     best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events.
     return_windows: also return best_wb[int64 R], the window begin of each read's best candidate (-1 if
     none; the largest one if several candidates tie on the whole selection key) -- what traceback_best needs --
     and best_g[int64 R], that candidate's locus (hit.loc: the diagonal clamped at the genome start), the
-    anchor position of paired-end opposite-mate windows."""
+    anchor position of paired-end opposite-mate windows.
+    params.mapq: `extras` (a dict) receives "mapq" (uint8 [R]), "second_score" (int32 [R], SCORE_MIN where a read has no
+    second alignment) and "second" (the second-best selection keys): nvBowtie's score_reduce bookkeeping (reduce_inl.h:65-140,
+    over the candidates in descending key order) and BowtieMapq2 (mapq.h)."""
     import torch
-    from . import best_candidate_reduce, best_candidate_unpack, diagonals_to_windows
+    from . import best_candidate_reduce, best_candidate_unpack, diagonals_to_windows, mapq, second_candidate_reduce
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
@@ -122,6 +128,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         e = tick("reduce")
         best_candidate_reduce(keys, scores, sinks, wb, top)
         tock(e)
+        if params.mapq:
+            scored.append((keys, scores, sinks, wb))
         if not return_windows:
             return None
         rc = (keys >> 33) & 1
@@ -130,7 +138,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         return rid.to(torch.int64), pack_best_key(torch, scores, rc, pos), wb, g
 
     use_direct = params.direct and fmi.supports_direct()
-    results, n_cand = [], 0
+    results, n_cand, scored = [], 0, []
     for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
         #    (FMIndexFilter::rank = match + scan; the two halves are called separately so that the
@@ -177,6 +185,18 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     e = tick("unpack")
     best_score, best_pos, best_rc = best_candidate_unpack(top)
     tock(e)
+    if params.mapq:
+        # 6. second-best per read (needs the final best of both strands) and the mapping quality
+        e = tick("mapq")
+        second = torch.zeros((R,), dtype=torch.int64, device=dev)
+        min_score = params.min_score_for(M)
+        for keys, scores, sinks, wb in scored:
+            second_candidate_reduce(keys, scores, sinks, wb, top, M // 2, min_score - 1, second)
+        match = int(params.scheme.c.match)
+        q, second_score = mapq(top, second, match * M, min_score, match == 0, params.mapq_version)
+        tock(e)
+        if extras is not None:
+            extras.update(mapq=q, second_score=second_score, second=second)
     if n_cand == 0:
         if return_windows:
             none = torch.full((R,), -1, dtype=torch.int64, device=dev)

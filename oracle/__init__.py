@@ -352,6 +352,22 @@ class Oracle:
                                   _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def score_reduce(self, scores, pos, rc, read_len, worst_score):
+        """nvBowtie's score_reduce_kernel for one read over candidates in the order given
+        -> (a1 aligned, a1 score, a1 pos, a1 rc, a2 aligned, a2 score, a2 pos, a2 rc)"""
+        scores = np.ascontiguousarray(scores, dtype=np.int32); pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        rc = np.ascontiguousarray(rc, dtype=np.uint8)
+        out = np.zeros(8, dtype=np.int64)
+        self.lib.orc_score_reduce(_p(scores, _i32p), _p(pos, _u32p), _p(rc, _u8p), ctypes.c_uint32(len(scores)),
+                                  ctypes.c_uint32(read_len), ctypes.c_int32(worst_score), out.ctypes.data_as(ctypes.c_void_p))
+        return tuple(int(v) for v in out)
+
+    def mapq(self, version, monotone, perfect_score, min_score, best_score, has_second, second_score):
+        """BowtieMapq2 / BowtieMapq3, single-end (nvBowtie/bowtie2/cuda/mapq.h)"""
+        return int(self.lib.orc_mapq(ctypes.c_int(version), ctypes.c_int(1 if monotone else 0), ctypes.c_int32(perfect_score),
+                                     ctypes.c_int32(min_score), ctypes.c_int32(best_score), ctypes.c_int(1 if has_second else 0),
+                                     ctypes.c_int32(second_score)))
+
     def banded_gotoh_batch(self, band, typ, scheme, pats, pat_off, txts, txt_off, quals=None):
         pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)
         pat_off, txt_off = _c32(pat_off), _c32(txt_off)

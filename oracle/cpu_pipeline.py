@@ -108,8 +108,10 @@ def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, se
 
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
                         aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, want_loci=False,
-                        max_seed_hits=None):
+                        max_seed_hits=None, second=None):
     """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates); with
+    second = dict(min_score, perfect_score, monotone, version) also a dict with nvBowtie's second-best alignment per read
+    (score_reduce over the read's candidates in descending order of the selection key) and the mapping quality; with
     traceback_stride > 0 also a dict with the traceback of every aligned read's best candidate (the one with
     the largest window begin among candidates tying on the selection key)."""
     scheme = scheme or Scheme(2, 2, 6, -8, -3, -8, -3)
@@ -176,6 +178,24 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
     best_score = np.where(has & (sv > 0), sv - (1 << 20), best_score).astype(np.int32)
     best_pos = np.where(has, top & ((1 << 33) - 1), best_pos)
     best_rc = np.where(has, (top >> 33) & 1, best_rc).astype(np.uint8)
+    if second is not None:
+        order = np.lexsort((-packed, rid))                     # per read, candidates in descending key order
+        r_s, p_s = rid[order], packed[order]
+        bounds = np.searchsorted(r_s, np.arange(R + 1))
+        sec_score = np.full(R, SCORE_MIN, dtype=np.int32); sec_pos = np.full(R, -1, dtype=np.int64)
+        sec_rc = np.zeros(R, dtype=np.uint8); mapq = np.zeros(R, dtype=np.uint8)
+        for r in range(R):
+            lo, hi = bounds[r], bounds[r + 1]
+            if lo == hi:
+                continue
+            k = p_s[lo:hi]
+            sc_r = ((k >> 34) - (1 << 20)).astype(np.int32)
+            out = O.score_reduce(sc_r, (k & ((1 << 33) - 1)).astype(np.uint32), ((k >> 33) & 1).astype(np.uint8), M, second["min_score"] - 1)
+            if out[4]:
+                sec_score[r], sec_pos[r], sec_rc[r] = out[5], out[6], out[7]
+            mapq[r] = O.mapq(second.get("version", 2), second["monotone"], second["perfect_score"], second["min_score"],
+                             int(best_score[r]), bool(out[4]), out[5])
+        return best_score, best_pos, best_rc, len(keys), dict(second_score=sec_score, second_pos=sec_pos, second_rc=sec_rc, mapq=mapq)
     if want_loci:
         best_g = np.full(R, -1, dtype=np.int64)
         win = packed == top[rid]

@@ -1131,3 +1131,120 @@ void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_
         free( p ); free( pq ); free( t );
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * nvBowtie's best / second-best bookkeeping and mapping quality, restated from device-only / thrust-bound sources
+ * (PARITY UNPINNED: neither reduce_inl.h nor mapq.h compiles host-only in the development container)
+ * ------------------------------------------------------------------------------------------ */
+static int distinct_alignments(uint32_t pos1, int rc1, uint32_t pos2, int rc2, uint32_t dist)   /* nvbio/io/alignments_inl.h:26-38 */
+{
+    if (rc1 != rc2) return 1;
+    return (pos1 >= pos2 - (pos2 < dist ? pos2 : dist) && pos1 <= pos2 + dist) ? 0 : 1;
+}
+
+/* score_reduce_kernel (nvBowtie/bowtie2/cuda/reduce_inl.h:65-140) for ONE read: candidates (score, position, strand) in the
+ * order given; a1 / a2 start unaligned at worst_score (init_alignments_kernel, aligner.h:279-301).
+ * out = { a1 aligned, a1 score, a1 pos, a1 rc, a2 aligned, a2 score, a2 pos, a2 rc } */
+void orc_score_reduce(const int32_t* scores, const uint32_t* pos, const uint8_t* rc, uint32_t n, uint32_t read_len, int32_t worst_score,
+                      int64_t out[8])
+{
+    int     a1_al = 0, a2_al = 0, a1_rc = 0, a2_rc = 0;
+    int32_t a1_s = worst_score, a2_s = worst_score;
+    uint32_t a1_p = 0xFFFFFFFFu, a2_p = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        if ((rc[i] == a1_rc && pos[i] == a1_p) || (rc[i] == a2_rc && pos[i] == a2_p)) continue;       /* :104-107 */
+        if (scores[i] > a1_s)
+        {
+            a2_al = a1_al; a2_s = a1_s; a2_p = a1_p; a2_rc = a1_rc;                                   /* :113-114 */
+            a1_al = 1; a1_s = scores[i]; a1_p = pos[i]; a1_rc = rc[i];
+        }
+        else if (scores[i] > a2_s && distinct_alignments( a1_p, a1_rc, pos[i], rc[i], read_len / 2u ))  /* :118-124 */
+        {
+            a2_al = 1; a2_s = scores[i]; a2_p = pos[i]; a2_rc = rc[i];
+        }
+    }
+    out[0] = a1_al; out[1] = a1_s; out[2] = a1_p; out[3] = a1_rc;
+    out[4] = a2_al; out[5] = a2_s; out[6] = a2_p; out[7] = a2_rc;
+}
+
+/* BowtieMapq3 / BowtieMapq2, single-end (nvBowtie/bowtie2/cuda/mapq.h:32-135 / :139-297) */
+int orc_mapq(int version, int monotone, int32_t perfect_score, int32_t minimum_score, int32_t best_score, int has_second, int32_t second_score)
+{
+    const float max_score = (float)perfect_score, min_score = (float)minimum_score;
+    if (version == 3)
+    {
+        static const int unpaired_one[11]         = { 43, 42, 41, 36, 32, 27, 20, 11, 4, 1, 0 };
+        static const int unpaired_two_perfect[11] = { 2, 16, 23, 30, 31, 32, 34, 36, 38, 40, 42 };
+        static const int unpaired_two[11][11] = {
+            {  2,  2,  2,  1,  1, 0, 0, 0, 0, 0, 0 }, { 20, 14,  7,  3,  2, 1, 0, 0, 0, 0, 0 }, { 20, 16, 10,  6,  3, 1, 0, 0, 0, 0, 0 },
+            { 20, 17, 13,  9,  3, 1, 1, 0, 0, 0, 0 }, { 21, 19, 15,  9,  5, 2, 2, 0, 0, 0, 0 }, { 22, 21, 16, 11, 10, 5, 0, 0, 0, 0, 0 },
+            { 23, 22, 19, 16, 11, 0, 0, 0, 0, 0, 0 }, { 24, 25, 21, 30,  0, 0, 0, 0, 0, 0, 0 }, { 30, 26, 29,  0,  0, 0, 0, 0, 0, 0, 0 },
+            { 30, 27,  0,  0,  0, 0, 0, 0, 0, 0, 0 }, { 30,  0,  0,  0,  0, 0, 0, 0, 0, 0, 0 } };
+        const float norm_factor = 10.0f / (max_score - min_score);
+        if ((float)best_score < min_score) return 0;
+        const int best = imax( (int)max_score - best_score, 0 );
+        int best_bin = (int)((float)best * norm_factor + 0.5f);
+        best_bin = best_bin < 0 ? 0 : (best_bin > 10 ? 10 : best_bin);
+        if (has_second)
+        {
+            const int diff = best_score - second_score;
+            int diff_bin = (int)((float)diff * norm_factor + 0.5f);
+            diff_bin = diff_bin < 0 ? 0 : (diff_bin > 10 ? 10 : diff_bin);
+            return ((float)best == max_score) ? unpaired_two_perfect[best_bin] : unpaired_two[diff_bin][best_bin];
+        }
+        return ((float)best == max_score) ? 44 : unpaired_one[best_bin];
+    }
+    const float diff = max_score - min_score;
+    const float best = (float)best_score;
+    if (best < min_score) return 0;
+    const float best_over = best - min_score;
+    const float sb = (float)second_score;
+    const float best_diff = has_second ? ((best < 0 ? -best : best) - (sb < 0 ? -sb : sb)) : 0.0f;
+    const float bd = best_diff < 0 ? -best_diff : best_diff;
+    if (monotone)
+    {
+        if (!has_second)
+        {
+            if      (best_over >= diff * 0.8f) return 42;
+            else if (best_over >= diff * 0.7f) return 40;
+            else if (best_over >= diff * 0.6f) return 24;
+            else if (best_over >= diff * 0.5f) return 23;
+            else if (best_over >= diff * 0.4f) return 8;
+            else if (best_over >= diff * 0.3f) return 3;
+            return 0;
+        }
+        if      (bd >= diff * 0.9f) return (best_over == diff) ? 39 : 33;
+        else if (bd >= diff * 0.8f) return (best_over == diff) ? 38 : 27;
+        else if (bd >= diff * 0.7f) return (best_over == diff) ? 37 : 26;
+        else if (bd >= diff * 0.6f) return (best_over == diff) ? 36 : 22;
+        else if (bd >= diff * 0.5f) { if (best_over == diff) return 35; if (best_over >= diff * 0.84f) return 25; if (best_over >= diff * 0.68f) return 16; return 5; }
+        else if (bd >= diff * 0.4f) { if (best_over == diff) return 34; if (best_over >= diff * 0.84f) return 21; if (best_over >= diff * 0.68f) return 14; return 4; }
+        else if (bd >= diff * 0.3f) { if (best_over == diff) return 32; if (best_over >= diff * 0.88f) return 18; if (best_over >= diff * 0.67f) return 15; return 3; }
+        else if (bd >= diff * 0.2f) { if (best_over == diff) return 31; if (best_over >= diff * 0.88f) return 17; if (best_over >= diff * 0.67f) return 11; return 0; }
+        else if (bd >= diff * 0.1f) { if (best_over == diff) return 30; if (best_over >= diff * 0.88f) return 12; if (best_over >= diff * 0.67f) return 7; return 0; }
+        else if (bd > 0)            return (best_over >= diff * 0.67f) ? 6 : 2;
+        return (best_over >= diff * 0.67f) ? 1 : 0;
+    }
+    if (!has_second)
+    {
+        if      (best_over >= diff * 0.8f) return 44;
+        else if (best_over >= diff * 0.7f) return 42;
+        else if (best_over >= diff * 0.6f) return 41;
+        else if (best_over >= diff * 0.5f) return 36;
+        else if (best_over >= diff * 0.4f) return 28;
+        else if (best_over >= diff * 0.3f) return 24;
+        return 22;
+    }
+    if      (bd >= diff * 0.9f) return 40;
+    else if (bd >= diff * 0.8f) return 39;
+    else if (bd >= diff * 0.7f) return 38;
+    else if (bd >= diff * 0.6f) return 37;
+    else if (bd >= diff * 0.5f) { if (best_over == diff) return 35; return (best_over >= diff * 0.50f) ? 25 : 20; }
+    else if (bd >= diff * 0.4f) { if (best_over == diff) return 34; return (best_over >= diff * 0.50f) ? 21 : 19; }
+    else if (bd >= diff * 0.3f) { if (best_over == diff) return 33; return (best_over >= diff * 0.5f) ? 18 : 16; }
+    else if (bd >= diff * 0.2f) { if (best_over == diff) return 32; return (best_over >= diff * 0.5f) ? 17 : 12; }
+    else if (bd >= diff * 0.1f) { if (best_over == diff) return 31; return (best_over >= diff * 0.5f) ? 14 : 9; }
+    else if (bd > 0)            return (best_over >= diff * 0.5f) ? 11 : 2;
+    return (best_over >= diff * 0.5f) ? 1 : 0;
+}

@@ -200,6 +200,11 @@ void orc_banded_gotoh_packed_batch(uint32_t band, int type, const orc_gotoh_sche
 
 int orc_num_threads(void);
 
+/* nvBowtie's best / second-best reduction for one read (reduce_inl.h:65-140) and Bowtie2's mapping quality (mapq.h:32-297) */
+void orc_score_reduce(const int32_t* scores, const uint32_t* pos, const uint8_t* rc, uint32_t n, uint32_t read_len, int32_t worst_score,
+                      int64_t out[8]);
+int  orc_mapq(int version, int monotone, int32_t perfect_score, int32_t min_score, int32_t best_score, int has_second, int32_t second_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,3 +158,82 @@ def test_paired_end_equals_cpu_path(amd, orc):
     ok = paired & (want["rc1"] != want["rc2"]) & (np.abs(want["pos1"] - want["pos2"]) <= 500)
     assert ok.sum() >= 0.99 * paired.sum()
     fmi.close()
+
+
+def test_mapq_kernel_covers_every_branch(amd, orc):
+    """nvbio_mapq against the oracle's restatement of BowtieMapq2 / BowtieMapq3 over a grid of (best, second) scores that
+    reaches every branch of mapq.h, for the end-to-end (monotone) and the local scoring ranges"""
+    import torch
+    for monotone, perfect, minimum in ((True, 0, -90), (False, 300, 50), (True, 0, -61), (False, 200, 53)):
+        best = np.arange(minimum - 3, perfect + 1, dtype=np.int64)
+        sec = np.arange(minimum - 3, perfect + 1, 7, dtype=np.int64)
+        B, S = np.meshgrid(best, sec, indexing="ij")
+        keep = S <= B
+        B, S = B[keep], S[keep]
+        has = (np.arange(len(B)) % 5) != 0                      # every fifth pair: no second alignment
+        bk = ((B + (1 << 20)) << 34) | 12345
+        sk = np.where(has, ((S + (1 << 20)) << 34) | (1 << 33) | 999, 0)
+        for version in (2, 3):
+            q, ss = amd.mapq(torch.from_numpy(bk).cuda(), torch.from_numpy(sk).cuda(), perfect, minimum, monotone, version)
+            want = np.array([orc.mapq(version, monotone, perfect, minimum, int(b), bool(h), int(s)) for b, s, h in zip(B, S, has)], dtype=np.uint8)
+            assert np.array_equal(q.cpu().numpy(), want), (monotone, version)
+            assert np.array_equal(ss.cpu().numpy()[has], S[has].astype(np.int32))
+            assert len(np.unique(want)) >= (12 if version == 2 else 8)
+
+
+@pytest.mark.parametrize("mode", ["e2e", "local"])
+def test_pipeline_second_best_and_mapq(amd, orc, mode):
+    """nvBowtie's best / second-best bookkeeping (score_reduce over the candidates in descending key order) and the mapping
+    quality on a genome with diverged repeats: exact copies (second = best), copies with a few substitutions (second < best),
+    tandem copies closer than read_len / 2 (not distinct: no second), copies on the other strand"""
+    import torch
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    rng = np.random.default_rng(77)
+    G = 1_000_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    unit = text[50000:50600].copy()
+    text[200000:200600] = unit                                        # exact copy
+    div = unit.copy(); div[rng.choice(600, 12, replace=False)] = rng.integers(0, 4, 12)
+    text[300000:300600] = div                                         # diverged copy
+    text[400000:400600] = 3 - unit[::-1]                              # reverse-complement copy
+    text[50640:50940] = unit[:300]                                    # tandem copy 40 bp after the original ends
+    text[600000:600060] = np.tile(text[600000:600003], 20)
+    hidx = orc.build_index(text)
+    genome2 = orc.pack2(text)
+    fmi = amd.FMIndex.build(genome2, G, kmer_len=10, sa_int=1)
+    R, M = 6000, 150
+    starts = rng.integers(0, G - M - 8, R)
+    starts[:1500] = 50000 + rng.integers(0, 450, 1500)
+    starts[1500:2000] = 300000 + rng.integers(0, 450, 500)
+    starts[2000:2300] = 400000 + rng.integers(0, 450, 300)
+    reads = mutate_reads(rng, text, starts, M)
+    rcm = rng.random(R) < 0.5
+    reads[rcm] = 3 - reads[rcm][:, ::-1]
+    reads[-20:] = rng.integers(0, 4, (20, M))
+    if mode == "e2e":
+        params = pipeline.SeedExtendParams.end_to_end()
+        osch, otype, perfect, mono = oracle.Scheme(0, 6, 6, -8, -3, -8, -3), oracle.SEMI_GLOBAL, 0, True
+    else:
+        params = pipeline.SeedExtendParams()
+        osch, otype, perfect, mono = oracle.Scheme(2, 2, 6, -8, -3, -8, -3), oracle.LOCAL, 2 * M, False
+    params.mapq = True
+    ms = params.min_score_for(M)
+    want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=otype, scheme=osch,
+                                            second=dict(min_score=ms, perfect_score=perfect, monotone=mono, version=2))
+    rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M)
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    extras = {}
+    bs, bp, brc, nc = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, extras=extras)
+    assert np.array_equal(bs.cpu().numpy(), want[0]) and np.array_equal(bp.cpu().numpy(), want[1])
+    x = want[4]
+    assert np.array_equal(extras["second_score"].cpu().numpy(), x["second_score"])
+    sk = extras["second"].cpu().numpy()
+    has = sk != 0
+    assert np.array_equal(has, x["second_pos"] >= 0)
+    assert np.array_equal((sk & ((1 << 33) - 1))[has], x["second_pos"][has]) and np.array_equal(((sk >> 33) & 1)[has], x["second_rc"][has])
+    assert np.array_equal(extras["mapq"].cpu().numpy(), x["mapq"])
+    q = x["mapq"]
+    # the repeats did their job: reads with a second alignment and a range of qualities; unique reads keep high ones
+    assert has[:2300].mean() > 0.8 and has[2300:-20].mean() < 0.05
+    assert len(np.unique(q)) >= 6 and (q[2300:-20] >= 20).mean() > 0.95 and (q[:1500] <= 1).mean() > 0.5
+    fmi.close()
