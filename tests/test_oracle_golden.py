@@ -350,3 +350,37 @@ def test_band31_out_of_range_text_reads_as_T(orc):
         tp = np.concatenate([t, np.full(181 - N, 3, dtype=np.uint8)])
         b = orc.banded_gotoh(31, oracle.LOCAL, sc, p, tp)
         assert a[1] == b[1]
+
+
+def test_score_reduce_in_descending_order_is_best_and_best_distinct(orc):
+    """nvBowtie's score_reduce loop (reduce_inl.h:65-140) fed a read's candidates in descending order of the selection key
+    ends with a1 = the largest key and a2 = the largest key among the candidates `distinct` from a1 that beat the threshold --
+    the order-free form the GPU passes compute (parity unpinned: restated from device-only code); plus a few fixed points of
+    BowtieMapq2 / BowtieMapq3 (mapq.h)"""
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        n = int(rng.integers(1, 12))
+        scores = rng.integers(-120, 1, n).astype(np.int32)
+        pos = (1000 + rng.integers(0, 4, n) * rng.integers(1, 200) + rng.integers(0, 3, n)).astype(np.uint32)
+        rc = rng.integers(0, 2, n).astype(np.uint8)
+        key = ((scores.astype(np.int64) + (1 << 20)) << 34) | (rc.astype(np.int64) << 33) | pos
+        key = np.unique(key)[::-1]                                   # one entry per (score, strand, position), descending
+        s = ((key >> 34) - (1 << 20)).astype(np.int32); p = (key & ((1 << 33) - 1)).astype(np.uint32); r = ((key >> 33) & 1).astype(np.uint8)
+        worst = -91
+        out = orc.score_reduce(s, p, r, 150, worst)
+        if s[0] <= worst:
+            assert out[0] == 0 and out[4] == 0
+            continue
+        assert out[:4] == (1, int(s[0]), int(p[0]), int(r[0]))
+        far = (r != r[0]) | ~((p[0].astype(np.int64) >= p.astype(np.int64) - np.minimum(p, 75)) & (p[0].astype(np.int64) <= p.astype(np.int64) + 75))
+        cand = np.nonzero(far & (s > worst) & ~((p == p[0]) & (r == r[0])))[0]
+        if len(cand) == 0:
+            assert out[4] == 0
+        else:
+            k = cand[0]
+            assert out[4:] == (1, int(s[k]), int(p[k]), int(r[k]))
+    # end-to-end, 150 bp: perfect unique read; read at the threshold; two equal alignments
+    assert orc.mapq(2, True, 0, -90, 0, False, 0) == 42 and orc.mapq(3, True, 0, -90, 0, False, 0) == 44
+    assert orc.mapq(2, True, 0, -90, -90, False, 0) == 0 and orc.mapq(2, True, 0, -90, -91, False, 0) == 0
+    assert orc.mapq(2, True, 0, -90, -6, True, -6) == 1 and orc.mapq(2, True, 0, -90, 0, True, -90) == 39
+    assert orc.mapq(2, False, 300, 50, 300, False, 0) == 44 and orc.mapq(2, False, 300, 50, 300, True, 300) == 1
