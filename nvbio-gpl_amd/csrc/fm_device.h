@@ -26,6 +26,7 @@ struct DevIndex
     uint32_t        sa_log;   // log2 of the SA sampling interval (4 in the reference's layout)
     const uint2*    ktab;     // optional: SA range of every kmer-mer (in scan order), or NULL
     uint32_t        kmer;
+    const uint2*    dtab;     // optional (full SA + text): ktab with every ONE-row entry replaced by (SA[row], 0xFFFFFFFF)
     const uint32_t* isa;      // optional (with a full SA): isa[p] = row of suffix p, isa[length] = 0
     const uint32_t* text;     // optional: the 2-bit packed text the index was built from
 };

@@ -31,6 +31,7 @@ struct FMIndexImpl
     nvbio_fm_index_view  view;        // host copy (device pointers inside)
     uint2*               ktab;        // owned
     uint32_t             kmer;
+    uint2*               dtab;        // owned, optional: the table of nvbio_fm_match_direct (positions for one-row k-mers)
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
     uint32_t*            isa;         // owned, optional (verify mode)
@@ -44,7 +45,7 @@ struct FMIndexImpl
         d.rec  = (const uint4*)view.bwt_occ_dev;
         d.ssa  = view.ssa_dev;
         d.sa_log = 0; while ((1u << d.sa_log) < (view.sa_int ? view.sa_int : 16u)) ++d.sa_log;
-        d.ktab = ktab; d.kmer = kmer;
+        d.ktab = ktab; d.kmer = kmer; d.dtab = dtab;
         d.isa = isa; d.text = text;
         return d;
     }
@@ -112,6 +113,8 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
         };
 
         uint32_t x = 0, y = f.length, s = 0, nblk = 0;
+        bool     have_pos = false;                              // DIRECT: the k-mer table already gave the text position
+        uint32_t tpos = 0;
 
         if (tab && len >= f.kmer)
         {
@@ -122,11 +125,19 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
                 ok = ok && (c < 4u);
                 key = (key << 2) | (c & 3u);
             }
-            if (ok) { const uint2 r = f.ktab[key]; x = r.x; y = r.y; s = f.kmer; }
+            if (ok)
+            {
+                // DIRECT: the handle's second table holds, for a k-mer with ONE occurrence, that occurrence's text position
+                // instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
+                const uint2 r = (DIRECT && f.dtab) ? f.dtab[key] : f.ktab[key];
+                s = f.kmer;
+                if (DIRECT && f.dtab && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
+                else { x = r.x; y = r.y; }
+            }
         }
 
         bool is_pos = false;
-        for (; s < len && x <= y; ++s)
+        for (; s < len && x <= y && !have_pos; ++s)
         {
             // DIRECT: a lane whose range has collapsed leaves the loop and waits for its neighbours, so that the
             // whole wave runs the two gathers of the tail below once, together, instead of once per collapse time
@@ -160,10 +171,14 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
             if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
             search_step<COUNT>( f, x, y, c, nblk );
         }
-        if (DIRECT && s < len && x == y)
+        if (DIRECT && ((s < len && x == y) || have_pos))
         {
-            const uint32_t sv = f.ssa[x];
-            const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
+            uint32_t p = tpos;
+            if (!have_pos)
+            {
+                const uint32_t sv = f.ssa[x];
+                p = (sv == 0xFFFFFFFFu) ? f.length : sv;                  // row 0 is the empty suffix
+            }
             const uint32_t r  = len - s;
             bool ok = (p >= r);
             if (ok)
@@ -404,20 +419,55 @@ static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t s
     return NVBIO_OK;
 }
 
+// the table of nvbio_fm_match_direct: ktab with every one-row range replaced by (text position of that row, 0xFFFFFFFF)
+__global__ void __launch_bounds__(256)
+fm_dtab_kernel(const uint2* __restrict__ ktab, const uint32_t* __restrict__ sa, const uint32_t length, uint2* __restrict__ dtab, const uint64_t n)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint2 r = ktab[e];
+        if (r.x == r.y)
+        {
+            const uint32_t sv = sa[r.x];
+            r = make_uint2( sv == 0xFFFFFFFFu ? length : sv, 0xFFFFFFFFu );
+        }
+        dtab[e] = r;
+    }
+}
+
+static nvbio_status build_direct_table(FMIndexImpl* idx, hipStream_t stream)
+{
+    idx->dtab = nullptr;
+    if (!(idx->ktab && idx->text && idx->view.ssa_dev && idx->view.sa_int == 1) || getenv( "NVBIO_AMD_NO_DIRECT_TABLE" )) return NVBIO_OK;
+    const uint64_t entries = 1ull << (2 * idx->kmer);
+    size_t free_b = 0, total_b = 0;
+    // an optimisation only: skipped when it would take more than half of what is left
+    if (hipMemGetInfo( &free_b, &total_b ) != hipSuccess || entries * sizeof(uint2) > free_b / 2u) return NVBIO_OK;
+    uint2* d = nullptr;
+    if (hipMalloc( (void**)&d, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); return NVBIO_OK; }
+    hipLaunchKernelGGL( fm_dtab_kernel, dim3( grid_for( entries ) ), dim3(256), 0, stream, (const uint2*)idx->ktab, idx->view.ssa_dev, idx->view.length, d, entries );
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess) { (void)hipFree( d ); set_error( "direct table build failed" ); return NVBIO_ERR_HIP; }
+    idx->dtab = d;
+    idx->owned_bytes += entries * sizeof(uint2);
+    return NVBIO_OK;
+}
+
 nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out,
                             uint32_t* isa, uint32_t* text)
 {
     FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
-    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->isa = nullptr; idx->text = nullptr;
+    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->isa = nullptr; idx->text = nullptr;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     idx->isa = isa; idx->text = text;
     if (isa)  idx->owned_bytes += ((uint64_t)view->length + 1u) * 4ull;
     if (text) idx->owned_bytes += (((uint64_t)view->length + 15u) / 16u) * 4ull;
-    const nvbio_status st = build_kmer_table( idx, kmer_len, stream );
+    nvbio_status st = build_kmer_table( idx, kmer_len, stream );
+    if (st == NVBIO_OK) st = build_direct_table( idx, stream );
     if (st != NVBIO_OK)
     {
+        if (idx->ktab) (void)hipFree( idx->ktab );
         if (owns) { (void)hipFree( (void*)view->bwt_occ_dev ); (void)hipFree( (void*)view->ssa_dev ); }
         if (isa)  (void)hipFree( isa );
         if (text) (void)hipFree( text );
@@ -457,6 +507,7 @@ nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
     FMIndexImpl* idx = (FMIndexImpl*)index;
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     if (idx->ktab) (void)hipFree( idx->ktab );
+    if (idx->dtab) (void)hipFree( idx->dtab );
     if (idx->isa)  (void)hipFree( idx->isa );
     if (idx->text) (void)hipFree( idx->text );
     if (idx->owns_arrays) { (void)hipFree( (void*)idx->view.bwt_occ_dev ); (void)hipFree( (void*)idx->view.ssa_dev ); }
