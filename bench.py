@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--ref-len", type=float, default=3e9, help="reference length (symbols)")
     ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--kmer", type=int, default=16, help="k of the k-mer SA-range table (0 disables)")
+    ap.add_argument("--kmer", type=int, default=17, help="k of the k-mer SA-range table (0 disables; 17 = 128 GiB, 16 = 32 GiB + the 32 GiB position table)")
     ap.add_argument("--sa-int", type=int, default=1, help="SA sampling interval of the index built for the run")
     ap.add_argument("--verify", action="store_true", help="build the index with the SA/ISA/text verification shortcut (needs --sa-int 1)")
     ap.add_argument("--mode", choices=("e2e", "local"), default="e2e",
@@ -160,7 +160,16 @@ def main():
     genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
     torch.cuda.synchronize()
     t1 = time.time()
-    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
+    try:
+        fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
+    except amd.NvbioError as e:
+        if args.kmer <= 16 or "memory" not in str(e):
+            raise
+        # the k = 17 table needs 128 + 32 GiB while it is built: fall back to k = 16 on a card that cannot give that
+        log("k-mer table k=%d does not fit (%s): falling back to k=16" % (args.kmer, e))
+        args.kmer = 16
+        torch.cuda.empty_cache()
+        fmi = amd.FMIndex.build(genome, n, kmer_len=16, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
     torch.cuda.synchronize()
     t2 = time.time()
     log("reference %d symbols generated in %.2fs, index built on the GPU in %.2fs (k-mer table k=%d, %.2f GB owned)"

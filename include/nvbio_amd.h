@@ -85,8 +85,8 @@ typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
  * reference's storage-free views).  kmer_len > 0 additionally builds, on the GPU, a table with
  * the SA range of every kmer_len-mer (4^kmer_len x 8 bytes, owned by the handle) which match()
  * uses to replace its first kmer_len backward-search steps with one lookup; results are
- * identical with and without it.  kmer_len = 0 disables it; values up to 16 are accepted
- * (k = 12: 128 MiB, k = 14: 2 GiB, k = 16: 32 GiB -- sized for 288 GB of HBM).
+ * identical with and without it.  kmer_len = 0 disables it; values up to 17 are accepted
+ * (k = 12: 128 MiB, k = 14: 2 GiB, k = 16: 32 GiB, k = 17: 128 GiB -- sized for 288 GB of HBM).
  * Replaces: constructing nvbio::fm_index / io::FMIndexDataDevice (nvbio/io/fmindex/fmindex_impl.cu:740-816). */
 nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len,
                                    void* stream, nvbio_fm_index_t* out);
@@ -100,7 +100,7 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
  * rather than sorted slowly. */
 typedef struct
 {
-    uint32_t kmer_len;   /* k of the k-mer SA-range table, 0..16 (0 = none)                                  */
+    uint32_t kmer_len;   /* k of the k-mer SA-range table, 0..17 (0 = none)                                  */
     uint32_t sa_int;     /* SA sampling interval, power of two in [1,64]; 0 = 16 (the reference's SA_INT)     */
     uint32_t max_lcp;    /* give up on texts with repeats longer than this many symbols; 0 = 4096            */
     uint32_t verify;     /* 1: also keep the inverse suffix array (4(n+1) bytes) and a copy of the text, so that

@@ -659,7 +659,7 @@ extern "C" nvbio_status nvbio_fm_index_load(const char* bwt_path, const char* sa
                                             void* stream, nvbio_fm_index_t* out)
 {
     NVB_REQUIRE( bwt_path && out, "bwt_path/out is NULL" );
-    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
+    NVB_REQUIRE( kmer_len <= 17, "kmer_len must be <= 17" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     return load_impl( bwt_path, sa_path, device, kmer_len, (hipStream_t)stream, out );
 }
@@ -686,7 +686,7 @@ extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t
     const uint32_t kmer_len = options ? options->kmer_len : 0u;
     const uint32_t sa_int   = (options && options->sa_int) ? options->sa_int : 16u;
     const uint32_t max_lcp  = options ? options->max_lcp : 0u;
-    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
+    NVB_REQUIRE( kmer_len <= 17, "kmer_len must be <= 17" );
     NVB_REQUIRE( sa_int <= 64 && (sa_int & (sa_int - 1u)) == 0, "sa_int must be a power of two in [1,64]" );
     const bool verify = options && options->verify;
     NVB_REQUIRE( !verify || sa_int == 1, "verify needs the full suffix array (sa_int = 1)" );

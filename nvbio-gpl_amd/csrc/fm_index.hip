@@ -118,7 +118,7 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
 
         if (tab && len >= f.kmer)
         {
-            uint32_t key = 0; bool ok = true;
+            uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
             for (uint32_t t = 0; t < f.kmer; ++t)
             {
                 const uint32_t c = sym( t );
@@ -489,7 +489,7 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
     NVB_REQUIRE( view && out, "view/out is NULL" );
     NVB_REQUIRE( view->bwt_occ_dev != nullptr, "bwt_occ_dev is NULL" );
     NVB_REQUIRE( ((uintptr_t)view->bwt_occ_dev & 31u) == 0, "bwt_occ_dev must be 32-byte aligned" );
-    NVB_REQUIRE( kmer_len <= 16, "kmer_len must be <= 16" );
+    NVB_REQUIRE( kmer_len <= 17, "kmer_len must be <= 17" );
     NVB_REQUIRE( view->L2[4] == view->length, "L2[4] must equal length" );
     const uint32_t K = view->sa_int ? view->sa_int : 16u;
     NVB_REQUIRE( K <= 64 && (K & (K - 1u)) == 0, "sa_int must be a power of two in [1,64]" );

@@ -145,7 +145,7 @@ def test_empty_and_error_paths(amd, fm_golden):
     with pytest.raises(amd.NvbioError):
         amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"][:8], g["ssa"])
     with pytest.raises(amd.NvbioError):
-        amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"], kmer_len=17)
+        amd.FMIndex.from_arrays(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"], kmer_len=18)
     fmi.close()
 
 
