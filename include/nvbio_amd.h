@@ -212,11 +212,26 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
 
 /* nvbio_fm_filter_locate[_direct] and nvbio_hits_to_diagonals (below) in one pass: the expansion writes each hit's
  * diagonal key (read << 34 | strand << 33 | diagonal + 1024) instead of the (position, query) pair; direct_dev may
- * be NULL (plain ranges).  keys_dev[h - begin] equals nvbio_hits_to_diagonals of the hit nvbio_fm_filter_locate writes. */
+ * be NULL (plain ranges).  keys_dev[h - begin] equals nvbio_hits_to_diagonals of the hit nvbio_fm_filter_locate writes.
+ * query_ids_dev (optional): the seed id of query i when the ranges are a compacted subset of a seed set (the residual
+ * list of nvbio_fm_match_seed_diagonals); NULL = query i is seed i. */
 nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
                                               const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
                                               uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
-                                              uint32_t strand, uint64_t* keys_dev, void* stream);
+                                              uint32_t strand, const uint32_t* query_ids_dev, uint64_t* keys_dev, void* stream);
+
+/* The whole seed pass of one strand in one kernel, for handles that hold the full suffix array and the text: nvBowtie's
+ * match_range over every seed (mapping_inl.h:73-86,193-282) followed, for every seed that ends on ONE SA row, by what
+ * FMIndexFilter::rank's scan, FMIndexFilter::locate (filter_inl.h:193-252), hit_to_diagonal (examples/fmmap/fmmap.cu:92-117)
+ * and the removal of adjacent duplicate diagonals would do with it: the hit's diagonal key goes straight to keys_dev
+ * (as nvbio_fm_filter_locate_diagonals writes it; seed order inside a block of 256 seeds, blocks in arbitrary order; a key
+ * equal to the previous key of its block is dropped).  Seeds that end on several rows go to the residual list
+ * (residual_ranges_dev[r], residual_ids_dev[r] = seed id) for nvbio_fm_filter_scan + nvbio_fm_filter_locate_diagonals.
+ * Capacities: seeds->n entries each.  counts_dev[0] = keys written, counts_dev[1] = residual seeds (zeroed by the call).
+ * The multiset of keys equals that of the plain operators up to duplicates. */
+nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
+                                           uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
+                                           uint32_t* counts_dev, void* stream);
 
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)

@@ -288,6 +288,26 @@ class FMIndex:
                                            _stream_ptr(self.device)))
         return ranges, direct
 
+    def match_seed_diagonals(self, seeds, flags, read_len, strand, buffers=None):
+        """the seed pass of one strand straight to candidate diagonals (nvbio_fm_match_seed_diagonals) ->
+        (keys int64 [n_keys], residual_ranges int32 [n_res, 2], residual_ids int32 [n_res]); one host read of the two counts.
+        buffers: optional dict reused across calls (the three n-entry output arrays)"""
+        torch = _torch()
+        n = seeds.n
+        if buffers is None:
+            buffers = {}
+        if buffers.get("n") != n:
+            buffers["n"] = n
+            buffers["keys"] = torch.empty(n, dtype=torch.int64, device=self.device)
+            buffers["ranges"] = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+            buffers["ids"] = torch.empty(n, dtype=torch.int32, device=self.device)
+            buffers["counts"] = torch.empty(2, dtype=torch.int32, device=self.device)
+        qs = seeds.c_struct()
+        _check(lib().nvbio_fm_match_seed_diagonals(self._h, ctypes.byref(qs), ctypes.c_uint32(flags), ctypes.c_uint32(read_len),
+                                                   ctypes.c_uint32(strand), _ptr(buffers["keys"]), _ptr(buffers["ranges"]),
+                                                   _ptr(buffers["ids"]), _ptr(buffers["counts"]), _stream_ptr(self.device)))
+        return buffers
+
     def rank(self, rows, syms):
         torch = _torch()
         rows = _dev_tensor(rows, torch.int32, self.device)
@@ -386,15 +406,17 @@ class FMIndexFilter:
                                             ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))
         return hits
 
-    def locate_diagonals(self, begin, end, seeds_per_read, seed_interval, seed_len, read_len, strand):
+    def locate_diagonals(self, begin, end, seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids=None):
         """locate() and hits_to_diagonals() in one pass (nvbio_fm_filter_locate_diagonals): int64 keys
-        read << 34 | strand << 33 | diagonal + 1024 of hit indices [begin, end)"""
+        read << 34 | strand << 33 | diagonal + 1024 of hit indices [begin, end); query_ids: the seed id of every range when
+        the ranges are a compacted subset (FMIndex.match_seed_diagonals' residual list)"""
         torch = _torch()
         keys = torch.empty(end - begin, dtype=torch.int64, device=self._index.device)
         _check(lib().nvbio_fm_filter_locate_diagonals(
             self._index._h, _ptr(self._ranges), _ptr(self._slots), _ptr(self._direct), ctypes.c_uint32(self._n_queries),
             ctypes.c_uint64(begin), ctypes.c_uint64(end), ctypes.c_uint32(seeds_per_read), ctypes.c_uint32(seed_interval),
-            ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), ctypes.c_uint32(strand), _ptr(keys), _stream_ptr(self._index.device)))
+            ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), ctypes.c_uint32(strand), _ptr(query_ids), _ptr(keys),
+            _stream_ptr(self._index.device)))
         return keys
 
     def n_hits(self):

@@ -90,112 +90,208 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
 // remaining symbol plus the SA lookup of a later locate).  Such a query reports its single hit as the TEXT
 // POSITION (ranges[i] = (pos, pos), direct[i] = 1) -- the position locate() would return for the final row;
 // a mismatch reports the empty range (1,0).  Needs the full SA and the text (handles built with sa_int = 1).
+template <int BITS, bool COUNT, bool TABLE, bool DIRECT>
+__device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev& q, const uint32_t flags, const bool tab, const bool verify,
+                                          const uint32_t i, uint32_t& x_out, uint32_t& y_out, uint32_t& nblk_out, bool& is_pos_out)
+{
+    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
+    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
+    uint32_t begin, len;
+    string_bounds( q, i, begin, len );
+    SymbolReader<BITS> rd( q.symbols );
+
+    // symbol s in scan order
+    auto sym = [&](const uint32_t s) -> uint32_t {
+        const uint32_t c = rd.get( fwd ? begin + s : begin + len - 1u - s );
+        return (comp && c < 4u) ? 3u - c : c;
+    };
+
+    uint32_t x = 0, y = f.length, s = 0, nblk = 0;
+    bool     have_pos = false;                              // DIRECT: the k-mer table already gave the text position
+    uint32_t tpos = 0;
+
+    if (tab && len >= f.kmer)
+    {
+        uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
+        for (uint32_t t = 0; t < f.kmer; ++t)
+        {
+            const uint32_t c = sym( t );
+            ok = ok && (c < 4u);
+            key = (key << 2) | (c & 3u);
+        }
+        if (ok)
+        {
+            // DIRECT: the handle's second table holds, for a k-mer with ONE occurrence, that occurrence's text position
+            // instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
+            const uint2 r = (DIRECT && f.dtab) ? f.dtab[key] : f.ktab[key];
+            s = f.kmer;
+            if (DIRECT && f.dtab && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
+            else { x = r.x; y = r.y; }
+        }
+    }
+
+    bool is_pos = false;
+    for (; s < len && x <= y && !have_pos; ++s)
+    {
+        // DIRECT: a lane whose range has collapsed leaves the loop and waits for its neighbours, so that the
+        // whole wave runs the two gathers of the tail below once, together, instead of once per collapse time
+        if (DIRECT && x == y) break;
+        if (verify && x == y && len - s >= 2u)
+        {
+            // The range is ONE row: the match can only continue along the text to the left of
+            // SA[x].  Compare the rest of the pattern with the text there and jump to the row of
+            // the position reached (ISA): 3 gathers instead of one per remaining symbol.  On a
+            // mismatch the loop resumes at the offending symbol from the exact row the reference
+            // would be at, so the (empty) range it returns is the reference's.
+            const uint32_t sv = f.ssa[x];
+            const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
+            const uint32_t r  = len - s;
+            // the row reached if everything matches is requested together with the text words
+            // (speculatively: both depend only on p), so the tail costs two dependent rounds
+            const uint32_t full = (p >= r) ? f.isa[p - r] : 0u;
+            SymbolReader<2> tr( f.text );
+            uint32_t t = 0;
+            while (t < r && t < p)
+            {
+                const uint32_t c = sym( s + t );
+                if (c > 3u || c != tr.get( p - 1u - t )) break;
+                ++t;
+            }
+            if (t == r)  { x = y = full; s = len; }
+            else if (t)  { x = y = f.isa[p - t]; s += t; }
+            if (s >= len) break;
+        }
+        const uint32_t c = sym( s );
+        if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
+        search_step<COUNT>( f, x, y, c, nblk );
+    }
+    if (DIRECT && ((s < len && x == y) || have_pos))
+    {
+        uint32_t p = tpos;
+        if (!have_pos)
+        {
+            const uint32_t sv = f.ssa[x];
+            p = (sv == 0xFFFFFFFFu) ? f.length : sv;                  // row 0 is the empty suffix
+        }
+        const uint32_t r  = len - s;
+        bool ok = (p >= r);
+        if (ok)
+        {
+            SymbolReader<2> tr( f.text );
+            for (uint32_t t = 0; t < r && ok; ++t)
+            {
+                const uint32_t c = sym( s + t );
+                ok = (c < 4u) && (c == tr.get( p - 1u - t ));
+            }
+        }
+        if (ok) { x = y = p - r; is_pos = true; }
+        else    { x = 1u; y = 0u; }
+    }
+    x_out = x; y_out = y; nblk_out = nblk; is_pos_out = is_pos;
+}
+
 template <int BITS, bool COUNT, bool TABLE, bool DIRECT = false>
 __global__ void __launch_bounds__(256)
 fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, uint2* __restrict__ ranges, uint32_t* __restrict__ blocks,
                 uint8_t* __restrict__ direct = nullptr)
 {
-    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
-    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
-    const bool tab  = TABLE && (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
+    const bool tab    = TABLE && (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE) && !COUNT;
     const bool verify = (f.isa != nullptr) && (f.sa_log == 0) && !(flags & NVBIO_FM_NO_VERIFY) && !COUNT;
 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x)
     {
-        uint32_t begin, len;
-        string_bounds( q, i, begin, len );
-        SymbolReader<BITS> rd( q.symbols );
-
-        // symbol s in scan order
-        auto sym = [&](const uint32_t s) -> uint32_t {
-            const uint32_t c = rd.get( fwd ? begin + s : begin + len - 1u - s );
-            return (comp && c < 4u) ? 3u - c : c;
-        };
-
-        uint32_t x = 0, y = f.length, s = 0, nblk = 0;
-        bool     have_pos = false;                              // DIRECT: the k-mer table already gave the text position
-        uint32_t tpos = 0;
-
-        if (tab && len >= f.kmer)
-        {
-            uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
-            for (uint32_t t = 0; t < f.kmer; ++t)
-            {
-                const uint32_t c = sym( t );
-                ok = ok && (c < 4u);
-                key = (key << 2) | (c & 3u);
-            }
-            if (ok)
-            {
-                // DIRECT: the handle's second table holds, for a k-mer with ONE occurrence, that occurrence's text position
-                // instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
-                const uint2 r = (DIRECT && f.dtab) ? f.dtab[key] : f.ktab[key];
-                s = f.kmer;
-                if (DIRECT && f.dtab && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
-                else { x = r.x; y = r.y; }
-            }
-        }
-
-        bool is_pos = false;
-        for (; s < len && x <= y && !have_pos; ++s)
-        {
-            // DIRECT: a lane whose range has collapsed leaves the loop and waits for its neighbours, so that the
-            // whole wave runs the two gathers of the tail below once, together, instead of once per collapse time
-            if (DIRECT && x == y) break;
-            if (verify && x == y && len - s >= 2u)
-            {
-                // The range is ONE row: the match can only continue along the text to the left of
-                // SA[x].  Compare the rest of the pattern with the text there and jump to the row of
-                // the position reached (ISA): 3 gathers instead of one per remaining symbol.  On a
-                // mismatch the loop resumes at the offending symbol from the exact row the reference
-                // would be at, so the (empty) range it returns is the reference's.
-                const uint32_t sv = f.ssa[x];
-                const uint32_t p  = (sv == 0xFFFFFFFFu) ? f.length : sv;      // row 0 is the empty suffix
-                const uint32_t r  = len - s;
-                // the row reached if everything matches is requested together with the text words
-                // (speculatively: both depend only on p), so the tail costs two dependent rounds
-                const uint32_t full = (p >= r) ? f.isa[p - r] : 0u;
-                SymbolReader<2> tr( f.text );
-                uint32_t t = 0;
-                while (t < r && t < p)
-                {
-                    const uint32_t c = sym( s + t );
-                    if (c > 3u || c != tr.get( p - 1u - t )) break;
-                    ++t;
-                }
-                if (t == r)  { x = y = full; s = len; }
-                else if (t)  { x = y = f.isa[p - t]; s += t; }
-                if (s >= len) break;
-            }
-            const uint32_t c = sym( s );
-            if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
-            search_step<COUNT>( f, x, y, c, nblk );
-        }
-        if (DIRECT && ((s < len && x == y) || have_pos))
-        {
-            uint32_t p = tpos;
-            if (!have_pos)
-            {
-                const uint32_t sv = f.ssa[x];
-                p = (sv == 0xFFFFFFFFu) ? f.length : sv;                  // row 0 is the empty suffix
-            }
-            const uint32_t r  = len - s;
-            bool ok = (p >= r);
-            if (ok)
-            {
-                SymbolReader<2> tr( f.text );
-                for (uint32_t t = 0; t < r && ok; ++t)
-                {
-                    const uint32_t c = sym( s + t );
-                    ok = (c < 4u) && (c == tr.get( p - 1u - t ));
-                }
-            }
-            if (ok) { x = y = p - r; is_pos = true; }
-            else    { x = 1u; y = 0u; }
-        }
+        uint32_t x, y, nblk; bool is_pos;
+        match_one<BITS,COUNT,TABLE,DIRECT>( f, q, flags, tab, verify, i, x, y, nblk, is_pos );
         ranges[i] = make_uint2( x, y );
         if (COUNT) blocks[i] = nblk;
         if (DIRECT) direct[i] = is_pos ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Seed pass straight to candidate diagonals (nvbio_fm_match_seed_diagonals): fm_match_kernel<.., DIRECT> over the seeds
+// of a read set, followed -- in the same kernel -- by what FMIndexFilter::rank's scan, FMIndexFilter::locate,
+// hit_to_diagonal (examples/fmmap/fmmap.cu:92-117) and the adjacent-duplicate removal do for a seed with ONE hit:
+//   * a seed that ended on one SA row is resolved to its text position (already known when the search finished on the
+//     text; one SA gather otherwise -- the handle holds the full SA);
+//   * its diagonal key (read << 34 | strand << 33 | position - offset of the seed in the read + 1024) is formed;
+//   * the keys of a block are compacted in LDS in seed order, keys equal to their predecessor are dropped (consecutive
+//     seeds of a read that agree on the diagonal), and the survivors are appended to keys_out with ONE atomic add per
+//     block and loop iteration.
+// Seeds that end on SEVERAL rows (repeats) are appended to a residual list (seed id, range) for the ordinary
+// scan + locate path.  The order of keys_out across blocks is arbitrary; nothing downstream depends on it (the per-read
+// reduction uses a total order).  counts[0] = keys written, counts[1] = residual seeds.
+// ---------------------------------------------------------------------------------------------
+template <int BITS>
+__global__ void __launch_bounds__(256)
+fm_seed_diagonals_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, const uint32_t read_len, const uint32_t strand,
+                         uint64_t* __restrict__ keys_out, uint2* __restrict__ res_ranges, uint32_t* __restrict__ res_ids,
+                         unsigned int* __restrict__ counts)
+{
+    __shared__ uint64_t s_keys[256];
+    __shared__ uint32_t s_wave[2][4];
+    __shared__ uint32_t s_base[2];
+    const bool tab = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    for (uint32_t base = blockIdx.x * 256u; base < q.n; base += gridDim.x * 256u)
+    {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t x = 1u, y = 0u, nblk; bool is_pos = false;
+        if (i < q.n) match_one<BITS,false,true,true>( f, q, flags, tab, false, i, x, y, nblk, is_pos );
+        bool single = is_pos;
+        if (!is_pos && x == y)                                   // one row left when the pattern ran out: its position
+        {
+            const uint32_t sv = f.ssa[x];
+            x = (sv == 0xFFFFFFFFu) ? f.length : sv; single = true;
+        }
+        const bool multi = !single && x < y;
+        uint64_t key = 0;
+        if (single)
+        {
+            const uint32_t rid = i / q.spr;
+            uint32_t       p   = (i - rid * q.spr) * q.interval;
+            if (strand) p = read_len - p - q.fixed_len;
+            key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
+        }
+        // ---- compaction 1: the block's keys in seed order ----
+        const uint64_t m1 = __ballot( single ), m2 = __ballot( multi );
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll( m1 ); s_wave[1][wave] = (uint32_t)__popcll( m2 ); }
+        __syncthreads();
+        uint32_t off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
+        #pragma unroll
+        for (uint32_t w = 0; w < 4; ++w)
+        {
+            if (w < wave) { off1 += s_wave[0][w]; off2 += s_wave[1][w]; }
+            tot1 += s_wave[0][w]; tot2 += s_wave[1][w];
+        }
+        if (single) s_keys[off1 + (uint32_t)__popcll( m1 & below )] = key;
+        __syncthreads();
+        // ---- drop keys equal to their predecessor; compaction 2 ----
+        const bool     cand = threadIdx.x < tot1;
+        const uint64_t k2   = cand ? s_keys[threadIdx.x] : 0ull;
+        const bool     keep = cand && (threadIdx.x == 0u || s_keys[threadIdx.x - 1u] != k2);
+        const uint64_t m3   = __ballot( keep );
+        __syncthreads();                                         // s_wave / s_keys are reused
+        if (lane == 0) s_wave[0][wave] = (uint32_t)__popcll( m3 );
+        __syncthreads();
+        uint32_t off3 = 0, tot3 = 0;
+        #pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) { if (w < wave) off3 += s_wave[0][w]; tot3 += s_wave[0][w]; }
+        if (threadIdx.x == 0)
+        {
+            s_base[0] = tot3 ? atomicAdd( &counts[0], tot3 ) : 0u;
+            s_base[1] = tot2 ? atomicAdd( &counts[1], tot2 ) : 0u;
+        }
+        __syncthreads();
+        if (keep)  keys_out[s_base[0] + off3 + (uint32_t)__popcll( m3 & below )] = k2;
+        if (multi)
+        {
+            const uint32_t r = s_base[1] + off2 + (uint32_t)__popcll( m2 & below );
+            res_ranges[r] = make_uint2( x, y ); res_ids[r] = i;
+        }
+        __syncthreads();
     }
 }
 
@@ -319,7 +415,7 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t* __restrict__
 
 // seed enumeration of a hit's query id -> its diagonal key (hit_to_diagonal, examples/fmmap/fmmap.cu:92-117; see
 // nvbio_hits_to_diagonals): with KEYS the expansion writes the 8-byte key instead of the (position, query) pair
-struct DiagSpec { uint32_t spr, interval, seed_len, read_len, strand; };
+struct DiagSpec { uint32_t spr, interval, seed_len, read_len, strand; const uint32_t* qid; };   // qid: optional seed id of every query
 
 template <bool KEYS>
 __global__ void __launch_bounds__(256)
@@ -360,8 +456,9 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
                     const uint32_t pos = is_pos ? j : f.ssa[j >> f.sa_log] + t;
                     if (KEYS)
                     {
-                        const uint32_t rid = slot / ds.spr;
-                        uint32_t       p   = (slot - rid * ds.spr) * ds.interval;
+                        const uint32_t sid = ds.qid ? ds.qid[slot] : slot;
+                        const uint32_t rid = sid / ds.spr;
+                        uint32_t       p   = (sid - rid * ds.spr) * ds.interval;
                         if (ds.strand) p = ds.read_len - p - ds.seed_len;
                         keys[h - begin] = ((uint64_t)rid << 34) | ((uint64_t)(ds.strand & 1u) << 33) | ((uint64_t)pos + 1024u - p);
                     }
@@ -736,6 +833,41 @@ nvbio_status nvbio_fm_match_direct(nvbio_fm_index_t index, const nvbio_string_se
     return NVBIO_OK;
 }
 
+nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
+                                           uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
+                                           uint32_t* counts_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    StringSetDev q; NVB_CHECK( make_set( seeds, &q ) );
+    NVB_REQUIRE( counts_dev != nullptr, "counts_dev is NULL" );
+    NVB_REQUIRE( q.spr > 0, "the string set must enumerate seeds (seeds_per_string > 0)" );
+    NVB_REQUIRE( (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
+    if (!(idx->text && idx->view.ssa_dev && idx->view.sa_int == 1))
+    {
+        set_error( "nvbio_fm_match_seed_diagonals needs the full suffix array and the text: build the index with sa_int = 1" );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    NVB_HIP( hipMemsetAsync( counts_dev, 0, 2 * sizeof(uint32_t), s ) );
+    if (q.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && residual_ranges_dev && residual_ids_dev, "NULL device pointer" );
+    const DevIndex f = idx->dev();
+    const dim3 grid( grid_for( q.n ) ), block( 256 );
+#define NVB_LAUNCH_SD(BITS) hipLaunchKernelGGL( (fm_seed_diagonals_kernel<BITS>), grid, block, 0, s, f, q, flags, read_len, strand, keys_dev, \
+                                                (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev )
+    switch (seeds->symbol_bits)
+    {
+    case 2: NVB_LAUNCH_SD(2); break;
+    case 4: NVB_LAUNCH_SD(4); break;
+    default: NVB_LAUNCH_SD(8); break;
+    }
+#undef NVB_LAUNCH_SD
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
 nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
                                            const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
                                            nvbio_uint2* hits_dev, void* stream)
@@ -755,7 +887,7 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
 nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
                                               const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
                                               uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
-                                              uint32_t strand, uint64_t* keys_dev, void* stream)
+                                              uint32_t strand, const uint32_t* query_ids_dev, uint64_t* keys_dev, void* stream)
 {
     NVB_REQUIRE( index != nullptr, "index is NULL" );
     if (end <= begin) return NVBIO_OK;
@@ -765,7 +897,7 @@ nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbi
     FMIndexImpl* idx = (FMIndexImpl*)index;
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, strand };
+    const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids_dev };
     hipLaunchKernelGGL( fm_filter_locate_kernel<true>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
                         idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)nullptr, direct_dev, ds, keys_dev );
     NVB_HIP( hipGetLastError() );

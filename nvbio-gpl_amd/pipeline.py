@@ -33,6 +33,8 @@ class SeedExtendParams:
                                                     # the first k rows of a seed's SA range (a deterministic stand-in for
                                                     # nvBowtie's max_hits cap, which guards against repeat seeds)
         self.direct = True                          # use match_direct when the index holds the full SA and the text
+        self.fused_seed_pass = True                 # ... and run match + scan + locate + diagonal keys + adjacent dedupe of
+                                                    # every single-hit seed in ONE kernel (nvbio_fm_match_seed_diagonals)
         self.mapq = False                           # also keep nvBowtie's second-best alignment per read and compute the
                                                     # mapping quality (score_reduce + BowtieMapq2); results go to `extras`
         self.mapq_version = 2
@@ -139,7 +141,52 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     use_direct = params.direct and fmi.supports_direct()
     results, n_cand, scored = [], 0, []
-    for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
+    fused = use_direct and params.fused_seed_pass
+    if fused:
+        # 2.-4. in one kernel per strand: every seed that ends on one SA row leaves it as a deduplicated diagonal key; the few
+        #    that end on several rows (repeats) come back as a residual list and take the scan + locate path.  Both strands'
+        #    seed passes are enqueued first; each one's two counts travel to pinned host memory behind it, so that the host
+        #    learns the forward strand's candidate count while the reverse strand's pass runs and the GPU never waits for it.
+        bufs = getattr(fmi, "_seed_bufs", None)
+        if bufs is None:
+            bufs = fmi._seed_bufs = ({}, {})
+        pending = []
+        for strand, flags in ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT)):
+            b = bufs[strand]
+            e = tick("match_fw" if strand == 0 else "match_rc")
+            fmi.match_seed_diagonals(qs, flags, M, strand, b)
+            tock(e)
+            if "host" not in b:
+                b["host"] = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            b["host"].copy_(b["counts"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.append((strand, b, ev))
+        for strand, b, ev in pending:
+            ev.synchronize()
+            n_keys, n_res = int(b["host"][0]), int(b["host"][1])
+            keys = b["keys"][:n_keys]
+            if n_res:
+                e = tick("locate")
+                ranges = b["ranges"][:n_res]
+                if params.max_seed_hits is not None:
+                    x = ranges[:, 0].to(torch.int64) & 0xFFFFFFFF
+                    y = ranges[:, 1].to(torch.int64) & 0xFFFFFFFF
+                    ycap = torch.minimum(y, x + (params.max_seed_hits - 1))
+                    ranges = torch.stack([ranges[:, 0], torch.where(ycap >= 2 ** 31, ycap - 2 ** 32, ycap).to(torch.int32)], dim=1).contiguous()
+                flt = FMIndexFilter()
+                n_hits = flt.rank_ranges(fmi, ranges, None)
+                rkeys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, query_ids=b["ids"][:n_res])
+                rkeys = torch.unique_consecutive(rkeys)
+                if rkeys.numel() > 2 * R:
+                    rkeys = torch.unique(rkeys)
+                keys = torch.cat([keys, rkeys])
+                tock(e)
+            if keys.numel() == 0:
+                continue
+            n_cand += keys.numel()
+            results.append(extend(keys, "_rc" if strand else "_fw"))
+    for strand, flags in (() if fused else ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT))):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
         #    (FMIndexFilter::rank = match + scan; the two halves are called separately so that the
         #    match kernel can be timed on its own)
