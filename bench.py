@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads timed on the host cores (0: sized for --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-direct", action="store_true", help="plain match() + locate() instead of the fused direct-position seed pass")
+    ap.add_argument("--no-fused-seeds", action="store_true", help="match_direct + scan + locate_diagonals + dedupe as separate operators instead of the one-kernel seed pass")
     ap.add_argument("--no-plain-ab", action="store_true", help="skip the (untimed) run through the plain operators without the two exact shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -181,6 +182,7 @@ def main():
     batch = pipeline.ReadBatch(reads4, R, M)
     params = pipeline.SeedExtendParams.end_to_end() if args.mode == "e2e" else pipeline.SeedExtendParams()
     params.direct = not args.no_direct
+    params.fused_seed_pass = not args.no_fused_seeds
     params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c
     scheme_t = tuple(int(getattr(sv, f)) for f, _ in sv._fields_)
@@ -298,13 +300,14 @@ def main():
     match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
     achieved = alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
     use_direct = bool(params.direct and fmi.supports_direct())
+    use_fused = bool(use_direct and params.fused_seed_pass)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if (tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer and tj.get("sa_int", 16) == args.sa_int
-                    and bool(tj.get("direct", False)) == use_direct):
+                    and bool(tj.get("direct", False)) == use_direct and bool(tj.get("fused", False)) == use_fused):
                 traffic = tj.get("match_hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -323,13 +326,15 @@ def main():
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
                    "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
-                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "sa_int": args.sa_int, "match_direct": use_direct, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
+                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
-        "roofline": {"kernel": ("fm_match_kernel<4,false,true,%s> (seed pass, one strand of %d seeds per launch%s)"
-                                % ("true" if use_direct else "false", n_seeds,
-                                   "; single-row searches finish on the text and return positions: match + locate fused" if use_direct else "")),
+        "roofline": {"kernel": (("fm_seed_diagonals_kernel<4> (seed pass, one strand of %d seeds per launch: match, and for every seed that ends "
+                                 "on one SA row also scan + locate + diagonal key + adjacent dedupe, in one kernel)" % n_seeds) if use_fused else
+                                ("fm_match_kernel<4,false,true,%s> (seed pass, one strand of %d seeds per launch%s)"
+                                 % ("true" if use_direct else "false", n_seeds,
+                                    "; single-row searches finish on the text and return positions: match + locate fused" if use_direct else ""))),
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,
