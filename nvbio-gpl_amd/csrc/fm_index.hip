@@ -854,7 +854,9 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     if (q.n == 0) return NVBIO_OK;
     NVB_REQUIRE( keys_dev && residual_ranges_dev && residual_ids_dev, "NULL device pointer" );
     const DevIndex f = idx->dev();
-    const dim3 grid( grid_for( q.n ) ), block( 256 );
+    unsigned cap = 256u * 256u;                               // measured: scripts/exp_occupancy.sh (8 k blocks: 5.58 ms, 64 k: 5.32, uncapped: 5.6)
+    if (const char* e = getenv( "NVBIO_AMD_SEED_GRID_BLOCKS" )) { const long v = atol( e ); if (v > 0) cap = (unsigned)v; }   // occupancy experiments
+    const dim3 grid( grid_for( q.n, 256, cap ) ), block( 256 );
 #define NVB_LAUNCH_SD(BITS) hipLaunchKernelGGL( (fm_seed_diagonals_kernel<BITS>), grid, block, 0, s, f, q, flags, read_len, strand, keys_dev, \
                                                 (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev )
     switch (seeds->symbol_bits)
