@@ -227,6 +227,7 @@ class FMIndex:
             _torch().cuda.synchronize(self.device)
             _check(lib().nvbio_fm_index_destroy(self._h))
             self._h = None
+            self._seed_bufs = None                   # the pipeline's per-strand seed-pass buffers (pipeline.seed_and_extend)
 
     def __del__(self):
         try:
