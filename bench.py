@@ -296,6 +296,7 @@ def main():
         plain = {"ms_per_step": pdt * 1e3, "match_ms_per_launch": 0.5 * (pst.get("match_fw", 0.0) + pst.get("match_rc", 0.0)),
                  "locate_ms_per_launch": pst.get("locate", 0.0), "extend_ms": pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0),
                  "extend_gcups": float(pnc) * params.band * M / ((pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0)) * 1e-3) / 1e9,
+                 "kmer_table": (args.kmer - 1) if (fmi.supports_direct() and args.kmer >= 2) else args.kmer,   # the handle's plain table
                  "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
     match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
     achieved = alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0

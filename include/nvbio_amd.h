@@ -87,6 +87,9 @@ typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
  * uses to replace its first kmer_len backward-search steps with one lookup; results are
  * identical with and without it.  kmer_len = 0 disables it; values up to 17 are accepted
  * (k = 12: 128 MiB, k = 14: 2 GiB, k = 16: 32 GiB, k = 17: 128 GiB -- sized for 288 GB of HBM).
+ * A handle that also holds the full suffix array and the text (nvbio_fm_index_build with sa_int = 1) keeps the last TWO
+ * levels of the table: level kmer_len - 1 as the table of match(), and level kmer_len with every one-row entry rewritten to
+ * that row's text position as the table of the direct seed pass (nvbio_fm_match_direct, nvbio_fm_match_seed_diagonals).
  * Replaces: constructing nvbio::fm_index / io::FMIndexDataDevice (nvbio/io/fmindex/fmindex_impl.cu:740-816). */
 nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len,
                                    void* stream, nvbio_fm_index_t* out);

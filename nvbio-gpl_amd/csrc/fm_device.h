@@ -26,7 +26,9 @@ struct DevIndex
     uint32_t        sa_log;   // log2 of the SA sampling interval (4 in the reference's layout)
     const uint2*    ktab;     // optional: SA range of every kmer-mer (in scan order), or NULL
     uint32_t        kmer;
-    const uint2*    dtab;     // optional (full SA + text): ktab with every ONE-row entry replaced by (SA[row], 0xFFFFFFFF)
+    const uint2*    dtab;     // optional (full SA + text): the table of the direct seed pass, one symbol longer than ktab (dkmer = kmer + 1):
+                              // SA range of every dkmer-mer, a ONE-row entry replaced by (SA[row], 0xFFFFFFFF)
+    uint32_t        dkmer;
     const uint32_t* isa;      // optional (with a full SA): isa[p] = row of suffix p, isa[length] = 0
     const uint32_t* text;     // optional: the 2-bit packed text the index was built from
 };

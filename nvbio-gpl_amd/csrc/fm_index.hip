@@ -31,7 +31,8 @@ struct FMIndexImpl
     nvbio_fm_index_view  view;        // host copy (device pointers inside)
     uint2*               ktab;        // owned
     uint32_t             kmer;
-    uint2*               dtab;        // owned, optional: the table of nvbio_fm_match_direct (positions for one-row k-mers)
+    uint2*               dtab;        // owned, optional: the table of the direct seed pass (positions for one-row k-mers)
+    uint32_t             dkmer;
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
     uint32_t*            isa;         // owned, optional (verify mode)
@@ -45,7 +46,7 @@ struct FMIndexImpl
         d.rec  = (const uint4*)view.bwt_occ_dev;
         d.ssa  = view.ssa_dev;
         d.sa_log = 0; while ((1u << d.sa_log) < (view.sa_int ? view.sa_int : 16u)) ++d.sa_log;
-        d.ktab = ktab; d.kmer = kmer; d.dtab = dtab;
+        d.ktab = ktab; d.kmer = kmer; d.dtab = dtab; d.dkmer = dkmer;
         d.isa = isa; d.text = text;
         return d;
     }
@@ -110,10 +111,14 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
     bool     have_pos = false;                              // DIRECT: the k-mer table already gave the text position
     uint32_t tpos = 0;
 
-    if (tab && len >= f.kmer)
+    // DIRECT: the handle's second table (one symbol longer) holds, for a k-mer with ONE occurrence, that occurrence's text
+    // position instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
+    const bool     use_d = DIRECT && f.dtab != nullptr && len >= f.dkmer;
+    const uint32_t tk    = use_d ? f.dkmer : f.kmer;
+    if (tab && len >= tk)
     {
         uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
-        for (uint32_t t = 0; t < f.kmer; ++t)
+        for (uint32_t t = 0; t < tk; ++t)
         {
             const uint32_t c = sym( t );
             ok = ok && (c < 4u);
@@ -121,11 +126,9 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
         }
         if (ok)
         {
-            // DIRECT: the handle's second table holds, for a k-mer with ONE occurrence, that occurrence's text position
-            // instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
-            const uint2 r = (DIRECT && f.dtab) ? f.dtab[key] : f.ktab[key];
-            s = f.kmer;
-            if (DIRECT && f.dtab && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
+            const uint2 r = use_d ? f.dtab[key] : f.ktab[key];
+            s = tk;
+            if (use_d && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
             else { x = r.x; y = r.y; }
         }
     }
@@ -488,18 +491,38 @@ static nvbio_status make_set(const nvbio_string_set* s, StringSetDev* d)
     return NVBIO_OK;
 }
 
+// in place: every one-row range of a table becomes (text position of that row, 0xFFFFFFFF)
+__global__ void __launch_bounds__(256)
+fm_dtab_kernel(uint2* __restrict__ tab, const uint32_t* __restrict__ sa, const uint32_t length, const uint64_t n)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint2 r = tab[e];
+        if (r.x == r.y)
+        {
+            const uint32_t sv = sa[r.x];
+            tab[e] = make_uint2( sv == 0xFFFFFFFFu ? length : sv, 0xFFFFFFFFu );
+        }
+    }
+}
+
+// The k-mer table is built level by level (level j from level j-1, one search step per entry), alternating between two
+// buffers.  A handle that holds the full SA and the text (direct-capable) keeps the LAST TWO levels: level k-1 stays the
+// plain table of match() (SA ranges), level k becomes the table of the direct seed pass, its one-row entries rewritten
+// in place to text positions.  Other handles keep level k as the plain table.  (k = 17: 32 + 128 GiB; k = 16: 8 + 32 GiB.)
 static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
 {
-    idx->ktab = nullptr; idx->kmer = 0;
+    idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0;
     if (k == 0) return NVBIO_OK;
+    const bool direct = idx->text && idx->view.ssa_dev && idx->view.sa_int == 1 && k >= 2 && !getenv( "NVBIO_AMD_NO_DIRECT_TABLE" );
     const uint64_t entries = 1ull << (2 * k);
     uint2 *a = nullptr, *b = nullptr;
-    if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
-    if (hipMalloc( (void**)&b, (entries / 4) * sizeof(uint2) ) != hipSuccess) { (void)hipFree( a ); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
-    // levels alternate between the two buffers so that level k lands in `a` (the large one)
+    if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (hipMalloc( (void**)&b, (entries / 4) * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); (void)hipFree( a ); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    // levels alternate between the two buffers so that level k lands in `a` (the large one) and level k-1 in `b`
     uint2* cur = (k % 2 == 0) ? a : b;
     uint2* oth = (k % 2 == 0) ? b : a;
-    DevIndex f = idx->dev(); f.ktab = nullptr; f.kmer = 0;
+    DevIndex f = idx->dev(); f.ktab = nullptr; f.kmer = 0; f.dtab = nullptr; f.dkmer = 0;
     hipLaunchKernelGGL( fm_ktab_root_kernel, dim3(1), dim3(1), 0, stream, cur, idx->view.length );
     for (uint32_t j = 1; j <= k; ++j)
     {
@@ -507,45 +530,26 @@ static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t s
         hipLaunchKernelGGL( fm_ktab_level_kernel, dim3( grid_for( n_next ) ), dim3(256), 0, stream, f, (const uint2*)cur, oth, n_next );
         uint2* t = cur; cur = oth; oth = t;
     }
-    NVB_HIP( hipGetLastError() );
-    NVB_HIP( hipStreamSynchronize( stream ) );
-    // cur == a by construction
-    (void)hipFree( b );
-    idx->ktab = a; idx->kmer = k;
-    idx->owned_bytes += entries * sizeof(uint2);
-    return NVBIO_OK;
-}
-
-// the table of nvbio_fm_match_direct: ktab with every one-row range replaced by (text position of that row, 0xFFFFFFFF)
-__global__ void __launch_bounds__(256)
-fm_dtab_kernel(const uint2* __restrict__ ktab, const uint32_t* __restrict__ sa, const uint32_t length, uint2* __restrict__ dtab, const uint64_t n)
-{
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+    // cur == a (level k), oth == b (level k-1) by construction
+    if (direct)
+        hipLaunchKernelGGL( fm_dtab_kernel, dim3( grid_for( entries ) ), dim3(256), 0, stream, a, idx->view.ssa_dev, idx->view.length, entries );
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess)
     {
-        uint2 r = ktab[e];
-        if (r.x == r.y)
-        {
-            const uint32_t sv = sa[r.x];
-            r = make_uint2( sv == 0xFFFFFFFFu ? length : sv, 0xFFFFFFFFu );
-        }
-        dtab[e] = r;
+        (void)hipFree( a ); (void)hipFree( b );
+        set_error( "k-mer table build failed" );
+        return NVBIO_ERR_HIP;
     }
-}
-
-static nvbio_status build_direct_table(FMIndexImpl* idx, hipStream_t stream)
-{
-    idx->dtab = nullptr;
-    if (!(idx->ktab && idx->text && idx->view.ssa_dev && idx->view.sa_int == 1) || getenv( "NVBIO_AMD_NO_DIRECT_TABLE" )) return NVBIO_OK;
-    const uint64_t entries = 1ull << (2 * idx->kmer);
-    size_t free_b = 0, total_b = 0;
-    // an optimisation only: skipped when it would take more than half of what is left
-    if (hipMemGetInfo( &free_b, &total_b ) != hipSuccess || entries * sizeof(uint2) > free_b / 2u) return NVBIO_OK;
-    uint2* d = nullptr;
-    if (hipMalloc( (void**)&d, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); return NVBIO_OK; }
-    hipLaunchKernelGGL( fm_dtab_kernel, dim3( grid_for( entries ) ), dim3(256), 0, stream, (const uint2*)idx->ktab, idx->view.ssa_dev, idx->view.length, d, entries );
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess) { (void)hipFree( d ); set_error( "direct table build failed" ); return NVBIO_ERR_HIP; }
-    idx->dtab = d;
-    idx->owned_bytes += entries * sizeof(uint2);
+    if (direct)
+    {
+        idx->ktab = b; idx->kmer = k - 1u; idx->dtab = a; idx->dkmer = k;
+        idx->owned_bytes += (entries + entries / 4) * sizeof(uint2);
+    }
+    else
+    {
+        (void)hipFree( b );
+        idx->ktab = a; idx->kmer = k;
+        idx->owned_bytes += entries * sizeof(uint2);
+    }
     return NVBIO_OK;
 }
 
@@ -554,17 +558,15 @@ nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_
 {
     FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
-    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->isa = nullptr; idx->text = nullptr;
+    idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->isa = nullptr; idx->text = nullptr;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     idx->isa = isa; idx->text = text;
     if (isa)  idx->owned_bytes += ((uint64_t)view->length + 1u) * 4ull;
     if (text) idx->owned_bytes += (((uint64_t)view->length + 15u) / 16u) * 4ull;
-    nvbio_status st = build_kmer_table( idx, kmer_len, stream );
-    if (st == NVBIO_OK) st = build_direct_table( idx, stream );
+    const nvbio_status st = build_kmer_table( idx, kmer_len, stream );
     if (st != NVBIO_OK)
     {
-        if (idx->ktab) (void)hipFree( idx->ktab );
         if (owns) { (void)hipFree( (void*)view->bwt_occ_dev ); (void)hipFree( (void*)view->ssa_dev ); }
         if (isa)  (void)hipFree( isa );
         if (text) (void)hipFree( text );
