@@ -477,6 +477,22 @@ nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int t
                                     const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
                                     void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* Scoring into aln::Best2Sink<int32>( distinct_dist ) (nvbio/alignment/sink.h:96-116, sink_inl.h:55-83) instead of BestSink: the
+ * best alignment in scores_dev / sinks_dev and a second one, ending more than distinct_dist text positions from the first, in
+ * scores2_dev / sinks2_dev (NVBIO_SCORE_MIN / (-1,-1) when there is none).  The reference's sink does not demote the old best
+ * when a new one arrives, so its result depends on the order of the reports; the kernels report cell by cell in the
+ * reference's order (band rows, then columns; 8-wide stripes in the full matrix).  int32 kernels only; reads 2/4/8 bit over
+ * 2-bit text, or bytes over bytes. */
+nvbio_status nvbio_banded_gotoh_score_best2(int device, uint32_t band, nvbio_alignment_type type,
+                                            const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch, uint32_t distinct_dist,
+                                            int32_t* scores_dev, nvbio_uint2* sinks_dev, int32_t* scores2_dev, nvbio_uint2* sinks2_dev,
+                                            void* stream);
+nvbio_status nvbio_full_gotoh_score_best2(int device, nvbio_alignment_type type, int text_blocking,
+                                          const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                          uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_scores_dev,
+                                          uint32_t distinct_dist, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                          int32_t* scores2_dev, nvbio_uint2* sinks2_dev, void* stream);
+
 /* The other two aligner families of the reference behind the same batch interface:
  * aln::SmithWatermanAligner<TYPE, scheme> and aln::EditDistanceAligner<TYPE> (nvbio/alignment/alignment.h:366-401,508-545).
  *   banded : banded_alignment_score<BAND> -> sw/sw_banded_inl.h:281-520 (the edit-distance aligner runs the same code with

@@ -669,6 +669,33 @@ class BatchedAlignmentScore:
         return scores, sinks
 
 
+def batch_banded_alignment_score_best2(band_len, aligner, batch, distinct_dist=0):
+    """banded scoring into aln::Best2Sink<int32>(distinct_dist) (nvbio/alignment/sink.h:96-116)
+    -> (scores, sinks, scores2, sinks2)"""
+    torch = _torch()
+    sc = [torch.empty(batch.n, dtype=torch.int32, device=batch.device) for _ in range(2)]
+    sk = [torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device) for _ in range(2)]
+    bs = batch.c_struct()
+    _check(lib().nvbio_banded_gotoh_score_best2(FMIndex._dev_index(batch.device), ctypes.c_uint32(band_len), ctypes.c_int(aligner.type),
+                                                ctypes.byref(aligner.scheme.c), ctypes.byref(bs), ctypes.c_uint32(distinct_dist),
+                                                _ptr(sc[0]), _ptr(sk[0]), _ptr(sc[1]), _ptr(sk[1]), _stream_ptr(batch.device)))
+    return sc[0], sk[0], sc[1], sk[1]
+
+
+def batch_alignment_score_best2(aligner, batch, max_pattern_len, max_text_len, distinct_dist=0, text_blocking=False, min_scores=None):
+    """full-matrix scoring into aln::Best2Sink<int32>(distinct_dist) -> (scores, sinks, scores2, sinks2)"""
+    torch = _torch()
+    sc = [torch.empty(batch.n, dtype=torch.int32, device=batch.device) for _ in range(2)]
+    sk = [torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device) for _ in range(2)]
+    ms = _dev_tensor(min_scores, torch.int32, batch.device)
+    bs = batch.c_struct()
+    _check(lib().nvbio_full_gotoh_score_best2(FMIndex._dev_index(batch.device), ctypes.c_int(aligner.type), ctypes.c_int(1 if text_blocking else 0),
+                                              ctypes.byref(aligner.scheme.c), ctypes.byref(bs), ctypes.c_uint32(max_pattern_len),
+                                              ctypes.c_uint32(max_text_len), _ptr(ms), ctypes.c_uint32(distinct_dist),
+                                              _ptr(sc[0]), _ptr(sk[0]), _ptr(sc[1]), _ptr(sk[1]), _stream_ptr(batch.device)))
+    return sc[0], sk[0], sc[1], sk[1]
+
+
 def hits_to_diagonals(hits, seeds_per_read, seed_interval, seed_len, read_len, strand):
     """hit_to_diagonal (examples/fmmap/fmmap.cu:92-117): int64 keys read<<34 | strand<<33 | diagonal+1024"""
     torch = _torch()

@@ -24,9 +24,13 @@
 
 namespace nvbio_amd {
 
-template <int BAND, int TYPE, int RBITS, int TBITS>
+// BEST2: the cells are reported one by one, in the reference's order, into a Best2Sink<int32>( distinct_dist )
+// (sink.h:96-116, sink_inl.h:55-83): best in scores / sinks, the second -- more than distinct_dist text positions away --
+// in scores2 / sinks2.  A new best does not demote the old one, so the result depends on the order of the reports.
+template <int BAND, int TYPE, int RBITS, int TBITS, bool BEST2 = false>
 __global__ void __launch_bounds__(128)
-banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                    const uint32_t distinct_dist = 0, int32_t* __restrict__ scores2 = nullptr, uint2* __restrict__ sinks2 = nullptr)
 {
     // mismatch score per quality value, computed once per workgroup
     __shared__ int32_t s_mm[64];
@@ -47,10 +51,17 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
 
     int32_t  best   = NVBIO_SCORE_MIN;
     uint32_t best_x = 0xFFFFFFFFu, best_y = 0xFFFFFFFFu;
+    int32_t  sec    = NVBIO_SCORE_MIN;                           // BEST2
+    uint32_t sec_x  = 0xFFFFFFFFu, sec_y = 0xFFFFFFFFu;
+    auto report2 = [&](const int32_t h, const uint32_t x, const uint32_t y) {
+        if (best <= h) { best = h; best_x = x; best_y = y; }
+        else if (sec <= h && ((uint32_t)(x + distinct_dist) < best_x || x > (uint32_t)(best_x + distinct_dist))) { sec = h; sec_x = x; sec_y = y; }
+    };
 
     if (N < M)                                                   // gotoh_banded_inl.h:422-423: nothing reported
     {
         scores[job] = best; sinks[job] = make_uint2( best_x, best_y );
+        if (BEST2) { scores2[job] = sec; sinks2[job] = make_uint2( sec_x, sec_y ); }
         return;
     }
 
@@ -127,7 +138,8 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
             if (TYPE == NVBIO_LOCAL)
             {
                 h = max2( h, 0 );
-                row_key = max2( row_key, (h << 5) | j );
+                if (BEST2) report2( h, i + (uint32_t)j + 1u, i + 1u );
+                else       row_key = max2( row_key, (h << 5) | j );
             }
             H[j] = h;
             E = (j == 0) ? h + I_o : max2( h + I_o, E + I_e );   // :507,562-565
@@ -142,7 +154,7 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
             cache_raw[BAND - 2] = g_new;
         }
 
-        if (TYPE == NVBIO_LOCAL)
+        if (TYPE == NVBIO_LOCAL && !BEST2)
         {
             // cells are reported row-major with j ascending and BestSink keeps the LAST maximum
             const int32_t h = row_key >> 5;
@@ -152,7 +164,8 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
 
     if (TYPE == NVBIO_GLOBAL)                                    // :629-630
     {
-        if (best <= H[BAND - 1]) { best = H[BAND - 1]; best_x = M + BAND - 1; best_y = M; }
+        if (BEST2) report2( H[BAND - 1], M + BAND - 1, M );
+        else if (best <= H[BAND - 1]) { best = H[BAND - 1]; best_x = M + BAND - 1; best_y = M; }
     }
     else if (TYPE == NVBIO_SEMI_GLOBAL)                          // :631-643
     {
@@ -161,10 +174,14 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
         #pragma unroll
         for (int j = 0; j < BAND; ++j)
             if (j == 0 || (uint32_t)j < m)
-                if (best <= H[j]) { best = H[j]; best_x = M + j; best_y = M; }
+            {
+                if (BEST2) report2( H[j], M + j, M );
+                else if (best <= H[j]) { best = H[j]; best_x = M + j; best_y = M; }
+            }
     }
     scores[job] = best;
     sinks[job]  = make_uint2( best_x, best_y );
+    if (BEST2) { scores2[job] = sec; sinks2[job] = make_uint2( sec_x, sec_y ); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,6 +774,61 @@ nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;
+
+template <int BAND, int TYPE>
+static nvbio_status launch_best2_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t dist,
+                                      int32_t* scores, uint2* sinks, int32_t* scores2, uint2* sinks2, hipStream_t s)
+{
+    const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
+#define NVB_GO2(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB,true>), grid, block, 0, s, b, sc, scores, sinks, dist, scores2, sinks2 )
+    if      (rbits == 4 && tbits == 2) NVB_GO2(4, 2);
+    else if (rbits == 2 && tbits == 2) NVB_GO2(2, 2);
+    else if (rbits == 8 && tbits == 2) NVB_GO2(8, 2);
+    else if (rbits == 8 && tbits == 8) NVB_GO2(8, 8);
+    else { set_error( "Best2Sink scoring: read_bits/text_bits %u/%u not instantiated (4/2, 2/2, 8/2, 8/8)", rbits, tbits ); return NVBIO_ERR_UNSUPPORTED; }
+#undef NVB_GO2
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+template <int BAND>
+static nvbio_status launch_best2_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t dist,
+                                      int32_t* scores, uint2* sinks, int32_t* scores2, uint2* sinks2, hipStream_t s)
+{
+    switch (type)
+    {
+    case NVBIO_GLOBAL:      return launch_best2_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, dist, scores, sinks, scores2, sinks2, s );
+    case NVBIO_LOCAL:       return launch_best2_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, dist, scores, sinks, scores2, sinks2, s );
+    case NVBIO_SEMI_GLOBAL: return launch_best2_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, dist, scores, sinks, scores2, sinks2, s );
+    }
+    set_error( "invalid alignment type %d", type );
+    return NVBIO_ERR_INVALID;
+}
+
+extern "C" nvbio_status nvbio_banded_gotoh_score_best2(int device, uint32_t band, nvbio_alignment_type type,
+                                                       const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch, uint32_t distinct_dist,
+                                                       int32_t* scores_dev, nvbio_uint2* sinks_dev, int32_t* scores2_dev, nvbio_uint2* sinks2_dev,
+                                                       void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (band != 3 && band != 7 && band != 15 && band != 31)
+    {
+        set_error( "band %u is not instantiated (3, 7, 15, 31)", band );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( scores_dev && sinks_dev && scores2_dev && sinks2_dev, "NULL output pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    const SchemeDev sc = scheme_dev( scheme );
+    hipStream_t s = (hipStream_t)stream;
+    switch (band)
+    {
+    case 3:  return launch_best2_type<3> ( type, b, sc, batch->read_bits, batch->text_bits, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s );
+    case 7:  return launch_best2_type<7> ( type, b, sc, batch->read_bits, batch->text_bits, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s );
+    case 15: return launch_best2_type<15>( type, b, sc, batch->read_bits, batch->text_bits, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s );
+    default: return launch_best2_type<31>( type, b, sc, batch->read_bits, batch->text_bits, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s );
+    }
+}
 
 static nvbio_status banded_score(int device, uint32_t band, int type, const SchemeDev sc, const BatchDev& b, const nvbio_alignment_batch* batch,
                                  int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)

@@ -23,15 +23,21 @@ namespace nvbio_amd {
 
 namespace {
 
-struct Sink
+// BestSink<int32>; with BEST2 also Best2Sink<int32>( dist ) (sink_inl.h:55-83): the second alignment ends more than dist text
+// positions from the first, and a new best does not demote the old one
+template <bool BEST2>
+struct SinkT
 {
     int32_t score; uint32_t x, y;
-    __device__ __forceinline__ void init() { score = NVBIO_SCORE_MIN; x = y = 0xFFFFFFFFu; }
+    int32_t score2; uint32_t x2, y2, dist;
+    __device__ __forceinline__ void init(const uint32_t d = 0) { score = score2 = NVBIO_SCORE_MIN; x = y = x2 = y2 = 0xFFFFFFFFu; dist = d; }
     __device__ __forceinline__ void report(const int32_t s, const uint32_t sx, const uint32_t sy)
     {
         if (score <= s) { score = s; x = sx; y = sy; }          // last maximum wins
+        else if (BEST2 && score2 <= s && ((uint32_t)(sx + dist) < x || sx > (uint32_t)(x + dist))) { score2 = s; x2 = sx; y2 = sy; }
     }
 };
+typedef SinkT<false> Sink;
 
 // (H,E) boundary cell: two int16, truncating like make_vector<short>(H,E) (gotoh_inl.h:942)
 __device__ __forceinline__ uint32_t pack_cell(const int32_t h, const int32_t e) { return ((uint32_t)h & 0xFFFFu) | ((uint32_t)e << 16); }
@@ -42,11 +48,12 @@ constexpr int STRIPE = 8;
 
 // TEXT_BLOCKING: stripes run over the text, the boundary column over the M pattern rows
 // otherwise     : stripes run over the pattern, the boundary column over the N text rows
-template <int TYPE, bool TEXT_BLOCKING, int RBITS, int TBITS>
+template <int TYPE, bool TEXT_BLOCKING, int RBITS, int TBITS, bool BEST2 = false>
 __global__ void __launch_bounds__(128)
 full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin, const uint32_t jobs, const int32_t* __restrict__ min_scores,
                   uint32_t* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
-                  const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
+                  const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
+                  const uint32_t distinct_dist = 0, int32_t* __restrict__ scores2 = nullptr, uint2* __restrict__ sinks2 = nullptr)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -98,7 +105,7 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
         col[(size_t)i * jobs] = pack_cell( x, y );
     }
 
-    Sink sink; sink.init();
+    SinkT<BEST2> sink; sink.init( distinct_dist );
     const uint32_t nb        = (cols + STRIPE - 1u) / STRIPE;
     const uint32_t end_block = (STRIPE * nb > (uint32_t)STRIPE) ? STRIPE * nb : (uint32_t)STRIPE;
 
@@ -156,7 +163,18 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
             col[(size_t)i * jobs] = pack_cell( H[STRIPE], E );
             max_score = max2( max_score, H[STRIPE] );
 
-            if (TYPE == NVBIO_LOCAL)
+            if (TYPE == NVBIO_LOCAL && BEST2)
+            {
+                // Best2Sink depends on the order of the reports: cell by cell, as the reference (8-wide stripes only)
+                #pragma unroll
+                for (int j = 1; j <= STRIPE; ++j)
+                    if (!last || block + j <= cols)
+                    {
+                        if (TEXT_BLOCKING) sink.report( H[j], block + j, i + 1u );
+                        else               sink.report( H[j], i + 1u, block + j );
+                    }
+            }
+            else if (TYPE == NVBIO_LOCAL)
             {
                 // the row's cells are reported with j ascending and the LAST maximum wins: one packed
                 // (score << 4 | j) max per cell and a single compare per row give the same sink
@@ -227,6 +245,7 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
     }
     scores[job] = sink.score;
     sinks[job]  = make_uint2( sink.x, sink.y );
+    if (BEST2) { scores2[job] = sink.score2; sinks2[job] = make_uint2( sink.x2, sink.y2 ); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -827,6 +846,63 @@ extern "C" nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type 
     NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
     return full_score( device, type, text_blocking, scheme_dev( scheme ), batch, max_pattern_len, max_text_len, min_scores_dev,
                        scores_dev, sinks_dev, temp_dev, temp_bytes, stream );
+}
+
+// Best2Sink scoring: the int32 kernel reporting cell by cell (no shortcut, no packed kernel: both rely on BestSink's rule)
+template <int TYPE, bool TB>
+static nvbio_status launch_best2(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
+                                 const int32_t* min_scores, uint32_t* column, uint32_t dist, int32_t* scores, uint2* sinks, int32_t* scores2, uint2* sinks2, hipStream_t s)
+{
+    const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
+#define NVB_GO2(RB, TBITS) hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS,true>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks, \
+                                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, dist, scores2, sinks2 )
+    if      (rbits == 4 && tbits == 2) NVB_GO2(4, 2);
+    else if (rbits == 2 && tbits == 2) NVB_GO2(2, 2);
+    else if (rbits == 8 && tbits == 2) NVB_GO2(8, 2);
+    else if (rbits == 8 && tbits == 8) NVB_GO2(8, 8);
+    else { set_error( "Best2Sink scoring: read_bits/text_bits %u/%u not instantiated (4/2, 2/2, 8/2, 8/8)", rbits, tbits ); return NVBIO_ERR_UNSUPPORTED; }
+#undef NVB_GO2
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_full_gotoh_score_best2(int device, nvbio_alignment_type type, int text_blocking,
+                                                     const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                                     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_scores_dev,
+                                                     uint32_t distinct_dist, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                                     int32_t* scores2_dev, nvbio_uint2* sinks2_dev, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( scores_dev && sinks_dev && scores2_dev && sinks2_dev, "NULL output pointer" );
+    NVB_REQUIRE( type == NVBIO_GLOBAL || type == NVBIO_LOCAL || type == NVBIO_SEMI_GLOBAL, "invalid alignment type" );
+    const uint64_t rows = text_blocking ? max_pattern_len : max_text_len;
+    NVB_REQUIRE( rows > 0, "max_pattern_len / max_text_len must bound the boundary column" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const SchemeDev sc = scheme_dev( scheme );
+    uint64_t cap_jobs = b.n;
+    const uint64_t budget = 8ull << 30;
+    if (cap_jobs * rows * sizeof(uint32_t) > budget) cap_jobs = budget / (rows * sizeof(uint32_t));
+    if (cap_jobs < 64) cap_jobs = 64;
+    void* column = nullptr;
+    if (hipMallocAsync( &column, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
+    {
+        set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
+        return NVBIO_ERR_NOMEM;
+    }
+    nvbio_status st = NVBIO_OK;
+    for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
+    {
+        const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
+#define NVB_B2(TYPE_) (text_blocking ? launch_best2<TYPE_,true> ( b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, (uint32_t*)column, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s ) \
+                                     : launch_best2<TYPE_,false>( b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, (uint32_t*)column, distinct_dist, scores_dev, (uint2*)sinks_dev, scores2_dev, (uint2*)sinks2_dev, s ))
+        st = type == NVBIO_GLOBAL ? NVB_B2( NVBIO_GLOBAL ) : type == NVBIO_LOCAL ? NVB_B2( NVBIO_LOCAL ) : NVB_B2( NVBIO_SEMI_GLOBAL );
+#undef NVB_B2
+    }
+    (void)hipFreeAsync( column, s );
+    return st;
 }
 
 extern "C" nvbio_status nvbio_full_sw_score(int device, nvbio_alignment_type type, int text_blocking,

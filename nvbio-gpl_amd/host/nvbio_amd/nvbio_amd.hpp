@@ -430,5 +430,27 @@ void batch_banded_alignment_score(const aligner_type& aligner, const nvbio_align
     batched.enact( stream_type( aligner, batch, scores_dev, sinks_dev, 0, 0 ), 0u, nullptr, device, s );
 }
 
+// aln::Best2Sink<int32>( distinct_dist ) (nvbio/alignment/sink.h:96-116) as a batch: best and second-best distinct alignment
+// of every job (Gotoh aligners; the int32 kernels report cell by cell in the reference's order)
+template <uint32_t BAND_LEN, AlignmentType T, typename scheme_type>
+void batch_banded_alignment_score_best2(const GotohAligner<T,scheme_type>& aligner, const nvbio_alignment_batch& batch, uint32_t distinct_dist,
+                                        int32_t* scores_dev, nvbio_uint2* sinks_dev, int32_t* scores2_dev, nvbio_uint2* sinks2_dev,
+                                        int device = 0, hipStream_t s = 0)
+{
+    const nvbio_gotoh_scheme f = aligner.scheme.flat();
+    check( nvbio_banded_gotoh_score_best2( device, BAND_LEN, (nvbio_alignment_type)T, &f, &batch, distinct_dist,
+                                           scores_dev, sinks_dev, scores2_dev, sinks2_dev, s ) );
+}
+template <AlignmentType T, typename scheme_type>
+void batch_alignment_score_best2(const GotohAligner<T,scheme_type>& aligner, const nvbio_alignment_batch& batch, uint32_t max_pattern_len,
+                                 uint32_t max_text_len, uint32_t distinct_dist, int32_t* scores_dev, nvbio_uint2* sinks_dev,
+                                 int32_t* scores2_dev, nvbio_uint2* sinks2_dev, bool text_blocking = false,
+                                 const int32_t* min_scores_dev = nullptr, int device = 0, hipStream_t s = 0)
+{
+    const nvbio_gotoh_scheme f = aligner.scheme.flat();
+    check( nvbio_full_gotoh_score_best2( device, (nvbio_alignment_type)T, text_blocking ? 1 : 0, &f, &batch, max_pattern_len, max_text_len,
+                                         min_scores_dev, distinct_dist, scores_dev, sinks_dev, scores2_dev, sinks2_dev, s ) );
+}
+
 } // namespace aln
 } // namespace nvbio_amd

@@ -332,6 +332,23 @@ class Oracle:
                                      _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def banded_gotoh_best2(self, band, typ, scheme, pat, txt, quals=None, dist=0):
+        """banded Gotoh reporting into Best2Sink<int32>(dist) -> (ok, (score1, x1, y1, score2, x2, y2))"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        out = np.zeros(6, dtype=np.int64)
+        ok = self.lib.orc_banded_gotoh_best2(ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(pat, _u8p), _p(quals, _u8p),
+                                             ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_uint32(dist),
+                                             out.ctypes.data_as(ctypes.c_void_p))
+        return ok, tuple(int(v) for v in out)
+
+    def full_gotoh_best2(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN, dist=0):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        out = np.zeros(6, dtype=np.int64)
+        ok = self.lib.orc_full_gotoh_best2(ctypes.c_int(typ), ctypes.c_int(blocking), ctypes.byref(scheme), _p(pat, _u8p), _p(quals, _u8p),
+                                           ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score),
+                                           ctypes.c_uint32(dist), out.ctypes.data_as(ctypes.c_void_p))
+        return ok, tuple(int(v) for v in out)
+
     def banded_sw(self, band, typ, sw, pat, txt):
         """linear-gap Smith-Waterman in a band; sw = (match, mismatch, deletion, insertion), signed"""
         pat, txt = _c8(pat), _c8(txt)
@@ -525,6 +542,25 @@ class Reference:
         ok = self.lib.ref_banded_ed(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
                                     _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_gotoh_best2(self, band, typ, scheme, pat, txt, quals=None, dist=0):
+        """aln::banded_alignment_score<BAND> with aln::Best2Sink<int32>(dist) (sink.h:96-116) -> (ok, (s1, x1, y1, s2, x2, y2))"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        arr = scheme.as_array()
+        out = np.zeros(6, dtype=np.int64)
+        ok = self.lib.ref_banded_gotoh_best2(ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p), _p(quals, _u8p),
+                                             ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_uint32(dist),
+                                             out.ctypes.data_as(ctypes.c_void_p))
+        return ok, tuple(int(v) for v in out)
+
+    def full_gotoh_best2(self, typ, blocking, scheme, pat, txt, quals=None, min_score=SCORE_MIN, dist=0):
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        arr = scheme.as_array()
+        out = np.zeros(6, dtype=np.int64)
+        ok = self.lib.ref_full_gotoh_best2(ctypes.c_int(typ), ctypes.c_int(blocking), _p(arr, _i32p), _p(pat, _u8p), _p(quals, _u8p),
+                                           ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score),
+                                           ctypes.c_uint32(dist), out.ctypes.data_as(ctypes.c_void_p))
+        return ok, tuple(int(v) for v in out)
 
     def banded_sw(self, band, typ, sw, pat, txt, min_score=SCORE_MIN):
         """aln::banded_alignment_score<BAND>( SmithWatermanAligner<TYPE,SimpleSmithWatermanScheme> ), sw = (match,

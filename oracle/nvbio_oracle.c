@@ -414,11 +414,19 @@ int32_t orc_mismatch(const orc_gotoh_scheme* s, uint32_t q)
 static inline int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 static inline int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
 
-typedef struct { int32_t score; uint32_t x, y; } best_sink;
-static inline void sink_init(best_sink* s) { s->score = ORC_SCORE_MIN; s->x = s->y = 0xFFFFFFFFu; }
+/* BestSink<int32> and, with two != 0, Best2Sink<int32> (sink.h:60-116, sink_inl.h:31-83): the second alignment must end more
+ * than `dist` text positions away from the first (uint32 arithmetic as the reference's, wrap-around included); a new best does
+ * not demote the old one */
+typedef struct { int32_t score; uint32_t x, y; int two; uint32_t dist; int32_t score2; uint32_t x2, y2; } best_sink;
+static inline void sink_init(best_sink* s)
+{
+    s->score = s->score2 = ORC_SCORE_MIN; s->x = s->y = s->x2 = s->y2 = 0xFFFFFFFFu; s->two = 0; s->dist = 0;
+}
 static inline void sink_report(best_sink* s, int32_t score, uint32_t x, uint32_t y)
 {
     if (s->score <= score) { s->score = score; s->x = x; s->y = y; }     /* last maximum wins (sink_inl.h:40-49) */
+    else if (s->two && s->score2 <= score && ((uint32_t)(x + s->dist) < s->x || x > (uint32_t)(s->x + s->dist)))
+    { s->score2 = score; s->x2 = x; s->y2 = y; }                         /* sink_inl.h:69-83 */
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -917,6 +925,28 @@ int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat,
         sink_report( &sink, band[ ((M - 1u) & (SW_STRIPE - 1u)) + 1u ], N, M );
     free( temp );
     *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    return ok;
+}
+
+/* the same two DPs reporting into a Best2Sink<int32>( distinct_dist ): out = { score1, sink1.x, sink1.y, score2, sink2.x, sink2.y } */
+int orc_banded_gotoh_best2(uint32_t B, int type, const orc_gotoh_scheme* sc, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                           const uint8_t* txt, uint32_t N, uint32_t distinct_dist, int64_t out[6])
+{
+    best_sink sink; sink_init( &sink ); sink.two = 1; sink.dist = distinct_dist;
+    int ok = 0;
+    if (B < 2 || B > ORC_MAX_BAND) return -1;
+    if (N >= M) { banded_core( B, type, sc, pat, quals, M, txt, N, &sink, 0 ); ok = 1; }
+    out[0] = sink.score; out[1] = sink.x; out[2] = sink.y; out[3] = sink.score2; out[4] = sink.x2; out[5] = sink.y2;
+    return ok;
+}
+int orc_full_gotoh_best2(int type, int blocking, const orc_gotoh_scheme* sc, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                         const uint8_t* txt, uint32_t N, int32_t min_score, uint32_t distinct_dist, int64_t out[6])
+{
+    best_sink sink; sink_init( &sink ); sink.two = 1; sink.dist = distinct_dist;
+    const int ok = blocking ?
+        full_text_blocking(    type, sc, pat, quals, M, txt, N, min_score, &sink ) :
+        full_pattern_blocking( type, sc, pat, quals, M, txt, N, min_score, &sink, 0 );
+    out[0] = sink.score; out[1] = sink.x; out[2] = sink.y; out[3] = sink.score2; out[4] = sink.x2; out[5] = sink.y2;
     return ok;
 }
 

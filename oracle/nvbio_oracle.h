@@ -168,6 +168,11 @@ int orc_full_gotoh_traceback(int type, const orc_gotoh_scheme* s,
  * (gotoh_inl.h:444-841 pattern blocking, :847-1256 text blocking; alignment_score_dispatch :1283-1330).
  * blocking: 0 = PatternBlockingTag (alignment_score default), 1 = TextBlockingTag (sw-benchmark).
  * Returns 0 when the stripe early-exit fires (max_score + missing*match < min_score), else 1. */
+/* Best2Sink<int32>( distinct_dist ) in place of BestSink: out = { score1, sink1.x, sink1.y, score2, sink2.x, sink2.y } */
+int orc_banded_gotoh_best2(uint32_t band, int type, const orc_gotoh_scheme* s, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                           const uint8_t* txt, uint32_t N, uint32_t distinct_dist, int64_t out[6]);
+int orc_full_gotoh_best2(int type, int blocking, const orc_gotoh_scheme* s, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                         const uint8_t* txt, uint32_t N, int32_t min_score, uint32_t distinct_dist, int64_t out[6]);
 /* linear-gap Smith-Waterman / edit-distance aligners (sw/sw_banded_inl.h, sw/sw_inl.h); sw = {match, mismatch, deletion, insertion} */
 int orc_banded_sw(uint32_t band, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                   int32_t* score, uint32_t sink[2]);

@@ -282,6 +282,55 @@ int banded_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint3
     return -1;
 }
 
+// Best2Sink<int32> through the same dispatches (banded and full matrix)
+template <uint32 BAND, aln::AlignmentType TYPE>
+int banded_best2_run(const QualRampScheme& scheme, const uint8* pat, const uint8* quals, uint32 M, const uint8* txt, uint32 N, uint32 dist, int64* out)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::Best2Sink<int32> best( dist );
+    bool ok;
+    if (quals) ok = aln::banded_alignment_score<BAND>( aln::make_gotoh_aligner<TYPE>( scheme ), string_type( M, pat ), quals, string_type( N, txt ), Field_traits<int32>::min(), best );
+    else       ok = aln::banded_alignment_score<BAND>( aln::make_gotoh_aligner<TYPE>( scheme ), string_type( M, pat ), aln::trivial_quality_string(), string_type( N, txt ), Field_traits<int32>::min(), best );
+    out[0] = best.score1; out[1] = best.sink1.x; out[2] = best.sink1.y; out[3] = best.score2; out[4] = best.sink2.x; out[5] = best.sink2.y;
+    return ok ? 1 : 0;
+}
+template <uint32 BAND>
+int banded_best2_type(int type, const QualRampScheme& scheme, const uint8* pat, const uint8* quals, uint32 M, const uint8* txt, uint32 N, uint32 dist, int64* out)
+{
+    switch (type)
+    {
+    case 0: return banded_best2_run<BAND,aln::GLOBAL>     ( scheme, pat, quals, M, txt, N, dist, out );
+    case 1: return banded_best2_run<BAND,aln::LOCAL>      ( scheme, pat, quals, M, txt, N, dist, out );
+    case 2: return banded_best2_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, quals, M, txt, N, dist, out );
+    }
+    return -1;
+}
+template <aln::AlignmentType TYPE, typename tag>
+int full_best2_run(const QualRampScheme& scheme, const uint8* pat, const uint8* quals, uint32 M, const uint8* txt, uint32 N, int32 min_score, uint32 dist, int64* out)
+{
+    typedef vector_view<const uint8*> string_type;
+    typedef aln::GotohAligner<TYPE,QualRampScheme,tag>              aligner_type;
+    typedef typename aln::column_storage_type<aligner_type>::type   cell_type;
+    std::vector<cell_type> column( (M > N ? M : N) + 16u );
+    aln::Best2Sink<int32> best( dist );
+    bool ok;
+    if (quals) ok = aln::alignment_score( aligner_type( scheme ), string_type( M, pat ), quals, string_type( N, txt ), min_score, best, &column[0] );
+    else       ok = aln::alignment_score( aligner_type( scheme ), string_type( M, pat ), aln::trivial_quality_string(), string_type( N, txt ), min_score, best, &column[0] );
+    out[0] = best.score1; out[1] = best.sink1.x; out[2] = best.sink1.y; out[3] = best.score2; out[4] = best.sink2.x; out[5] = best.sink2.y;
+    return ok ? 1 : 0;
+}
+template <typename tag>
+int full_best2_type(int type, const QualRampScheme& scheme, const uint8* pat, const uint8* quals, uint32 M, const uint8* txt, uint32 N, int32 min_score, uint32 dist, int64* out)
+{
+    switch (type)
+    {
+    case 0: return full_best2_run<aln::GLOBAL,tag>     ( scheme, pat, quals, M, txt, N, min_score, dist, out );
+    case 1: return full_best2_run<aln::LOCAL,tag>      ( scheme, pat, quals, M, txt, N, min_score, dist, out );
+    case 2: return full_best2_run<aln::SEMI_GLOBAL,tag>( scheme, pat, quals, M, txt, N, min_score, dist, out );
+    }
+    return -1;
+}
+
 // the other two aligner families through the same entry points: SmithWatermanAligner<TYPE,SimpleSmithWatermanScheme>
 // (linear gaps; sw/sw_banded_inl.h:281-520, sw/sw_inl.h) and the full-matrix EditDistanceAligner (ed/ed_inl.h -> sw/sw_inl.h
 // with EditDistanceSWScheme); column cells are int16 (nvbio/alignment/utils.h:55-56)
@@ -569,6 +618,29 @@ int ref_banded_ed(uint32_t band, int type, const uint8_t* pat, uint32_t M, const
     case 31: return banded_ed_type<31>( type, pat, M, txt, N, score, sink );
     }
     return -1;
+}
+
+int ref_banded_gotoh_best2(uint32_t band, int type, const int32_t* sc, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                           const uint8_t* txt, uint32_t N, uint32_t dist, int64_t* out)
+{
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    switch (band)
+    {
+    case 3:  return banded_best2_type<3> ( type, scheme, pat, quals, M, txt, N, dist, (int64*)out );
+    case 7:  return banded_best2_type<7> ( type, scheme, pat, quals, M, txt, N, dist, (int64*)out );
+    case 15: return banded_best2_type<15>( type, scheme, pat, quals, M, txt, N, dist, (int64*)out );
+    case 31: return banded_best2_type<31>( type, scheme, pat, quals, M, txt, N, dist, (int64*)out );
+    }
+    return -1;
+}
+int ref_full_gotoh_best2(int type, int blocking, const int32_t* sc, const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                         const uint8_t* txt, uint32_t N, int32_t min_score, uint32_t dist, int64_t* out)
+{
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    return blocking ? full_best2_type<aln::TextBlockingTag>   ( type, scheme, pat, quals, M, txt, N, min_score, dist, (int64*)out )
+                    : full_best2_type<aln::PatternBlockingTag>( type, scheme, pat, quals, M, txt, N, min_score, dist, (int64*)out );
 }
 
 int ref_banded_sw(uint32_t band, int type, int match, int mm, int del, int ins,

@@ -135,6 +135,20 @@ int main()
             REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
         }
     }
+    // Best2Sink: best and second-best distinct alignment (local), against the oracle
+    {
+        device_vector<int32_t> d_s2( J ); device_vector<nvbio_uint2> d_k2( J );
+        aln::batch_banded_alignment_score_best2<31>( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, 8u, d_scores.data(), d_sinks.data(), d_s2.data(), d_k2.data() );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<int32_t> sc = d_scores.to_host(), s2 = d_s2.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host(), k2 = d_k2.to_host();
+        for (uint32_t j = 0; j < J; ++j)
+        {
+            int64_t out[6];
+            orc_banded_gotoh_best2( 31, 1, &os, &pats[j*M], nullptr, M, &text[wb[j]], we[j] - wb[j], 8u, out );
+            REQUIRE( sc[j] == out[0] && sk[j].x == (uint32_t)out[1] && sk[j].y == (uint32_t)out[2] );
+            REQUIRE( s2[j] == out[3] && k2[j].x == (uint32_t)out[4] && k2[j].y == (uint32_t)out[5] );
+        }
+    }
     // banded traceback through BatchedBandedAlignmentTraceback (semi-global): Alignment + CIGAR runs equal to the oracle
     {
         const uint32_t STRIDE = 32;

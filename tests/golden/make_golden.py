@@ -17,6 +17,7 @@ Fixtures:
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
   ed_golden.npz   the same pairs scored by the reference's banded edit-distance aligner.
   ftb_golden.npz  the same pairs traced back through the full matrix (alignment_traceback).
+  best2_golden.npz the same pairs scored into aln::Best2Sink (best two distinct alignments).
   sw_golden.npz   the same pairs scored by the reference's linear-gap Smith-Waterman aligner (banded and full
                   matrix) and by its full-matrix edit-distance aligner.
   tb_golden.npz   the same pairs traced back by the reference (banded_alignment_traceback, bands
@@ -329,6 +330,41 @@ def make_sw(R):
     print("sw_golden.npz: %d pairs" % n)
 
 
+BEST2_DISTS = (0, 8)
+
+
+def make_best2(R):
+    """best2_golden.npz: every pair of dp_golden.npz scored by the reference into aln::Best2Sink<int32>(distinct_dist) --
+    banded (bands 3/7/15/31 x 3 types) and full matrix (both blockings x 3 types x {no, finite} min score), for two
+    distinct distances.  Out-of-band text is the 255 sentinel the reference substitutes."""
+    g = np.load(os.path.join(HERE, "dp_golden.npz"))
+    n = len(g["pat_off"]) - 1
+    bands = [int(b) for b in g["bands"]]
+    S = len(g["schemes"])
+    b2 = np.zeros((n, len(BEST2_DISTS), len(bands), 3, 7), dtype=np.int64)      # ok (-1: not pinned), s1, x1, y1, s2, x2, y2
+    f2 = np.zeros((n, len(BEST2_DISTS), 2, 3, 2, 7), dtype=np.int64)
+    for i in range(n):
+        sc = oracle.Scheme(*[int(v) for v in g["schemes"][i % S]])
+        pat = g["pats"][g["pat_off"][i]:g["pat_off"][i + 1]]
+        txt = g["txts"][g["txt_off"][i]:g["txt_off"][i + 1]]
+        q = g["quals"][g["pat_off"][i]:g["pat_off"][i + 1]] if int(g["has_quals"][i]) else None
+        for di, dist in enumerate(BEST2_DISTS):
+            for bi, b in enumerate(bands):
+                for typ in range(3):
+                    if len(txt) < b - 1:
+                        b2[i, di, bi, typ, 0] = -1
+                        continue
+                    ok, out = R.banded_gotoh_best2(b, typ, sc, pat, txt, q, dist)
+                    b2[i, di, bi, typ] = (ok,) + out
+            for blk in range(2):
+                for typ in range(3):
+                    for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                        ok, out = R.full_gotoh_best2(typ, blk, sc, pat, txt, q, ms, dist)
+                        f2[i, di, blk, typ, v] = (ok,) + out
+    np.savez_compressed(os.path.join(HERE, "best2_golden.npz"), banded=b2, full=f2, bands=np.array(bands), dists=np.array(BEST2_DISTS))
+    print("best2_golden.npz: %d pairs" % n)
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -339,3 +375,4 @@ if __name__ == "__main__":
     make_ed(R)
     make_ftb(R)
     make_sw(R)
+    make_best2(R)

@@ -226,6 +226,44 @@ def test_banded_smith_waterman_golden(amd, orc, dp_golden, sw_golden):
                     assert (int(sc[k]), int(sk[k, 0]), int(sk[k, 1])) == (s, snk[0], snk[1]), (band, sw, typ, k)
 
 
+def test_best2_sink_golden(amd, dp_golden, best2_golden):
+    """nvbio_banded_gotoh_score_best2 / nvbio_full_gotoh_score_best2 == the reference's DP reporting into aln::Best2Sink, every
+    band, type, blocking and distinct distance, with and without qualities / minimum scores, on the reference's own outputs"""
+    g, w = dp_golden, best2_golden
+    S = len(g["schemes"])
+    n = len(g["pat_off"]) - 1
+    lens_p = np.diff(g["pat_off"]); lens_t = np.diff(g["txt_off"])
+    checked = 0
+    for si in range(S):
+        for hq in (0, 1):
+            cases = np.array([i for i in range(n) if i % S == si and int(g["has_quals"][i]) == hq], dtype=np.uint32)
+            if len(cases) == 0:
+                continue
+            batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][cases], g["txt_off"][cases + 1],
+                                       quals=g["quals"] if hq else None, read_id=cases)
+            for typ in range(3):
+                al = amd.make_gotoh_aligner(typ, _scheme(amd, g["schemes"][si]))
+                for di, dist in enumerate(w["dists"]):
+                    for bi, band in enumerate(w["bands"]):
+                        out = amd.batch_banded_alignment_score_best2(int(band), al, batch, int(dist))
+                        want = w["banded"][cases, di, bi, typ]
+                        pin = want[:, 0] >= 0
+                        got = np.stack([out[0].cpu().numpy().astype(np.int64), amd.u32(out[1])[:, 0], amd.u32(out[1])[:, 1],
+                                        out[2].cpu().numpy().astype(np.int64), amd.u32(out[3])[:, 0], amd.u32(out[3])[:, 1]], axis=1)
+                        assert np.array_equal(got[pin], want[pin, 1:]), (si, hq, typ, dist, band)
+                        checked += int(pin.sum())
+                    for blk in (0, 1):
+                        for v in (0, 1):
+                            out = amd.batch_alignment_score_best2(al, batch, int(lens_p.max()), int(lens_t.max()), int(dist), text_blocking=bool(blk),
+                                                                  min_scores=g["min_scores"][cases] if v else None)
+                            want = w["full"][cases, di, blk, typ, v]
+                            got = np.stack([out[0].cpu().numpy().astype(np.int64), amd.u32(out[1])[:, 0], amd.u32(out[1])[:, 1],
+                                            out[2].cpu().numpy().astype(np.int64), amd.u32(out[3])[:, 0], amd.u32(out[3])[:, 1]], axis=1)
+                            assert np.array_equal(got, want[:, 1:]), (si, hq, typ, dist, blk, v)
+                            checked += len(cases)
+    assert checked > 15000
+
+
 def test_end_to_end_shortcut_edge_cases(amd, orc):
     """the ungapped shortcut and its second chance (U* <= G but only single-gap, mismatch-free alignments could reach
     it): reads with 0-3 substitutions, and reads whose only difference is a 1-4 bp indel a few bases from either end --

@@ -258,6 +258,33 @@ def test_smith_waterman_family_golden(orc, dp_golden, sw_golden):
     assert checked > 20000
 
 
+def test_best2_sink_golden(orc, dp_golden, best2_golden):
+    """aln::Best2Sink<int32>(distinct_dist) (sink.h:96-116): the best two distinct alignments of the banded and the full-matrix
+    DP, on the reference's own outputs -- an order-dependent sink, so this also pins the order of the reports"""
+    g, w = dp_golden, best2_golden
+    S = len(g["schemes"])
+    checked = seconds = 0
+    for i in range(0, len(g["pat_off"]) - 1):
+        sc = oracle.Scheme(*[int(v) for v in g["schemes"][i % S]])
+        p, t, q = _case(g, i)
+        for di, dist in enumerate(w["dists"]):
+            for bi, b in enumerate(w["bands"]):
+                for typ in range(3):
+                    want = tuple(int(v) for v in w["banded"][i, di, bi, typ])
+                    if want[0] < 0:
+                        continue
+                    ok, out = orc.banded_gotoh_best2(int(b), typ, sc, p, t, q, int(dist))
+                    assert (ok,) + out == want, (i, dist, b, typ)
+                    checked += 1; seconds += out[3] > oracle.SCORE_MIN
+            for blk in range(2):
+                for typ in range(3):
+                    for v, ms in enumerate((oracle.SCORE_MIN, int(g["min_scores"][i]))):
+                        ok, out = orc.full_gotoh_best2(typ, blk, sc, p, t, q, ms, int(dist))
+                        assert (ok,) + out == tuple(int(x) for x in w["full"][i, di, blk, typ, v]), (i, dist, blk, typ, v)
+                        checked += 1; seconds += out[3] > oracle.SCORE_MIN
+    assert checked > 15000 and seconds > 5000
+
+
 def test_full_traceback_golden(orc, dp_golden, ftb_golden):
     """score, source, sink and run-length CIGAR of the reference's full-matrix alignment_traceback"""
     g, t = dp_golden, ftb_golden
