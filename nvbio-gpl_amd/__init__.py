@@ -106,6 +106,24 @@ def _torch():
     return torch
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes, cap=8 << 30):
+    """one persistent scratch tensor per device for the DP kernels' boundary columns / direction vectors (at most `cap`
+    bytes; the library processes a batch in as many launches as the scratch allows).  Handing the library caller scratch
+    keeps multi-GiB stream-ordered allocations out of every call: their cost depends on the state of the HIP memory pool
+    (observed: an occasional 0.7 s stall in a paired-end step).  All users are ordered on the current stream."""
+    torch = _torch()
+    nbytes = int(min(max(nbytes, 1 << 20), cap))
+    key = str(device)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        _SCRATCH[key] = None
+        t = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return t
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -615,6 +633,8 @@ class BatchedAlignmentTraceback:
         lens = torch.empty(n, dtype=torch.int32, device=dev)
         ms = _dev_tensor(min_scores, torch.int32, dev)
         bs = batch.c_struct()
+        if temp is None and n:
+            temp = _scratch(dev, self.min_temp_storage(batch, max_pattern_len, max_text_len))
         _check(lib().nvbio_full_gotoh_traceback(
             FMIndex._dev_index(dev), ctypes.c_int(self.aligner.type), ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs),
             ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms), _ptr(scores), _ptr(sources), _ptr(sinks),
@@ -661,11 +681,13 @@ class BatchedAlignmentScore:
         bs = batch.c_struct()
         sw = getattr(self.aligner, "sw", None)
         fn = lib().nvbio_full_sw_score if sw is not None else lib().nvbio_full_gotoh_score
+        rows = max_pattern_len if self.text_blocking else max_text_len
+        temp = _scratch(batch.device, batch.n * max(rows, 1) * 4)
         _check(fn(FMIndex._dev_index(batch.device), ctypes.c_int(self.aligner.type),
                   ctypes.c_int(1 if self.text_blocking else 0),
                   ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c), ctypes.byref(bs),
                   ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms),
-                  _ptr(scores), _ptr(sinks), None, ctypes.c_uint64(0), _stream_ptr(batch.device)))
+                  _ptr(scores), _ptr(sinks), _ptr(temp), ctypes.c_uint64(temp.numel()), _stream_ptr(batch.device)))
         return scores, sinks
 
 
