@@ -48,7 +48,8 @@ constexpr int STRIPE = 8;
 
 // TEXT_BLOCKING: stripes run over the text, the boundary column over the M pattern rows
 // otherwise     : stripes run over the pattern, the boundary column over the N text rows
-template <int TYPE, bool TEXT_BLOCKING, int RBITS, int TBITS, bool BEST2 = false>
+// WIDE: the linear-gap Smith-Waterman / edit-distance family (separate deletion / insertion terms, logical stripes of 16)
+template <int TYPE, bool TEXT_BLOCKING, int RBITS, int TBITS, bool BEST2 = false, bool WIDE = false>
 __global__ void __launch_bounds__(128)
 full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin, const uint32_t jobs, const int32_t* __restrict__ min_scores,
                   uint32_t* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
@@ -86,11 +87,11 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 
     // F runs down the rows of a stripe, E along it: with pattern blocking the rows are text positions (F = the text advancing
     // alone), with text blocking they are pattern positions.  The Gotoh aligner charges the same terms to both (SchemeDev).
-    const int32_t F_o = TEXT_BLOCKING ? sc.ins_go : sc.pat_go, F_e = TEXT_BLOCKING ? sc.ins_ge : sc.pat_ge;
-    const int32_t E_o = TEXT_BLOCKING ? sc.pat_go : sc.ins_go, E_e = TEXT_BLOCKING ? sc.pat_ge : sc.ins_ge;
+    const int32_t F_o = (WIDE && TEXT_BLOCKING) ? sc.ins_go : sc.pat_go, F_e = (WIDE && TEXT_BLOCKING) ? sc.ins_ge : sc.pat_ge;
+    const int32_t E_o = !WIDE ? F_o : (TEXT_BLOCKING ? sc.pat_go : sc.ins_go), E_e = !WIDE ? F_e : (TEXT_BLOCKING ? sc.pat_ge : sc.ins_ge);
     const int32_t infimum = -32768 - (sc.pat_go < sc.pat_ge ? sc.pat_go : sc.pat_ge);   // gotoh_inl.h:634,1038
     const int32_t V = sc.match;
-    const bool    wide = sc.wide != 0;                          // logical stripes of 16 (the SW / edit-distance aligners)
+    constexpr bool wide = WIDE;                                 // logical stripes of 16 (the SW / edit-distance aligners)
 
     const uint32_t rows = TEXT_BLOCKING ? M : N;                // length of the boundary column
     const uint32_t cols = TEXT_BLOCKING ? N : M;                // extent the stripes cover
@@ -132,7 +133,8 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
         for (int j = 0; j <= STRIPE; ++j)
         {
             const bool penal = TEXT_BLOCKING ? (TYPE == NVBIO_GLOBAL) : (TYPE != NVBIO_LOCAL);      // :1061-1066 / :676-681
-            H[j] = penal ? ((block + j > 0) ? sc.top_go + sc.top_ge * (int32_t)(block + j - 1u) : 0) : 0;
+            const int32_t t_o = WIDE ? sc.top_go : sc.pat_go, t_e = WIDE ? sc.top_ge : sc.pat_ge;
+            H[j] = penal ? ((block + j > 0) ? t_o + t_e * (int32_t)(block + j - 1u) : 0) : 0;
             F[j] = infimum;
         }
         int32_t max_score = NVBIO_SCORE_MIN;
@@ -660,7 +662,8 @@ nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits,
                          const uint32_t* job_list, const uint32_t* job_count)
 {
     const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
-#define NVB_GO(RB, TBITS) hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks, job_list, job_count )
+#define NVB_GO(RB, TBITS) do { if (sc.wide) hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS,false,true>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks, job_list, job_count ); \
+                               else         hipLaunchKernelGGL( (full_gotoh_kernel<TYPE,TB,RB,TBITS>), grid, block, 0, s, b, sc, job_begin, jobs, min_scores, column, scores, sinks, job_list, job_count ); } while (0)
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -726,7 +729,8 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
     int32_t P = 0;
     const bool packable_bits = batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2);
     const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && plain_gotoh( sc ) && full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" );
-    const bool packed   = !text_blocking && packable_bits && plain_gotoh( sc ) && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
+    // (two jobs per lane only pay when the lanes still fill the chip: 100 k jobs of the sw-benchmark shape ran 15-20 % slower packed)
+    const bool packed   = !text_blocking && packable_bits && (b.n >= 262144u || getenv( "NVBIO_AMD_FORCE_PACKED_DP" )) && plain_gotoh( sc ) && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
                           !getenv( "NVBIO_AMD_NO_PACKED_DP" );
     if (shortcut || packed)
     {

@@ -217,12 +217,13 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
 
 
 @pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL", "GLOBAL"])
-def test_packed_pattern_blocking_kernel(amd, orc, typ):
+def test_packed_pattern_blocking_kernel(amd, orc, typ, monkeypatch):
     """pattern blocking on a batch of one dominant shape (150 x 400, the opposite-mate case): those jobs run two per
     lane in 16-bit registers, odd-shaped ones through the int32 kernel; odd job counts, reversed / complemented
     reads, qualities, N's, per-job min_score (early exit of one job of a pair only), with and without the
     end-to-end shortcut in front -- every score and sink equals the reference algorithm's"""
     typ = getattr(oracle, typ)
+    monkeypatch.setenv("NVBIO_AMD_FORCE_PACKED_DP", "1")           # the library keeps small batches on the int32 kernel
     rng = np.random.default_rng(41)
     G = 200000
     text = rng.integers(0, 4, G, dtype=np.uint8)
