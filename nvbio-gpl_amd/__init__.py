@@ -89,6 +89,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NvbioError(5, "%s is missing: build it with __graft_entry__.build() "
                                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch first: it ships its own HIP runtime, and the library must bind to the one that owns the tensors it is handed
+        # (loaded the other way round the two runtimes do not see each other's device context: NVBIO_ERR_NO_DEVICE)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.nvbio_amd_last_error.restype = ctypes.c_char_p
         L.nvbio_amd_version.restype = ctypes.c_int
