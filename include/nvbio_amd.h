@@ -223,6 +223,24 @@ nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbi
                                               uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
                                               uint32_t strand, const uint32_t* query_ids_dev, uint64_t* keys_dev, void* stream);
 
+/* Approximate matching by backtracking under the Hamming distance: nvbio::hamming_backtrack (nvbio/fmindex/backtrack.h:51-157),
+ * the kernel of the reference's "approximate search" benchmark (nvbio-test/fmindex_test.cu:739-800; the building block of
+ * nvBowtie's approximate seed mapper, mapping_inl.h:114-184).  The last seed_len symbols of every query are matched exactly, the
+ * rest may differ from the text in up to `mismatches` positions.
+ *   counts_dev[i]   = total number of occurrences (the reference benchmark's CountDelegate: sum of the reported range sizes)
+ *   n_ranges_dev[i] = number of SA ranges the delegate receives (optional)
+ *   ranges_dev      = (optional) the first max_ranges of them per query, [i * max_ranges + k], in the reference's order
+ * The traversal uses the reference benchmark's 128-entry stack; a query that would overflow it makes the call return
+ * NVBIO_ERR_UNSUPPORTED (the reference writes past its array there).  Synchronises the stream.
+ * flags: by default a branch stops when it reaches the start of the pattern, as the reference documents.  The reference's code
+ * does not (backtrack.h:110-116 falls through at l == 0): a branch arriving there with all mismatches used reports its range
+ * twice, and one arriving with some left continues through the symbols that PRECEDE the query in its stream, every branch it
+ * spawns there ending in a report.  NVBIO_BACKTRACK_REFERENCE_QUIRKS reproduces exactly that (queries must then not start at
+ * symbol 0 of the stream; pinned against the reference's own code over PackedStream patterns, tests/golden/bt_golden.npz). */
+enum { NVBIO_BACKTRACK_REFERENCE_QUIRKS = 1 };
+nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t seed_len, uint32_t mismatches, uint32_t flags,
+                                        uint32_t* counts_dev, uint32_t* n_ranges_dev, nvbio_uint2* ranges_dev, uint32_t max_ranges, void* stream);
+
 /* The whole seed pass of one strand in one kernel, for handles that hold the full suffix array and the text: nvBowtie's
  * match_range over every seed (mapping_inl.h:73-86,193-282) followed, for every seed that ends on ONE SA row, by what
  * FMIndexFilter::rank's scan, FMIndexFilter::locate (filter_inl.h:193-252), hit_to_diagonal (examples/fmmap/fmmap.cu:92-117)

@@ -30,6 +30,7 @@ SCORE_MIN = -(1 << 30)
 FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY = 1, 2, 4, 8
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
+BACKTRACK_REFERENCE_QUIRKS = 1
 
 _STATUS = {0: "OK", 1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "UNSUPPORTED", 5: "NO_DEVICE"}
 
@@ -309,6 +310,18 @@ class FMIndex:
         _check(lib().nvbio_fm_match_direct(self._h, ctypes.byref(qs), ctypes.c_uint32(flags), _ptr(ranges), _ptr(direct),
                                            _stream_ptr(self.device)))
         return ranges, direct
+
+    def hamming_backtrack(self, queries, seed_len, mismatches, quirks=False, max_ranges=0):
+        """nvbio::hamming_backtrack with a counting delegate (nvbio_fm_hamming_backtrack) -> (counts, n_ranges, ranges or None)"""
+        torch = _torch()
+        counts = torch.empty(queries.n, dtype=torch.int32, device=self.device)
+        nr = torch.empty(queries.n, dtype=torch.int32, device=self.device)
+        rg = torch.zeros((queries.n, max_ranges, 2), dtype=torch.int32, device=self.device) if max_ranges else None
+        qs = queries.c_struct()
+        _check(lib().nvbio_fm_hamming_backtrack(self._h, ctypes.byref(qs), ctypes.c_uint32(seed_len), ctypes.c_uint32(mismatches),
+                                                ctypes.c_uint32(BACKTRACK_REFERENCE_QUIRKS if quirks else 0), _ptr(counts), _ptr(nr), _ptr(rg),
+                                                ctypes.c_uint32(max_ranges), _stream_ptr(self.device)))
+        return counts, nr, rg
 
     def match_seed_diagonals(self, seeds, flags, read_len, strand, buffers=None):
         """the seed pass of one strand straight to candidate diagonals (nvbio_fm_match_seed_diagonals) ->

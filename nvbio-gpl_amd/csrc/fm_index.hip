@@ -298,6 +298,110 @@ fm_seed_diagonals_kernel(const DevIndex f, const StringSetDev q, const uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hamming_backtrack (nvbio/fmindex/backtrack.h:51-157): approximate matching by backtracking -- the last `seed` symbols of
+// the pattern are matched exactly, the rest may differ from the text in up to `mismatches` positions.  Same traversal as the
+// reference (children pushed for c = 0..3, popped last-in first-out; a branch that has used all its mismatches finishes with
+// an exact match of what is left), so the ranges reach the delegate in the reference's order.  The delegate here is the
+// reference benchmark's CountDelegate (nvbio-test/fmindex_test.cu:720-737) plus, optionally, the list of ranges.
+// The stack lives in private memory (128 entries as the reference's count_core, :757).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rank4_pair(const DevIndex& f, const uint32_t l, const uint32_t r, uint32_t lo[4], uint32_t hi[4])
+{
+    #pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) { lo[c] = rank_row( f, l, c ); hi[c] = rank_row( f, r, c ); }
+}
+
+constexpr uint32_t BACKTRACK_STACK = 128u;
+
+template <int BITS>
+__global__ void __launch_bounds__(128)
+fm_hamming_backtrack_kernel(const DevIndex f, const StringSetDev q, const uint32_t seed_len, const uint32_t mismatches, const bool quirks,
+                            uint32_t* __restrict__ counts, uint32_t* __restrict__ n_ranges, uint2* __restrict__ ranges, const uint32_t max_ranges,
+                            uint32_t* __restrict__ overflow)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x)
+    {
+        uint32_t begin, len;
+        string_bounds( q, i, begin, len );
+        SymbolReader<BITS> rd( q.symbols );
+        auto pat = [&](const uint32_t k) -> uint32_t { return rd.get( (uint32_t)(begin + k) ); };   // 32-bit index arithmetic, as PackedStream's
+        // match( fmi, pattern + off, n, range ): backward over pattern[off + n - 1 .. off]; the reference's loop index is an
+        // int32 (fmindex_inl.h:223), so a length above 2^31 (quirks mode only) runs no step at all
+        auto match_from = [&](uint32_t x, uint32_t y, const uint32_t off, const uint32_t n, uint32_t& ox, uint32_t& oy) {
+            uint32_t nb = 0;
+            for (uint32_t k = (n > 0x80000000u ? 0u : n); k > 0u && x <= y; --k)
+            {
+                const uint32_t c = pat( off + k - 1u );
+                if (c > 3u) { x = 1u; y = 0u; break; }
+                search_step<false>( f, x, y, c, nb );
+            }
+            ox = x; oy = y;
+        };
+        uint32_t total = 0, nr = 0;
+        auto report = [&](const uint32_t x, const uint32_t y) {
+            total += y + 1u - x;
+            if (ranges && nr < max_ranges) ranges[(size_t)i * max_ranges + nr] = make_uint2( x, y );
+            ++nr;
+        };
+        const uint32_t seed = seed_len < len ? seed_len : len;
+        if (mismatches == 0u || seed == len)
+        {
+            uint32_t x, y; match_from( 0u, f.length, 0u, len, x, y );
+            if (x <= y) report( x, y );
+        }
+        else
+        {
+            uint32_t rx, ry; match_from( 0u, f.length, len - seed, seed, rx, ry );
+            if (rx <= ry)
+            {
+                uint4 stack[BACKTRACK_STACK];
+                uint32_t sp = 0;
+                uint32_t lo[4], hi[4];
+                rank4_pair( f, rx - 1u, ry, lo, hi );
+                const uint32_t c0 = pat( len - seed - 1u );
+                for (uint32_t c = 0; c < 4u; ++c)
+                    if (lo[c] < hi[c])
+                        stack[sp++] = make_uint4( L2_of( f, c ) + lo[c] + 1u, L2_of( f, c ) + hi[c], (c == c0) ? 0u : 1u, len - seed - 1u );
+                while (sp)
+                {
+                    const uint4 e = stack[--sp];
+                    const uint32_t cost = e.z, l = e.w;
+                    if (l == 0u)
+                    {
+                        if (e.x <= e.y) report( e.x, e.y );
+                        // The reference does not stop here (backtrack.h:110-116 falls through): a branch that arrives with all
+                        // its mismatches used reports the range a second time, one that arrives with some left goes on past
+                        // the start of the pattern, through whatever precedes it in the stream (index l - 1 = 0xFFFFFFFF wraps),
+                        // and every branch it spawns there ends in a "match" over a length of 2^32 - k symbols that runs no
+                        // step and reports.  Default: stop, as the documentation describes.  quirks: do as the code does.
+                        if (!quirks) continue;
+                    }
+                    if (cost < mismatches)
+                    {
+                        rank4_pair( f, e.x - 1u, e.y, lo, hi );
+                        const uint32_t cp = pat( l - 1u );
+                        for (uint32_t c = 0; c < 4u; ++c)
+                            if (lo[c] < hi[c])
+                            {
+                                if (sp < BACKTRACK_STACK)
+                                    stack[sp++] = make_uint4( L2_of( f, c ) + lo[c] + 1u, L2_of( f, c ) + hi[c], cost + (c == cp ? 0u : 1u), l - 1u );
+                                else atomicAdd( overflow, 1u );
+                            }
+                    }
+                    else
+                    {
+                        uint32_t x, y; match_from( e.x, e.y, 0u, l, x, y );
+                        if (x <= y) report( x, y );
+                    }
+                }
+            }
+        }
+        counts[i] = total;
+        if (n_ranges) n_ranges[i] = nr;
+    }
+}
+
 // level j of the k-mer table from level j-1: entry (key<<2 | c) = one search step on entry key
 // (or the entry itself when it is already empty: the reference's loop would have stopped there)
 __global__ void __launch_bounds__(256)
@@ -832,6 +936,41 @@ nvbio_status nvbio_fm_match_direct(nvbio_fm_index_t index, const nvbio_string_se
     }
 #undef NVB_LAUNCH_DIRECT
     NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t seed_len, uint32_t mismatches, uint32_t flags,
+                                        uint32_t* counts_dev, uint32_t* n_ranges_dev, nvbio_uint2* ranges_dev, uint32_t max_ranges, void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    StringSetDev q; NVB_CHECK( make_set( queries, &q ) );
+    if (q.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( counts_dev != nullptr, "counts_dev is NULL" );
+    NVB_REQUIRE( ranges_dev == nullptr || max_ranges > 0, "ranges_dev without max_ranges" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* overflow = nullptr;
+    NVB_HIP( hipMallocAsync( (void**)&overflow, sizeof(uint32_t), s ) );
+    NVB_HIP( hipMemsetAsync( overflow, 0, sizeof(uint32_t), s ) );
+    const DevIndex f = idx->dev();
+    const dim3 grid( grid_for( q.n, 128 ) ), block( 128 );
+#define NVB_LAUNCH_BT(BITS) hipLaunchKernelGGL( (fm_hamming_backtrack_kernel<BITS>), grid, block, 0, s, f, q, seed_len, mismatches, (flags & NVBIO_BACKTRACK_REFERENCE_QUIRKS) != 0, counts_dev, n_ranges_dev, \
+                                                (uint2*)ranges_dev, max_ranges, overflow )
+    switch (queries->symbol_bits)
+    {
+    case 2: NVB_LAUNCH_BT(2); break;
+    case 4: NVB_LAUNCH_BT(4); break;
+    default: NVB_LAUNCH_BT(8); break;
+    }
+#undef NVB_LAUNCH_BT
+    uint32_t h_over = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync( &h_over, overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s );
+    if (e == hipSuccess) e = hipStreamSynchronize( s );
+    (void)hipFreeAsync( overflow, s );
+    if (e != hipSuccess) { set_error( "hamming_backtrack failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    if (h_over) { set_error( "hamming_backtrack: the 128-entry stack of the reference's benchmark overflowed for %u branches", h_over ); return NVBIO_ERR_UNSUPPORTED; }
     return NVBIO_OK;
 }
 

@@ -369,6 +369,18 @@ class Oracle:
                                   _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def hamming_backtrack(self, idx, stream, begin, length, seed, mismatches, quirks=False, cap=64):
+        """hamming_backtrack with a counting delegate -> (count, n_ranges, ranges uint32 [min(n, cap), 2]); stream: uint8 symbols"""
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        cnt = ctypes.c_uint32(0)
+        rg = np.zeros((cap, 2), dtype=np.uint32)
+        self.lib.orc_hamming_backtrack.restype = ctypes.c_uint32
+        v = idx.view()
+        n = self.lib.orc_hamming_backtrack(ctypes.byref(v), _p(stream, _u8p), ctypes.c_uint32(begin), ctypes.c_uint32(length),
+                                           ctypes.c_uint32(seed), ctypes.c_uint32(mismatches), ctypes.c_int(1 if quirks else 0),
+                                           ctypes.byref(cnt), _p(rg, _u32p), ctypes.c_uint32(cap))
+        return cnt.value, int(n), rg[:min(int(n), cap)].copy()
+
     def score_reduce(self, scores, pos, rc, read_len, worst_score):
         """nvBowtie's score_reduce_kernel for one read over candidates in the order given
         -> (a1 aligned, a1 score, a1 pos, a1 rc, a2 aligned, a2 score, a2 pos, a2 rc)"""
@@ -542,6 +554,17 @@ class Reference:
         ok = self.lib.ref_banded_ed(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
                                     _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def hamming_backtrack(self, idx, stream_words, begin, length, seed, mismatches, cap=64):
+        """nvbio::hamming_backtrack over a 2-bit PackedStream pattern, as the reference's benchmark (fmindex_test.cu:744-767)"""
+        w = np.ascontiguousarray(stream_words, dtype=np.uint32)
+        cnt = ctypes.c_uint32(0)
+        rg = np.zeros((cap, 2), dtype=np.uint32)
+        self.lib.ref_hamming_backtrack.restype = ctypes.c_uint32
+        n = self.lib.ref_hamming_backtrack(idx.handle, _p(w, _u32p), ctypes.c_uint32(begin), ctypes.c_uint32(length),
+                                           ctypes.c_uint32(seed), ctypes.c_uint32(mismatches), ctypes.byref(cnt), _p(rg, _u32p),
+                                           ctypes.c_uint32(cap))
+        return cnt.value, int(n), rg[:min(int(n), cap)].copy()
 
     def banded_gotoh_best2(self, band, typ, scheme, pat, txt, quals=None, dist=0):
         """aln::banded_alignment_score<BAND> with aln::Best2Sink<int32>(dist) (sink.h:96-116) -> (ok, (s1, x1, y1, s2, x2, y2))"""

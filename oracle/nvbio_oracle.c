@@ -1163,6 +1163,80 @@ void orc_banded_gotoh_traceback_packed_batch(uint32_t band, int type, const orc_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * hamming_backtrack (nvbio/fmindex/backtrack.h:51-157) with the reference benchmark's CountDelegate
+ * (nvbio-test/fmindex_test.cu:720-737).  stream = the whole symbol stream the pattern lives in, pattern = stream + begin.
+ * quirks = 0: a branch stops at the start of the pattern (the documented behaviour);
+ * quirks = 1: the code's behaviour -- no stop at l == 0 (:110-116): second report when all mismatches are used, otherwise the walk
+ *             continues through the symbols preceding the pattern (32-bit index arithmetic, as the benchmark's PackedStream), and
+ *             match() over a length above 2^31 runs no step (its loop index is an int32, fmindex_inl.h:223).
+ * Returns the number of ranges reported; *count = sum of their sizes (uint32); the first `cap` ranges go to ranges[2k], [2k+1].
+ * ------------------------------------------------------------------------------------------ */
+static void bt_match(const orc_fm_index* f, const uint8_t* stream, uint32_t begin, uint32_t len, uint32_t range[2])
+{
+    uint32_t x = range[0], y = range[1];
+    for (int32_t i = (int32_t)(len - 1u); i >= 0 && x <= y; --i)
+    {
+        const uint8_t c = stream[(uint32_t)(begin + (uint32_t)i)];
+        if (c > 3) { x = 1; y = 0; break; }
+        uint32_t r[2]; fm_rank2( f, x - 1u, y, c, r, 0 );
+        x = f->L2[c] + r[0] + 1u; y = f->L2[c] + r[1];
+    }
+    range[0] = x; range[1] = y;
+}
+uint32_t orc_hamming_backtrack(const orc_fm_index* f, const uint8_t* stream, uint32_t begin, uint32_t len, uint32_t seed, uint32_t mismatches,
+                               int quirks, uint32_t* count, uint32_t* ranges, uint32_t cap)
+{
+    uint32_t total = 0, nr = 0;
+#define BT_REPORT(X, Y) do { total += (Y) + 1u - (X); if (ranges && nr < cap) { ranges[2u*nr] = (X); ranges[2u*nr+1u] = (Y); } ++nr; } while (0)
+    if (seed > len) seed = len;
+    if (mismatches == 0 || seed == len)
+    {
+        uint32_t r[2] = { 0, f->length }; bt_match( f, stream, begin, len, r );
+        if (r[0] <= r[1]) BT_REPORT( r[0], r[1] );
+    }
+    else
+    {
+        uint32_t root[2] = { 0, f->length }; bt_match( f, stream, begin + len - seed, seed, root );
+        if (root[0] <= root[1])
+        {
+            static __thread uint32_t stack[4096][4];
+            uint32_t sp = 0, lo[4], hi[4];
+            orc_rank4( f, root[0] - 1u, lo ); orc_rank4( f, root[1], hi );
+            const uint8_t c0 = stream[(uint32_t)(begin + len - seed - 1u)];
+            for (uint32_t c = 0; c < 4; ++c)
+                if (lo[c] < hi[c]) { stack[sp][0] = f->L2[c] + lo[c] + 1u; stack[sp][1] = f->L2[c] + hi[c]; stack[sp][2] = (c == c0) ? 0u : 1u; stack[sp][3] = len - seed - 1u; ++sp; }
+            while (sp)
+            {
+                --sp;
+                uint32_t range[2] = { stack[sp][0], stack[sp][1] };
+                const uint32_t cost = stack[sp][2], l = stack[sp][3];
+                if (l == 0u)
+                {
+                    if (range[0] <= range[1]) BT_REPORT( range[0], range[1] );
+                    if (!quirks) continue;
+                }
+                if (cost < mismatches)
+                {
+                    orc_rank4( f, range[0] - 1u, lo ); orc_rank4( f, range[1], hi );
+                    const uint8_t cp = stream[(uint32_t)(begin + (uint32_t)(l - 1u))];
+                    for (uint32_t c = 0; c < 4; ++c)
+                        if (lo[c] < hi[c] && sp < 4096u)
+                        { stack[sp][0] = f->L2[c] + lo[c] + 1u; stack[sp][1] = f->L2[c] + hi[c]; stack[sp][2] = cost + (c == cp ? 0u : 1u); stack[sp][3] = l - 1u; ++sp; }
+                }
+                else
+                {
+                    bt_match( f, stream, begin, l, range );
+                    if (range[0] <= range[1]) BT_REPORT( range[0], range[1] );
+                }
+            }
+        }
+    }
+#undef BT_REPORT
+    *count = total;
+    return nr;
+}
+
+/* ------------------------------------------------------------------------------------------
  * nvBowtie's best / second-best bookkeeping and mapping quality, restated from device-only / thrust-bound sources
  * (PARITY UNPINNED: neither reduce_inl.h nor mapq.h compiles host-only in the development container)
  * ------------------------------------------------------------------------------------------ */

@@ -205,6 +205,9 @@ void orc_banded_gotoh_packed_batch(uint32_t band, int type, const orc_gotoh_sche
 
 int orc_num_threads(void);
 
+/* hamming_backtrack (nvbio/fmindex/backtrack.h) with a counting delegate; see nvbio_oracle.c */
+uint32_t orc_hamming_backtrack(const orc_fm_index* f, const uint8_t* stream, uint32_t begin, uint32_t len, uint32_t seed, uint32_t mismatches,
+                               int quirks, uint32_t* count, uint32_t* ranges, uint32_t cap);
 /* nvBowtie's best / second-best reduction for one read (reduce_inl.h:65-140) and Bowtie2's mapping quality (mapq.h:32-297) */
 void orc_score_reduce(const int32_t* scores, const uint32_t* pos, const uint8_t* rc, uint32_t n, uint32_t read_len, int32_t worst_score,
                       int64_t out[8]);

@@ -32,6 +32,7 @@
 #include <nvbio/fmindex/bwt.h>
 #include <nvbio/fmindex/rank_dictionary.h>
 #include <nvbio/fmindex/fmindex.h>
+#include <nvbio/fmindex/backtrack.h>
 #include <nvbio/alignment/alignment.h>
 #include <vector>
 #include <cstring>
@@ -547,6 +548,32 @@ void ref_fm_rank4(void* h, uint32_t k, uint32_t* out)
 }
 
 // queries: one symbol per byte (values > 3 are 'N'), offsets[n_q+1]
+// nvbio::hamming_backtrack (nvbio/fmindex/backtrack.h:51-157) exactly as the reference's benchmark calls it (count_core,
+// nvbio-test/fmindex_test.cu:744-767): the pattern is an iterator into a 2-bit PackedStream of all reads (32-bit index
+// arithmetic), the stack holds 128 uint4, the delegate adds up the range sizes -- here it also records the ranges.
+struct RecordingCountDelegate
+{
+    uint32 count, n; uint32* ranges; uint32 cap;
+    void operator() (const uint2 range)
+    {
+        count += range.y + 1u - range.x;
+        if (ranges && n < cap) { ranges[2*n] = range.x; ranges[2*n+1] = range.y; }
+        ++n;
+    }
+};
+uint32_t ref_hamming_backtrack(void* h, const uint32_t* stream_words, uint32_t begin, uint32_t len, uint32_t seed, uint32_t mismatches,
+                               uint32_t* count, uint32_t* ranges, uint32_t cap)
+{
+    const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();
+    typedef PackedStream<const uint32*,uint8,2u,true> stream_type;
+    const stream_type stream( stream_words );
+    uint4 stack[32*4 + 1024];                      // the benchmark's 32*4 plus slack: an overrun must not corrupt the driver
+    RecordingCountDelegate d; d.count = 0; d.n = 0; d.ranges = ranges; d.cap = cap;
+    hamming_backtrack( fmi, stream.begin() + begin, len, seed, mismatches, stack, d );
+    *count = d.count;
+    return d.n;
+}
+
 void ref_fm_match(void* h, const uint8_t* syms, const uint32_t* offsets, uint32_t n_q, uint32_t* ranges, int reverse)
 {
     const RefIndex::fm_index_type fmi = ((RefIndex*)h)->fmi();

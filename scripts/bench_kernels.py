@@ -103,6 +103,23 @@ def main():
     ms = timed(torch, lambda: flt.locate(0, total), reps=20, warm=3)
     print(json.dumps({"config": "2 locate of every hit", "hits": int(total), "ms": ms, "hits_per_s": total / (ms * 1e-3)}), flush=True)
 
+    # ---- the reference's "approximate search" benchmark shape (nvbio-test/fmindex_test.cu:890-965): hamming_backtrack -------
+    if os.environ.get("BENCH_ONLY", "approx") == "approx" or not os.environ.get("BENCH_ONLY"):
+        for L2_, seed_, mm_ in ((32, 0, 1), (50, 25, 2)):
+            g.manual_seed(3)
+            st = torch.randint(0, n - L2_, (Q,), device=dev, generator=g, dtype=torch.int64)
+            sy = bench.genome_symbols(genome, st[:, None] + torch.arange(L2_, device=dev)[None, :])
+            sub = torch.rand(sy.shape, device=dev, generator=g) < 0.01
+            sy = torch.where(sub, (sy + 1) % 4, sy)
+            stride = 56
+            pad = torch.zeros((Q, stride), dtype=torch.uint8, device=dev); pad[:, :L2_] = sy
+            qa = amd.PackedStringSet(bench.pack4(pad.reshape(-1)), 4, Q, fixed_len=L2_, stride=stride, device=dev)
+            ms = timed(torch, lambda: fmi.hamming_backtrack(qa, seed_, mm_), reps=5, warm=1)
+            cnt, nr, _ = fmi.hamming_backtrack(qa, seed_, mm_)
+            print(json.dumps({"config": "FM approximate search (hamming_backtrack) 1M x %d bp, seed %d, <= %d mismatches, vs 3 Gbp" % (L2_, seed_, mm_),
+                              "ms": ms, "queries_per_s": Q / (ms * 1e-3), "queries_with_hits": float((cnt != 0).float().mean()),
+                              "mean_ranges": float(nr.float().mean())}), flush=True)
+
     # ---- config 4 slice: 6.25 M pairs, band 31 -----------------------------------------------------
     P, M = 6_250_000, 150
     g.manual_seed(4)

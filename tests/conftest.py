@@ -62,6 +62,11 @@ def ed_golden():
 
 
 @pytest.fixture(scope="session")
+def bt_golden():
+    return np.load(os.path.join(GOLDEN, "bt_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def best2_golden():
     return np.load(os.path.join(GOLDEN, "best2_golden.npz"), allow_pickle=False)
 

@@ -17,6 +17,7 @@ Fixtures:
                   full-matrix Gotoh (pattern/text blocking x 3 types, with and without min_score).
   ed_golden.npz   the same pairs scored by the reference's banded edit-distance aligner.
   ftb_golden.npz  the same pairs traced back through the full matrix (alignment_traceback).
+  bt_golden.npz   hamming_backtrack (approximate FM-index search) over that index.
   best2_golden.npz the same pairs scored into aln::Best2Sink (best two distinct alignments).
   sw_golden.npz   the same pairs scored by the reference's linear-gap Smith-Waterman aligner (banded and full
                   matrix) and by its full-matrix edit-distance aligner.
@@ -365,6 +366,43 @@ def make_best2(R):
     print("best2_golden.npz: %d pairs" % n)
 
 
+def make_bt(R):
+    """bt_golden.npz: nvbio::hamming_backtrack (the reference's approximate-search benchmark kernel, fmindex_test.cu:739-800)
+    over the index of fm_golden.npz: 300 queries of 20-28 symbols in one 2-bit PackedStream (64 symbols of padding in front:
+    the reference's traversal walks into what precedes a query, see nvbio_amd.h), text substrings with 0-2 substitutions plus
+    random ones, for (seed, mismatches) in ((10,1), (12,2), (8,0)): count, number of ranges, first 48 ranges each."""
+    g = np.load(os.path.join(HERE, "fm_golden.npz"))
+    text = g["text"]
+    O = oracle.Oracle()
+    hidx = R.build_index(text)
+    rng = np.random.default_rng(4242)
+    Q = 300
+    lens = rng.integers(20, 29, Q)
+    offs = np.zeros(Q + 1, dtype=np.uint32); offs[0] = 64; offs[1:] = 64 + np.cumsum(lens)
+    stream = rng.integers(0, 4, int(offs[-1]) + 64, dtype=np.uint8)
+    for i in range(Q):
+        if i % 6 != 5:
+            p0 = int(rng.integers(0, len(text) - lens[i]))
+            q = text[p0:p0 + lens[i]].copy()
+            for _ in range(int(rng.integers(0, 3))):
+                k = int(rng.integers(0, lens[i])); q[k] = (q[k] + 1 + rng.integers(0, 3)) % 4
+            stream[offs[i]:offs[i + 1]] = q
+    words = O.pack2(stream)
+    modes = ((10, 1), (12, 2), (8, 0))
+    CAP = 48
+    counts = np.zeros((len(modes), Q), dtype=np.int64); nrs = np.zeros((len(modes), Q), dtype=np.int64)
+    ranges = np.zeros((len(modes), Q, CAP, 2), dtype=np.int64)
+    for mi, (seed, mm) in enumerate(modes):
+        for i in range(Q):
+            c, n, rg = R.hamming_backtrack(hidx, words, int(offs[i]), int(lens[i]), seed, mm, cap=CAP)
+            counts[mi, i], nrs[mi, i] = c, n
+            ranges[mi, i, :len(rg)] = rg
+    R.destroy(hidx)
+    np.savez_compressed(os.path.join(HERE, "bt_golden.npz"), stream=stream, offs=offs, modes=np.array(modes), counts=counts,
+                        n_ranges=nrs, ranges=ranges)
+    print("bt_golden.npz: %d queries, %d..%d ranges" % (Q, nrs.min(), nrs.max()))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -376,3 +414,4 @@ if __name__ == "__main__":
     make_ftb(R)
     make_sw(R)
     make_best2(R)
+    make_bt(R)

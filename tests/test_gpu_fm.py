@@ -214,3 +214,50 @@ def test_seed_enumeration_and_diagonal_helpers(amd, orc, big):
     np.maximum.at(want, ck.cpu().numpy() >> 34, sel)
     assert np.array_equal(best, want)
     fmi.close()
+
+
+def test_hamming_backtrack(amd, orc, fm_golden, bt_golden):
+    """nvbio_fm_hamming_backtrack: reference-quirks mode against the reference's own outputs (bt_golden.npz: counts, numbers
+    of ranges, ranges in delegate order), default mode against the oracle (itself checked against a brute-force Hamming scan),
+    2-bit, 4-bit and byte queries; then 20,000 queries on a larger index against the oracle"""
+    g, b = fm_golden, bt_golden
+    fmi = _golden_dev_index(amd, g, 4)
+    stream, offs = b["stream"], b["offs"].astype(np.uint32)
+    hidx = oracle.HostIndex(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"])
+    Q = len(offs) - 1
+    for bits, sym in ((2, orc.pack2(stream)), (4, orc.pack4(stream)), (8, stream)):
+        qs = amd.PackedStringSet(sym, bits, Q, offsets=offs, ranges=True)
+        for mi, (seed, mm) in enumerate(b["modes"]):
+            cnt, nr, rg = fmi.hamming_backtrack(qs, int(seed), int(mm), quirks=True, max_ranges=48)
+            assert np.array_equal(amd.u32(cnt).astype(np.int64), b["counts"][mi]) and np.array_equal(amd.u32(nr).astype(np.int64), b["n_ranges"][mi])
+            got = amd.u32(rg).astype(np.int64)
+            for i in range(Q):
+                k = min(int(b["n_ranges"][mi, i]), 48)
+                assert np.array_equal(got[i, :k], b["ranges"][mi, i, :k]), (bits, mi, i)
+            cnt, nr, _ = fmi.hamming_backtrack(qs, int(seed), int(mm))
+            want = [orc.hamming_backtrack(hidx, stream, int(offs[i]), int(offs[i + 1] - offs[i]), int(seed), int(mm))[:2] for i in range(Q)]
+            assert np.array_equal(amd.u32(cnt), np.array([w[0] for w in want], dtype=np.uint32))
+            assert np.array_equal(amd.u32(nr), np.array([w[1] for w in want], dtype=np.uint32))
+    fmi.close()
+    rng = np.random.default_rng(8)
+    G = 400000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.from_arrays(hidx.n, hidx.primary, hidx.L2, hidx.bwt_occ, hidx.ssa, kmer_len=8)
+    Q, L = 20000, 32
+    starts = rng.integers(0, G - L, Q)
+    qsym = np.stack([text[s:s + L] for s in starts]).copy()
+    flip = rng.random(qsym.shape) < 0.03
+    qsym[flip] = (qsym[flip] + 1 + rng.integers(0, 3, int(flip.sum()))) % 4
+    flat = np.concatenate([rng.integers(0, 4, 64, dtype=np.uint8), qsym.reshape(-1)])
+    offs = (64 + np.arange(Q + 1) * L).astype(np.uint32)
+    qs = amd.PackedStringSet(orc.pack2(flat), 2, Q, offsets=offs, ranges=True)
+    for seed, mm in ((16, 1), (14, 2)):
+        for quirks in (False, True):
+            cnt, nr, _ = fmi.hamming_backtrack(qs, seed, mm, quirks=quirks)
+            cnt, nr = amd.u32(cnt), amd.u32(nr)
+            for i in range(0, Q, 9):
+                c, n, _ = orc.hamming_backtrack(hidx, flat, int(offs[i]), L, seed, mm, quirks=quirks)
+                assert (int(cnt[i]), int(nr[i])) == (c, n), (seed, mm, quirks, i)
+        assert (cnt > 0).mean() > 0.5
+    fmi.close()

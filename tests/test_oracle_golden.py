@@ -258,6 +258,29 @@ def test_smith_waterman_family_golden(orc, dp_golden, sw_golden):
     assert checked > 20000
 
 
+def test_hamming_backtrack_golden(orc, fm_golden, bt_golden):
+    """nvbio::hamming_backtrack (approximate FM-index search, the reference's benchmark kernel): in `quirks` mode the restatement
+    equals the reference's own code run over PackedStream patterns -- count, number of ranges, the ranges in delegate order --
+    including what that code does at the start of the pattern (no stop at l == 0); in the default mode it equals a brute-force
+    Hamming scan of the text (seed part exact, at most `mismatches` elsewhere)"""
+    g, b = fm_golden, bt_golden
+    hidx = oracle.HostIndex(len(g["text"]), int(g["primary"]), g["L2"], g["bwt_occ"], g["ssa"])
+    stream, offs, text = b["stream"], b["offs"], g["text"]
+    differ = 0
+    for mi, (seed, mm) in enumerate(b["modes"]):
+        for i in range(len(offs) - 1):
+            L = int(offs[i + 1] - offs[i])
+            c, n, rg = orc.hamming_backtrack(hidx, stream, int(offs[i]), L, int(seed), int(mm), quirks=True, cap=48)
+            assert (c, n) == (int(b["counts"][mi, i]), int(b["n_ranges"][mi, i])), (mi, i)
+            assert np.array_equal(rg.astype(np.int64), b["ranges"][mi, i, :min(n, 48)]), (mi, i)
+            c2, _, _ = orc.hamming_backtrack(hidx, stream, int(offs[i]), L, int(seed), int(mm))
+            mis = np.lib.stride_tricks.sliding_window_view(text, L) != stream[offs[i]:offs[i + 1]][None, :]
+            hit = (mis.sum(1) == 0) if int(mm) == 0 else ((mis[:, L - int(seed):].sum(1) == 0) & (mis.sum(1) <= int(mm)))
+            assert c2 == int(hit.sum()), (mi, i)
+            differ += c != c2
+    assert differ > 100            # the reference's fall-through at l == 0 inflates the counts of most hitting queries
+
+
 def test_best2_sink_golden(orc, dp_golden, best2_golden):
     """aln::Best2Sink<int32>(distinct_dist) (sink.h:96-116): the best two distinct alignments of the banded and the full-matrix
     DP, on the reference's own outputs -- an order-dependent sink, so this also pins the order of the reports"""
