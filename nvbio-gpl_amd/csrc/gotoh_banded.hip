@@ -500,13 +500,20 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
 // Reportable end columns: d = 0 always, d >= 1 iff d < min(M+30, N) - (M-1) (gotoh_banded_inl.h:631-643); such
 // diagonals lie inside the text, so the band-31 cache quirk for symbols past the text end never touches them.
 // ---------------------------------------------------------------------------------------------
-template <int RBITS>
+// THIRD = false: the pass over every job (first and second chance); a job that neither settles but whose U* a third chance could
+//   still settle (see below) gets need_dp = 2.
+// THIRD = true : the pass over the list of those jobs (job_list / job_count on the device), which resolves each to 0 or 1.
+//   Kept apart because the third chance is ten times the work of the rest and only one job in eight needs it: inside the first
+//   pass every wave paid for it (measured: 0.39 -> 2.1 ms per launch), on a dense list it costs what it saves several times over.
+template <int RBITS, bool THIRD>
 __global__ void __launch_bounds__(256)
 ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
-                      int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp)
+                      int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp,
+                      const uint32_t* __restrict__ job_list = nullptr, const uint32_t* __restrict__ job_count = nullptr)
 {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= b.n) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (THIRD ? slot >= *job_count : slot >= b.n) return;
+    const uint32_t job = THIRD ? job_list[slot] : slot;
     const uint32_t rid   = b.read_id ? b.read_id[job] : job;
     const uint32_t first = b.read_offsets[rid];
     const uint32_t M     = b.read_offsets[rid + 1] - first;
@@ -586,7 +593,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     }
     const int64_t U = -(int64_t)P * (int64_t)best_cnt;
     bool settled = U > (int64_t)G;
-    if (!settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u)
+    if (!THIRD && !settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u)
     {
         // Second chance (two mismatches at nvBowtie's -6 / -8 / -3).  U* <= G, but one gap plus one mismatch and two gaps
         // both score below U*: the only gapped alignments that could reach U* have exactly ONE gap and NO mismatch, i.e. a
@@ -641,6 +648,129 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
             settled = !gapped;
         }
     }
+    // which classes of gapped alignments can reach U* by score alone (third chance; two or three mismatches at -6 / -8 / -3):
+    //   A  one gap of g <= gmax0 symbols, no mismatch          (open + (g-1) ext >= U*)
+    //   B  one gap of g <= gmax1 symbols and ONE mismatch      (open + (g-1) ext - P >= U*)
+    //   C  two gaps of one symbol each, no mismatch            (2 open >= U*)
+    // anything beyond (one gap + two mismatches, two gaps with a longer one or a mismatch, three gaps, gaps over 4) means DP.
+    const int64_t go = gap_open, ge = gap_ext;
+    int32_t gmax0 = 0, gmax1 = 0;
+    while (gmax0 < 5 && go + (int64_t)gmax0 * ge >= U) ++gmax0;
+    while (gmax1 < 5 && go + (int64_t)gmax1 * ge - P >= U) ++gmax1;
+    const bool two11  = 2 * go >= U;
+    const bool beyond = gmax0 > 4 || gmax1 > 4 || go - 2 * (int64_t)P >= U || 2 * go + ge >= U || 2 * go - P >= U || 3 * go >= U || ge < go;
+    const bool third_applies = !settled && N >= M + 30u && !beyond && gmax0 >= 1 && (gmax1 >= 1 || two11);
+    if (!THIRD && third_applies)
+    {
+        need_dp[job] = 2;                                        // for the second launch
+        return;
+    }
+    if (THIRD && third_applies)
+    {
+        // With lead0/lead1(d) = rows before the first / second mismatch of diagonal d and tail0/tail1(d) = rows after its last /
+        // last-but-one mismatch:
+        //   text gap g (prefix on d-g, suffix on d) with <= e mismatches  iff  lead_i(d-g) + tail_{e-i}(d) >= M for some i <= e
+        //   pattern gap g (prefix on d, suffix on d-g)                    iff  lead_i(d) + tail_{e-i}(d-g) + g >= M
+        //   C through a middle diagonal b with neighbours a, c = b +- 1: the prefix on a may run to row lo = lead0(a) (+1 after a
+        //     pattern gap), the suffix on c may start at row hi = M - tail0(c) (-1 before a pattern gap): it exists iff lo >= hi
+        //     or b has no mismatch in rows [lo, hi).
+        // Existence is over-approximated (band limits and reportable columns are ignored), which only costs a DP.  If no class
+        // has a member the optimum is U* and only ungapped diagonals reach it.  A gapped alignment that merely TIES U* also goes
+        // to the DP (the sink rule decides there).  (N >= M + 30: all 31 diagonals lie inside the text, no sentinel cell.)
+        #pragma unroll
+        for (int k = 0; k < 7; ++k) { ql[k] = ql0[k]; qh[k] = qh0[k]; }
+        uint32_t lead0_p[4] = { 0, 0, 0, 0 }, lead1_p[4] = { 0, 0, 0, 0 }, tail0_p[4] = { 0, 0, 0, 0 }, tail1_p[4] = { 0, 0, 0, 0 };   // d-1 .. d-4
+        uint32_t mmp[6] = { 0, 0, 0, 0, 0, 0 };                                         // mismatch words of diagonal d-1
+        bool gapped = false;
+        for (uint32_t d = 0; d <= 31u && !gapped; ++d)
+        {
+            const bool have = d < 31u;                                                  // d = 31 only closes class C for b = 30
+            uint32_t mm[6];
+            uint32_t first = M, second = M, last = 0xFFFFFFFFu, last2 = 0xFFFFFFFFu;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k) mm[k] = have ? ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k]) : 0u;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                uint32_t w = mm[k];
+                if (first == M && w) { first = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                if (first != M && second == M && w) second = 32u * k + (uint32_t)__builtin_ctz( w );
+            }
+            #pragma unroll
+            for (int k = 5; k >= 0; --k)
+            {
+                uint32_t w = mm[k];
+                if (last == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); last = 32u * k + t; w &= ~(1u << t); }
+                if (last != 0xFFFFFFFFu && last2 == 0xFFFFFFFFu && w) last2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
+            }
+            const uint32_t lead0 = first, lead1 = second;                               // rows before the 1st / 2nd mismatch
+            const uint32_t tail0 = (last  == 0xFFFFFFFFu) ? M : M - 1u - last;          // rows after the last / last-but-one
+            const uint32_t tail1 = (last2 == 0xFFFFFFFFu) ? M : M - 1u - last2;
+            if (have)
+            {
+                #pragma unroll
+                for (int g = 1; g <= 4; ++g)
+                    if (d >= (uint32_t)g)
+                    {
+                        if (g <= gmax0)
+                        {
+                            if (lead0_p[g - 1] + tail0 >= M) gapped = true;                                   // A, text gap
+                            if (lead0 + tail0_p[g - 1] + (uint32_t)g >= M) gapped = true;                     // A, pattern gap
+                        }
+                        if (g <= gmax1)
+                        {
+                            if (lead0_p[g - 1] + tail1 >= M || lead1_p[g - 1] + tail0 >= M) gapped = true;    // B, text gap
+                            if (lead0 + tail1_p[g - 1] + (uint32_t)g >= M || lead1 + tail0_p[g - 1] + (uint32_t)g >= M) gapped = true;
+                        }
+                    }
+            }
+            if (two11 && d >= 1u)
+            {
+                // middle diagonal b = d-1 (words mmp); neighbours d-2 (lead0_p[1] / tail0_p[1], if d >= 2) and d (if have)
+                int32_t lo_c[2], hi_c[2]; int n_lo = 0, n_hi = 0;
+                if (d >= 2u) { lo_c[n_lo++] = (int32_t)lead0_p[1];        hi_c[n_hi++] = (int32_t)M - (int32_t)tail0_p[1] - 1; }   // a = b-1: text gap in; c = b-1: pattern gap out
+                if (have)    { lo_c[n_lo++] = (int32_t)lead0 + 1;         hi_c[n_hi++] = (int32_t)M - (int32_t)tail0; }           // a = b+1: pattern gap in; c = b+1: text gap out
+                for (int x = 0; x < n_lo; ++x)
+                    for (int y = 0; y < n_hi; ++y)
+                    {
+                        const int32_t lo = lo_c[x], hi = hi_c[y];
+                        if (lo >= hi) { gapped = true; continue; }
+                        // cheap first: b's first or last mismatch inside [lo, hi) settles it (nearly always, b being an unrelated
+                        // diagonal); only otherwise look at the words
+                        const int32_t bf = (int32_t)lead0_p[0], bl = (int32_t)M - 1 - (int32_t)tail0_p[0];
+                        bool any = (bf >= lo && bf < hi) || (tail0_p[0] < M && bl >= lo && bl < hi);
+                        if (!any)
+                        {
+                            #pragma unroll
+                            for (int k = 0; k < 6; ++k)
+                            {
+                                const int32_t a0 = lo - 32 * k > 0 ? lo - 32 * k : 0, a1 = hi - 32 * k < 32 ? hi - 32 * k : 32;
+                                if (a0 < a1)
+                                {
+                                    const uint32_t hi_m = (a1 >= 32) ? 0xFFFFFFFFu : ((1u << a1) - 1u);
+                                    const uint32_t lo_m = (1u << a0) - 1u;                                       // a0 < a1 <= 32 -> a0 <= 31
+                                    any = any || ((mmp[k] & hi_m & ~lo_m) != 0u);
+                                }
+                            }
+                        }
+                        if (!any) gapped = true;
+                    }
+            }
+            #pragma unroll
+            for (int k = 3; k > 0; --k) { lead0_p[k] = lead0_p[k - 1]; lead1_p[k] = lead1_p[k - 1]; tail0_p[k] = tail0_p[k - 1]; tail1_p[k] = tail1_p[k - 1]; }
+            lead0_p[0] = lead0; lead1_p[0] = lead1; tail0_p[0] = tail0; tail1_p[0] = tail1;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k) mmp[k] = mm[k];
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+            }
+            ql[6] >>= 1; qh[6] >>= 1;
+        }
+        settled = !gapped;
+    }
     if (settled)
     {
         scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
@@ -678,6 +808,8 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
     return ((int64_t)max_read_len + 32) * step <= 8000;
 }
 
+struct IsTwo { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 2u ? 1u : 0u; } };
+
 template <int TYPE, int RB>
 static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
@@ -692,18 +824,35 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+        const bool third = !getenv( "NVBIO_AMD_NO_THIRD_CHANCE" );
         void* aux = nullptr;
-        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (hipMallocAsync( &aux, flags_bytes + 2u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             set_error( "banded score: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
         uint8_t*  need_dp   = (uint8_t*)aux;
         uint32_t* job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
-        uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
-        void*     sel_temp  = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
-        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp );
-        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        uint32_t* list_t    = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
+        uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + 2u * list_bytes);
+        uint32_t* count_t   = job_count + 1;
+        void*     sel_temp  = (uint8_t*)aux + flags_bytes + 2u * list_bytes + 256u;
+        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,false>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+        hipError_t e = hipSuccess;
+        {
+            // the jobs a third chance can still settle (need_dp == 2), compacted, through their own launch: each ends as 0 or 1.
+            // (With NVBIO_AMD_NO_THIRD_CHANCE they are simply handed to the DP: a non-zero flag selects.)
+            if (third)
+            {
+                hipcub::TransformInputIterator<uint8_t, IsTwo, const uint8_t*> twos( (const uint8_t*)need_dp, IsTwo() );
+                e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, twos, list_t, count_t, (int)b.n, s );
+                if (e == hipSuccess)
+                    hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,true>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                        (const uint32_t*)list_t, (const uint32_t*)count_t );
+            }
+        }
+        if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
             hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
                                 (const uint32_t*)job_list, (const uint32_t*)job_count );
