@@ -91,6 +91,11 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
 // remaining symbol plus the SA lookup of a later locate).  Such a query reports its single hit as the TEXT
 // POSITION (ranges[i] = (pos, pos), direct[i] = 1) -- the position locate() would return for the final row;
 // a mismatch reports the empty range (1,0).  Needs the full SA and the text (handles built with sa_int = 1).
+#ifndef NVB_NT_TABLE
+#define NVB_NT_TABLE 1
+#endif
+constexpr bool NT_TABLE = NVB_NT_TABLE != 0;
+
 template <int BITS, bool COUNT, bool TABLE, bool DIRECT>
 __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev& q, const uint32_t flags, const bool tab, const bool verify,
                                           const uint32_t i, uint32_t& x_out, uint32_t& y_out, uint32_t& nblk_out, bool& is_pos_out)
@@ -126,7 +131,14 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
         }
         if (ok)
         {
-            const uint2 r = use_d ? f.dtab[key] : f.ktab[key];
+            // the table entry has no reuse: a non-temporal load keeps it from displacing the text and bwt_occ lines the caches can hold
+            uint2 r;
+            if (use_d && NT_TABLE)
+            {
+                const unsigned long long v = __builtin_nontemporal_load( (const unsigned long long*)f.dtab + key );
+                r = make_uint2( (uint32_t)v, (uint32_t)(v >> 32) );
+            }
+            else r = use_d ? f.dtab[key] : f.ktab[key];
             s = tk;
             if (use_d && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
             else { x = r.x; y = r.y; }
@@ -173,7 +185,7 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
         uint32_t p = tpos;
         if (!have_pos)
         {
-            const uint32_t sv = f.ssa[x];
+            const uint32_t sv = NT_TABLE ? __builtin_nontemporal_load( f.ssa + x ) : f.ssa[x];
             p = (sv == 0xFFFFFFFFu) ? f.length : sv;                  // row 0 is the empty suffix
         }
         const uint32_t r  = len - s;
