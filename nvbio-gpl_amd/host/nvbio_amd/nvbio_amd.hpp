@@ -155,6 +155,16 @@ inline void match(const fm_index& fmi, const string_set& patterns, nvbio_uint2* 
 { check( nvbio_fm_match( fmi.handle(), &patterns.c, 0u, ranges_dev, nullptr, stream ) ); }
 inline void match_reverse(const fm_index& fmi, const string_set& patterns, nvbio_uint2* ranges_dev, hipStream_t stream = 0)
 { check( nvbio_fm_match( fmi.handle(), &patterns.c, NVBIO_FM_SCAN_FORWARD, ranges_dev, nullptr, stream ) ); }
+// nvbio::hamming_backtrack over a batch with the reference benchmark's counting delegate (nvbio/fmindex/backtrack.h:51-157,
+// nvbio-test/fmindex_test.cu:720-800): counts_dev[i] = occurrences of pattern i within `mismatches` substitutions outside its
+// exactly matched last `seed` symbols.  reference_quirks: count as the reference's code does (see nvbio_amd.h).
+inline void hamming_backtrack(const fm_index& fmi, const string_set& patterns, uint32_t seed, uint32_t mismatches, uint32_t* counts_dev,
+                              uint32_t* n_ranges_dev = nullptr, nvbio_uint2* ranges_dev = nullptr, uint32_t max_ranges = 0,
+                              bool reference_quirks = false, hipStream_t stream = 0)
+{
+    check( nvbio_fm_hamming_backtrack( fmi.handle(), &patterns.c, seed, mismatches, reference_quirks ? NVBIO_BACKTRACK_REFERENCE_QUIRKS : 0u,
+                                       counts_dev, n_ranges_dev, ranges_dev, max_ranges, stream ) );
+}
 inline void locate(const fm_index& fmi, const uint32_t* rows_dev, uint32_t n, uint32_t* pos_dev, hipStream_t stream = 0)
 { check( nvbio_fm_locate( fmi.handle(), rows_dev, n, pos_dev, stream ) ); }
 inline void locate_ssa_iterator(const fm_index& fmi, const uint32_t* rows_dev, uint32_t n, nvbio_uint2* jt_dev, hipStream_t stream = 0)

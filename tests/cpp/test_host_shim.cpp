@@ -71,6 +71,24 @@ int main()
         for (uint64_t h = 0; h < total; ++h) REQUIRE( hits1[h].x == want_hits[2*h] && hits1[h].y == want_hits[2*h+1] );
     }
 
+    // approximate search (hamming_backtrack), default semantics, against the oracle
+    {
+        std::vector<uint8_t> stream( 64 + Q * L );
+        for (uint32_t k = 0; k < 64; ++k) stream[k] = rng() & 3;
+        for (uint32_t k = 0; k < Q * L; ++k) stream[64 + k] = qsyms[k];
+        std::vector<uint32_t> offs( Q + 1 );
+        for (uint32_t k = 0; k <= Q; ++k) offs[k] = 64 + k * L;
+        device_vector<uint8_t> d_stream( stream ); device_vector<uint32_t> d_offs( offs ), d_cnt( Q );
+        hamming_backtrack( fmi, string_set::concatenated( d_stream.data(), 8, d_offs.data(), Q ), L / 2, 1, d_cnt.data() );
+        std::vector<uint32_t> cnt = d_cnt.to_host();
+        for (uint32_t k = 0; k < Q; ++k)
+        {
+            uint32_t want = 0;
+            orc_hamming_backtrack( &oidx, stream.data(), offs[k], L, L / 2, 1, 0, &want, nullptr, 0 );
+            REQUIRE( cnt[k] == want );
+        }
+    }
+
     // banded Gotoh through BatchedBandedAlignmentScore, SimpleGotohScheme, all three types
     const uint32_t J = 3000, M = 100;
     std::vector<uint8_t> pats( J * M ); std::vector<uint32_t> poffs( J + 1 ), wb( J ), we( J );
