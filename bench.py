@@ -30,6 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
+TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
+SEED_KERNEL_TAG = "fm_seed_tiles_kernel<4>"
 
 
 def log(msg):
@@ -71,7 +74,21 @@ def pack4(sym_flat):
     return torch.cat([w.to(torch.int32), torch.zeros(4, dtype=torch.int32, device=sym_flat.device)])
 
 
-def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000):
+def plant_family(words, n, copies, device, seed, unit=300):
+    """overwrite `copies` random loci of the reference (16-symbol aligned) with one random `unit`-bp element: a repeat family.
+    Returns the loci (int64 tensor)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    uw = (unit + 15) // 16
+    elem = torch.randint(-2 ** 31, 2 ** 31 - 1, (uw,), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    slots = torch.randperm((n // 16 - uw - 8) // (2 * uw), device=device, generator=g)[:copies].to(torch.int64) * (2 * uw)   # disjoint word offsets
+    idx = (slots[:, None] + torch.arange(uw, device=device)[None, :]).view(-1)
+    words[idx] = elem.repeat(copies)
+    return slots * 16
+
+
+def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000, family=None):
     """150 bp reads drawn from the reference: 1 % substitutions, 0.1 %/base 1-3 bp indels,
     50 % reverse-complemented.  Returns (reads uint8 [R,M], truth pos, rc)."""
     import torch
@@ -81,6 +98,11 @@ def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000):
     for b in range(0, n_reads, chunk):
         r = min(chunk, n_reads - b)
         pos = torch.randint(0, n - M - 8, (r,), device=device, generator=g, dtype=torch.int64)
+        if family is not None:
+            # 5 % of the reads start inside a copy of the repeat family (300 bp element: offsets 0..149 keep the read inside it)
+            inside = torch.rand(r, device=device, generator=g) < 0.05
+            pick = family[torch.randint(0, family.numel(), (r,), device=device, generator=g)]
+            pos = torch.where(inside, pick + torch.randint(0, 150, (r,), device=device, generator=g), pos)
         j = torch.arange(M, device=device, dtype=torch.int64)[None, :]
         # indel: with probability 1-(1-0.001)^150 a read carries one indel of 1-3 bp
         has = torch.rand(r, device=device, generator=g) < (1.0 - (1.0 - 0.001) ** M)
@@ -130,6 +152,11 @@ def main():
                     help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--no-mapq", action="store_true", help="leave nvBowtie's second-best bookkeeping and the mapping quality out of the step")
     ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
+    ap.add_argument("--with-traceback", action="store_true", help="put the traceback of every aligned read's best alignment (CIGARs) inside the timed step")
+    ap.add_argument("--build-breakdown", action="store_true", help="build the index once more without tables to report index_build_s and table_build_s separately")
+    ap.add_argument("--max-seed-hits", type=int, default=0, help="extend at most this many SA rows of a seed's range (0: all; needed with --repeat-family)")
+    ap.add_argument("--repeat-family", type=int, default=0, metavar="COPIES",
+                    help="plant COPIES copies of a random 300 bp element in the reference (and draw 5 %% of the reads from them): a repeat-rich workload")
     args = ap.parse_args()
 
     import numpy as np
@@ -159,8 +186,21 @@ def main():
     M = args.read_len
     t0 = time.time()
     genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
+    family = None
+    if args.repeat_family:
+        family = plant_family(genome, n, args.repeat_family, device, seed=4321)
     torch.cuda.synchronize()
     t1 = time.time()
+    # the suffix sort / BWT / SA alone (no tables), timed on its own so that the table build can be reported separately
+    index_only_s = None
+    if args.build_breakdown:
+        tb0 = time.time()
+        tmp = amd.FMIndex.build(genome, n, kmer_len=0, sa_int=args.sa_int)
+        torch.cuda.synchronize()
+        index_only_s = time.time() - tb0
+        tmp.close(); del tmp
+        torch.cuda.empty_cache()
+        t1 = time.time()
     try:
         fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
     except amd.NvbioError as e:
@@ -175,13 +215,15 @@ def main():
     t2 = time.time()
     log("reference %d symbols generated in %.2fs, index built on the GPU in %.2fs (k-mer table k=%d, %.2f GB owned)"
         % (n, t1 - t0, t2 - t1, args.kmer, fmi.device_bytes() / 1e9))
-    reads_sym, truth_pos, truth_rc = make_reads(genome, n, R, M, device, seed=1000 + rank)
+    build_s = t2 - t1
+    reads_sym, truth_pos, truth_rc = make_reads(genome, n, R, M, device, seed=1000 + rank, family=family)
     reads4 = pack4(reads_sym.view(-1))
     torch.cuda.synchronize()
     log("%d reads x %d bp per rank generated in %.2fs" % (R, M, time.time() - t2))
     batch = pipeline.ReadBatch(reads4, R, M)
     params = pipeline.SeedExtendParams.end_to_end() if args.mode == "e2e" else pipeline.SeedExtendParams()
     params.direct = not args.no_direct
+    params.max_seed_hits = args.max_seed_hits or None
     params.fused_seed_pass = not args.no_fused_seeds
     params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c
@@ -195,7 +237,11 @@ def main():
     extras = {}
 
     def step(timers=None):
-        bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras)
+        if args.with_traceback:
+            bs, bp, brc, nc, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, return_windows=True)
+            extras["traceback"] = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=TB_STRIDE, timers=timers, best_pos=bp)
+        else:
+            bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras)
         if gatherer is not None:
             gatherer.submit(sharding.pack_result64(bs, bp, brc))
         return bs, bp, brc, nc
@@ -236,7 +282,7 @@ def main():
         tms = []
         for _ in range(3):
             tt = {}
-            ids, tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=16, timers=tt, best_pos=bp)
+            ids, tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=TB_STRIDE, timers=tt, best_pos=bp)
             torch.cuda.synchronize()
             tms.append(event_ms(tt["traceback"])[0])
         tb_ms = float(np.median(tms))
@@ -248,27 +294,48 @@ def main():
                    "reads": int(ids.numel()), "ms": tb_ms, "reads_per_s": ids.numel() / (tb_ms * 1e-3),
                    "gapped_fraction": float((lens_i > 1).float().mean()),
                    "scores_equal_scoring_pass": bool(torch.equal(tsc, bs[ids])),
-                   "mean_cigar_elements": float(lens_i.float().mean()), "max_cigar_elements": int(lens_i.max())}
+                   "mean_cigar_elements": float(lens_i.float().mean()), "max_cigar_elements": int(lens_i.max()),
+                   "cigar_stride": TB_STRIDE, "cigars_truncated": int((lens_i > TB_STRIDE).sum())}
         del bwb, ids, tsc, tpos, tsrc, tsnk, tcig, tln
 
-    # ---- stage times and the roofline of the dominant HBM kernel (the seed pass match kernel) --
+    # ---- stage times and the roofline of the dominant HBM kernel (the seed pass) --------------------------------
     stage_ms = {k: float(np.mean(event_ms(v))) for k, v in timers.items()}
     spr = (M - params.seed_len) // params.interval_for(M) + 1
     n_seeds = R * spr
-    # algorithmic bytes of one match launch: 32 B x distinct bwt_occ records the reference's
-    # backward search touches (counted by the kernel's NO_KMER_TABLE accounting mode, outside the
-    # timed region) + 11 B of query symbols (22 x 4 bit) + 8 B of result per query
     qs = amd.PackedStringSet(reads4, 4, n_seeds, fixed_len=params.seed_len, stride=M, device=device, seeds_per_string=spr,
                              seed_interval=params.interval_for(M))
+    strands = ((0, 0), (1, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT))
+    use_direct = bool(params.direct and fmi.supports_direct())
+    use_fused = bool(use_direct and params.fused_seed_pass)
+    # (1) bytes the TIMED launch has to move, at the 64-byte sector granularity of the fabric (outside the timed region, by the
+    #     kernel's accounting instantiation, NVBIO_FM_COUNT_SECTORS): every gather of a search -- direct-table entry, group of a
+    #     2..7-occurrence k-mer, bwt_occ records of the rank steps that are left, SA word, text words -- counted as one sector
+    #     per distinct 64 bytes, plus what the launch streams: the packed reads once, the tiles' keys and counts written, then
+    #     read and written again by the compaction, the residual list.
+    launch_bytes = sectors = None
+    if use_fused:
+        acc = []
+        for strand, flags in strands:
+            bufs = fmi.match_seed_diagonals(qs, flags | amd.FM_COUNT_SECTORS, M, strand)
+            c = bufs["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            n_tiles = -(-R // (64 // spr if spr <= 64 else 1))
+            sect = int(c[2] | (c[3] << 32))
+            streamed = R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1])
+            acc.append((sect, streamed))
+            del bufs
+        sectors = float(np.mean([a_[0] for a_ in acc]))
+        launch_bytes = sectors * SECTOR + float(np.mean([a_[1] for a_ in acc]))
+    # (2) algorithmic bytes of the REFERENCE's algorithm for the same launch: 32 B x distinct bwt_occ records its
+    #     backward search touches (counted by the match kernel's NO_KMER_TABLE accounting mode) + 11 B of query symbols
+    #     (22 x 4 bit) + 8 B of result per query -- and the time of that algorithm's own kernel (no table, every symbol stepped)
     blocks = 0
-    for flags in (0, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT):
+    for _, flags in strands:
         _, blk = fmi.match(qs, flags | amd.FM_NO_KMER_TABLE, want_blocks=True)
         blocks += int((blk.to(torch.int64) & 0xFFFFFFFF).sum())
+        del blk
     alg_bytes_per_launch = (blocks * 32 + 2 * n_seeds * (11 + 8)) / 2.0
-    # the same launch through the reference's own algorithm (every symbol stepped through rank(), no
-    # k-mer table), timed outside the timed region: what the kernel achieves without the table
     nt = []
-    for flags in (0, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT):
+    for _, flags in strands:
         a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a_ev.record()
         fmi.match(qs, flags | amd.FM_NO_KMER_TABLE)
@@ -284,13 +351,13 @@ def main():
     if not args.no_plain_ab:
         prev_direct = params.direct
         params.direct = False
-        os.environ["NVBIO_AMD_NO_UNGAPPED_SCORE"] = "1"
+        params.algo_flags = amd.ALN_NO_UNGAPPED_SCORE                                  # nvbio_alignment_batch::algo_flags: DP for every candidate
         pipeline.seed_and_extend(fmi, genome, n, batch, params, None)                 # warm
         pt = {}
         torch.cuda.synchronize(); p0 = time.perf_counter()
         pbs, pbp, pbrc, pnc = pipeline.seed_and_extend(fmi, genome, n, batch, params, pt)
         torch.cuda.synchronize(); pdt = time.perf_counter() - p0
-        del os.environ["NVBIO_AMD_NO_UNGAPPED_SCORE"]
+        params.algo_flags = 0
         params.direct = prev_direct
         pst = {k: float(np.mean(event_ms(v))) for k, v in pt.items()}
         plain = {"ms_per_step": pdt * 1e3, "match_ms_per_launch": 0.5 * (pst.get("match_fw", 0.0) + pst.get("match_rc", 0.0)),
@@ -299,58 +366,97 @@ def main():
                  "kmer_table": (args.kmer - 1) if (fmi.supports_direct() and args.kmer >= 2) else args.kmer,   # the handle's plain table
                  "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
     match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
-    achieved = alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
-    use_direct = bool(params.direct and fmi.supports_direct())
-    use_fused = bool(use_direct and params.fused_seed_pass)
-    traffic = None
+    if launch_bytes is None:                    # the separate operators: what their match kernel moves is not accounted; use the reference's bytes
+        launch_bytes = alg_bytes_per_launch
+    achieved = launch_bytes / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+    traffic = traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if (tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer and tj.get("sa_int", 16) == args.sa_int
-                    and bool(tj.get("direct", False)) == use_direct and bool(tj.get("fused", False)) == use_fused):
+                    and bool(tj.get("direct", False)) == use_direct and bool(tj.get("fused", False)) == use_fused
+                    and tj.get("kernel_tag") == SEED_KERNEL_TAG):
                 traffic = tj.get("match_hbm_bytes_per_launch")
+                traffic_src = ("profiles/traffic.json (tag %s): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this configuration, "
+                               "not measured in this run" % tj.get("tag"))
         except Exception:
             traffic = None
+    # the measured ceiling for this access pattern: a chain of two dependent random 8-byte gathers over 128 GiB
+    # (scripts/ubench/gather_rate.hip, profiles/r02_gather_rate.jsonl)
+    ceiling = None
+    gpath = os.path.join(ROOT, "profiles", "r02_gather_rate.jsonl")
+    if os.path.exists(gpath):
+        for line in open(gpath):
+            try:
+                gj = json.loads(line)
+            except Exception:
+                continue
+            if gj.get("footprint_bytes") == 128 << 30 and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
+                ceiling = gj.get("G_gathers_per_s")
     cells = float(nc) * params.band * M
     extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0)
+    step_ms = elapsed / args.steps * 1e3
+    build = {"index_and_tables_s": build_s}
+    if index_only_s is not None:
+        build.update(index_build_s=index_only_s, table_build_s=max(build_s - index_only_s, 0.0))
+    build["break_even_reads"] = int(build_s / (step_ms * 1e-3) * R)      # reads mapped in the time the index took to build
 
     result = {
         "metric": "aligned reads/sec (150 bp single-end, 3 Gbp ref); GCUPS of the banded extend pass in `extend`",
         "value": world * R * args.steps / elapsed,
         "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32/i32", "data": "synthetic",
-        "config": {"workload": "nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150) else "custom",
+        "dtype": "u32 (FM-index coordinates) / i16x2 (band-31 DP, two alignments per 32-bit lane; exact, bound-checked on the host)",
+        "data": "synthetic",
+        "config": {"workload": ("nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150 and not args.repeat_family) else "custom"),
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
                    "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
                                  if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
-                   "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world},
+                   "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world,
+                   "traceback_in_step": bool(args.with_traceback), "repeat_family_copies": args.repeat_family,
+                   "max_seed_hits": params.max_seed_hits},
+        "left_out_of_the_step": {"note": "the timed step re-runs one HBM-resident batch: no H2D/D2H, no index build"
+                                         + ("" if args.with_traceback else ", no traceback (see `traceback`; --with-traceback puts it inside)"),
+                                 "build": build},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
-        "roofline": {"kernel": (("fm_seed_diagonals_kernel<4> (seed pass, one strand of %d seeds per launch: match, and for every seed that ends "
-                                 "on one SA row also scan + locate + diagonal key + adjacent dedupe, in one kernel)" % n_seeds) if use_fused else
+        "roofline": {"kernel": (("seed pass launch of one strand, %d seeds: %s (match + locate + diagonal key + adjacent dedupe of every seed, one wave per "
+                                 "tile of whole reads) followed by the tile-count scan and fm_seed_compact_kernel (a few %% of the launch)" % (n_seeds, SEED_KERNEL_TAG)) if use_fused else
                                 ("fm_match_kernel<4,false,true,%s> (seed pass, one strand of %d seeds per launch%s)"
                                  % ("true" if use_direct else "false", n_seeds,
                                     "; single-row searches finish on the text and return positions: match + locate fused" if use_direct else ""))),
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "bytes": ("bytes the timed launch has to move at 64-byte sector granularity (counted by the kernel's accounting instantiation, outside "
+                               "the timed region): gathered sectors x 64 + packed reads + keys / counts written and compacted"),
+                     "bytes_per_launch": launch_bytes, "gathered_sectors_per_launch": sectors, "ms_per_launch": match_ms,
+                     "sectors_per_seed": (sectors / n_seeds) if sectors else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,
-                     "algorithmic_bytes_per_launch": alg_bytes_per_launch, "ms_per_launch": match_ms,
                      "queries_per_s": n_seeds / (match_ms * 1e-3) if match_ms > 0 else 0.0,
-                     "without_kmer_table": {"ms_per_launch": no_table_ms,
-                                            "achieved": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9,
-                                            "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                     "gather_rate_G_per_s": (sectors / (match_ms * 1e-3) / 1e9) if (sectors and match_ms > 0) else None,
+                     "gather_ceiling_G_per_s": ceiling,
+                     "frac_of_gather_ceiling": (sectors / (match_ms * 1e-3) / 1e9 / ceiling) if (sectors and ceiling and match_ms > 0) else None,
+                     # not a roofline fraction: how the timed launch compares with the reference's algorithm running at the HBM peak
+                     "vs_reference_algorithm_at_peak": (alg_bytes_per_launch / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if match_ms > 0 else None,
+                     "reference_algorithm": {"kernel": "fm_match_kernel<4,false,false,false>: match() as the reference runs it, one rank step per symbol, no table",
+                                             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "ms_per_launch": no_table_ms,
+                                             "achieved": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9,
+                                             "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "extend": {"kernel": ("ungapped_e2e31_kernel<4> (31 diagonals by XOR + popcount on bit planes; settles every candidate whose best diagonal "
                               "beats any gapped alignment) + banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4> over the rest (two alignments per lane, "
-                              "int16 packed); gcups = cells of the full band DP / time, i.e. effective") if args.mode == "e2e" else
+                              "int16 packed)") if args.mode == "e2e" else
                              "banded_gotoh_band31_pk_kernel<LOCAL,4> (two alignments per lane, int16 packed)",
                    "bound": "valu (integer; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
-                   "gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
+                   # GCUPS of the DP kernel itself: the A/B run below, where the DP computes every cell of every candidate
+                   "gcups": plain.get("extend_gcups") if plain else None,
+                   # cells of the full band DP / time of the step's extension stage, in which the exact shortcuts settle most candidates
+                   "effective_gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
         "traceback": tb_info,
         "mapq": ({"evaluator": "BowtieMapq2 over (best, second best) of nvBowtie's score_reduce; inside the timed step (stage_ms.mapq)",
                   "second_alignment_fraction": float((extras["second"] != 0).float().mean()),

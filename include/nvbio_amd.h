@@ -88,8 +88,11 @@ typedef struct nvbio_fm_index_s* nvbio_fm_index_t;     /* opaque handle */
  * identical with and without it.  kmer_len = 0 disables it; values up to 17 are accepted
  * (k = 12: 128 MiB, k = 14: 2 GiB, k = 16: 32 GiB, k = 17: 128 GiB -- sized for 288 GB of HBM).
  * A handle that also holds the full suffix array and the text (nvbio_fm_index_build with sa_int = 1) keeps the last TWO
- * levels of the table: level kmer_len - 1 as the table of match(), and level kmer_len with every one-row entry rewritten to
- * that row's text position as the table of the direct seed pass (nvbio_fm_match_direct, nvbio_fm_match_seed_diagonals).
+ * levels of the table: level kmer_len - 1 as the table of match(), and level kmer_len as the table of the direct seed pass
+ * (nvbio_fm_match_direct, nvbio_fm_match_seed_diagonals): the entry of a k-mer with ONE occurrence rewritten to that
+ * occurrence's text position and the 15 text symbols to its left, that of a k-mer with 2..7 occurrences pointing to a
+ * 32/64-byte group with the same for each of them -- a 22-mer seed of a 3 Gbp genome is then matched AND located by the
+ * table gather alone (texts up to 3.22 G symbols; longer ones keep positions without the context).
  * Replaces: constructing nvbio::fm_index / io::FMIndexDataDevice (nvbio/io/fmindex/fmindex_impl.cu:740-816). */
 nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, uint32_t kmer_len,
                                    void* stream, nvbio_fm_index_t* out);
@@ -110,7 +113,19 @@ typedef struct
                             match() can finish a search whose range has collapsed to ONE row by comparing the
                             rest of the pattern with the text at SA[row] and jumping to ISA[position] (3 gathers
                             instead of one per remaining symbol).  Requires sa_int = 1.  Results are identical. */
+    uint32_t table_flags;     /* NVBIO_FM_TABLE_*: which form of the k-mer tables a direct-capable handle keeps (A/B measurements and
+                                 tests; results are identical with every combination)                                              */
+    uint32_t bucket_symbols;  /* suffix sort: 0 = choose the number of prefix symbols used for bucketing from the text length;
+                                 1 + v forces v in 0..4 (tests run the bucketed path on small texts this way)                      */
 } nvbio_fm_build_options;
+
+enum
+{
+    NVBIO_FM_TABLE_NO_DIRECT  = 1,  /* keep the plain SA-range table only, even if the handle holds the full SA and the text      */
+    NVBIO_FM_TABLE_NO_CONTEXT = 2,  /* direct table, format 1: one-row entries hold the position only (the rest of a seed is then
+                                       verified with a gather from the text)                                                      */
+    NVBIO_FM_TABLE_NO_GROUPS  = 4   /* no groups for k-mers with 2..7 occurrences (they keep their SA range and take rank steps)  */
+};
 
 nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
                                   const nvbio_fm_build_options* options /* NULL = defaults */,
@@ -167,7 +182,8 @@ enum
     NVBIO_FM_COMPLEMENT   = 2,   /* search the complement (c < 4 ? 3-c : c), as nvBowtie's rc seeds
                                     (mapping_inl.h:264-279)                                                   */
     NVBIO_FM_NO_KMER_TABLE = 4,  /* step every symbol through rank() even if the handle has a table         */
-    NVBIO_FM_NO_VERIFY     = 8   /* never take the SA/ISA verification shortcut even if the handle has it   */
+    NVBIO_FM_NO_VERIFY     = 8,  /* never take the SA/ISA verification shortcut even if the handle has it   */
+    NVBIO_FM_COUNT_SECTORS = 16  /* nvbio_fm_match_seed_diagonals only: an accounting launch (see there)        */
 };
 
 /* ranges_dev[i] = SA range (inclusive; empty iff x > y) of query i: nvbio::match / match_reverse
@@ -241,18 +257,28 @@ enum { NVBIO_BACKTRACK_REFERENCE_QUIRKS = 1 };
 nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_string_set* queries, uint32_t seed_len, uint32_t mismatches, uint32_t flags,
                                         uint32_t* counts_dev, uint32_t* n_ranges_dev, nvbio_uint2* ranges_dev, uint32_t max_ranges, void* stream);
 
-/* The whole seed pass of one strand in one kernel, for handles that hold the full suffix array and the text: nvBowtie's
+/* The whole seed pass of one strand, for handles that hold the full suffix array and the text: nvBowtie's
  * match_range over every seed (mapping_inl.h:73-86,193-282) followed, for every seed that ends on ONE SA row, by what
  * FMIndexFilter::rank's scan, FMIndexFilter::locate (filter_inl.h:193-252), hit_to_diagonal (examples/fmmap/fmmap.cu:92-117)
  * and the removal of adjacent duplicate diagonals would do with it: the hit's diagonal key goes straight to keys_dev
- * (as nvbio_fm_filter_locate_diagonals writes it; seed order inside a block of 256 seeds, blocks in arbitrary order; a key
- * equal to the previous key of its block is dropped).  Seeds that end on several rows go to the residual list
- * (residual_ranges_dev[r], residual_ids_dev[r] = seed id) for nvbio_fm_filter_scan + nvbio_fm_filter_locate_diagonals.
- * Capacities: seeds->n entries each.  counts_dev[0] = keys written, counts_dev[1] = residual seeds (zeroed by the call).
- * The multiset of keys equals that of the plain operators up to duplicates. */
+ * (as nvbio_fm_filter_locate_diagonals writes it), IN SEED ORDER; a key equal to the previous key of the same read is
+ * dropped (consecutive seeds of a read that agree on the diagonal).  Seeds that end on several rows go to the residual list
+ * (residual_ranges_dev[r], residual_ids_dev[r] = seed id, in arbitrary order) for nvbio_fm_filter_scan +
+ * nvbio_fm_filter_locate_diagonals.  Capacities: seeds->n entries each.  counts_dev[0] = keys written, counts_dev[1] =
+ * residual seeds (zeroed by the call).  The set of keys equals that of the plain operators over the same seeds.
+ * seeds->n must be a whole number of strings (n = strings x seeds_per_string).
+ * flags: NVBIO_FM_SCAN_FORWARD / NVBIO_FM_COMPLEMENT / NVBIO_FM_NO_KMER_TABLE as nvbio_fm_match; bits 16..31, if non-zero, cap
+ * the launch at that many x 64 workgroups (a tuning / testing knob: results do not depend on it).
+ * NVBIO_FM_COUNT_SECTORS: same results, and counts_dev (then 4 words, 8-byte aligned) also receives, as a uint64 in words
+ * 2..3, the number of distinct 64-byte sectors the searches gathered from the index arrays (table entry, group, bwt_occ
+ * records, SA word, text words): the unit in which the pass's memory traffic is accounted (a slower kernel instantiation,
+ * for measurement harnesses).
+ * temp_dev / temp_bytes: optional caller scratch (nvbio_fm_match_seed_diagonals_temp_bytes); if NULL the library allocates and
+ * frees stream-ordered scratch itself. */
+nvbio_status nvbio_fm_match_seed_diagonals_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes);
 nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                            uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
-                                           uint32_t* counts_dev, void* stream);
+                                           uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes, void* stream);
 
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)
@@ -347,9 +373,23 @@ typedef struct
     const uint32_t* win_end_dev;       /* n entries: window end (exclusive)                                 */
     uint32_t        n;
     uint32_t        max_read_len;      /* the stream's max_pattern_length() (batched.h stream concept), or 0 if
-                                          unknown.  A hint only: it lets the library pick 16-bit packed kernels
-                                          when every score provably fits; results do not depend on it.       */
+                                          unknown.  It lets the library pick 16-bit packed kernels when every
+                                          score provably fits: a job whose pattern is LONGER than a non-zero
+                                          max_read_len is rejected (score NVBIO_SCORE_MIN, sink (-1,-1)) rather
+                                          than scored in registers that could wrap.                          */
+    uint32_t        algo_flags;        /* NVBIO_ALN_*: which of the library's exact shortcuts / kernel variants a
+                                          call may use (0 = all; A/B measurements and tests -- results are
+                                          identical with every combination)                                  */
 } nvbio_alignment_batch;
+
+enum
+{
+    NVBIO_ALN_NO_UNGAPPED_SCORE     = 1,   /* every job through the DP (no ungapped end-to-end shortcut, banded and full matrix) */
+    NVBIO_ALN_NO_THIRD_CHANCE       = 2,   /* three-mismatch jobs go to the DP                                                  */
+    NVBIO_ALN_NO_PACKED_DP          = 4,   /* int32 kernels only                                                                */
+    NVBIO_ALN_FORCE_PACKED_DP       = 8,   /* packed full-matrix kernel also for small batches                                  */
+    NVBIO_ALN_NO_UNGAPPED_TRACEBACK = 16   /* every traceback through the direction-vector DP                                   */
+};
 
 enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };
 

@@ -27,9 +27,13 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
-FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY = 1, 2, 4, 8
+FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS = 1, 2, 4, 8, 16
+FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS = 1, 2, 4      # nvbio_fm_build_options::table_flags
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
+# nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)
+ALN_NO_UNGAPPED_SCORE, ALN_NO_THIRD_CHANCE, ALN_NO_PACKED_DP, ALN_FORCE_PACKED_DP, ALN_NO_UNGAPPED_TRACEBACK = 1, 2, 4, 8, 16
+DEFAULT_ALGO_FLAGS = 0          # what an AlignmentBatch is created with unless told otherwise (tests set it for a whole run)
 BACKTRACK_REFERENCE_QUIRKS = 1
 
 _STATUS = {0: "OK", 1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "UNSUPPORTED", 5: "NO_DEVICE"}
@@ -50,7 +54,7 @@ class _View(ctypes.Structure):
 
 class _BuildOptions(ctypes.Structure):
     _fields_ = [("kmer_len", ctypes.c_uint32), ("sa_int", ctypes.c_uint32), ("max_lcp", ctypes.c_uint32),
-                ("verify", ctypes.c_uint32)]
+                ("verify", ctypes.c_uint32), ("table_flags", ctypes.c_uint32), ("bucket_symbols", ctypes.c_uint32)]
 
 
 class _StringSet(ctypes.Structure):
@@ -77,7 +81,7 @@ class _Batch(ctypes.Structure):
                 ("read_id_dev", ctypes.c_void_p), ("flags_dev", ctypes.c_void_p),
                 ("text_dev", ctypes.c_void_p), ("text_bits", ctypes.c_uint32),
                 ("win_begin_dev", ctypes.c_void_p), ("win_end_dev", ctypes.c_void_p), ("n", ctypes.c_uint32),
-                ("max_read_len", ctypes.c_uint32)]
+                ("max_read_len", ctypes.c_uint32), ("algo_flags", ctypes.c_uint32)]
 
 
 _lib = None
@@ -220,12 +224,16 @@ class FMIndex:
         return cls(h, device, keep=(b, s))
 
     @classmethod
-    def build(cls, text2, length, kmer_len=0, max_lcp=0, sa_int=16, verify=False, device="cuda:0"):
-        """build the index on the GPU from a 2-bit packed text (nvbio_fm_index_build)"""
+    def build(cls, text2, length, kmer_len=0, max_lcp=0, sa_int=16, verify=False, device="cuda:0", table_flags=0,
+              bucket_symbols=None):
+        """build the index on the GPU from a 2-bit packed text (nvbio_fm_index_build).
+        table_flags: FM_TABLE_* (which form of the k-mer tables a direct-capable handle keeps; results do not depend on it);
+        bucket_symbols: None = automatic, 0..4 forces that many prefix symbols in the suffix sort's bucketing (tests)"""
         torch = _torch()
         t = _dev_tensor(text2, torch.int32, device)
         h = ctypes.c_void_p()
-        opts = _BuildOptions(kmer_len, sa_int, max_lcp, 1 if verify else 0)
+        opts = _BuildOptions(kmer_len, sa_int, max_lcp, 1 if verify else 0, int(table_flags),
+                             0 if bucket_symbols is None else 1 + int(bucket_symbols))
         _check(lib().nvbio_fm_index_build(_ptr(t), ctypes.c_uint32(length), cls._dev_index(device),
                                           ctypes.byref(opts), _stream_ptr(device), ctypes.byref(h)))
         return cls(h, device, keep=(t,))
@@ -323,24 +331,33 @@ class FMIndex:
                                                 ctypes.c_uint32(max_ranges), _stream_ptr(self.device)))
         return counts, nr, rg
 
-    def match_seed_diagonals(self, seeds, flags, read_len, strand, buffers=None):
-        """the seed pass of one strand straight to candidate diagonals (nvbio_fm_match_seed_diagonals) ->
-        (keys int64 [n_keys], residual_ranges int32 [n_res, 2], residual_ids int32 [n_res]); one host read of the two counts.
-        buffers: optional dict reused across calls (the three n-entry output arrays)"""
+    def match_seed_diagonals(self, seeds, flags, read_len, strand, buffers=None, grid_blocks=0):
+        """the seed pass of one strand straight to candidate diagonals (nvbio_fm_match_seed_diagonals) -> the buffers dict:
+        "keys" int64 (the first counts[0] are valid, in seed order), "ranges" int32 [., 2] and "ids" int32 (the first counts[1]:
+        the residual seeds on several SA rows), "counts" int32 [2] (on the device: the caller reads them).
+        buffers: optional dict reused across calls (the output arrays and the call's scratch);
+        grid_blocks: cap of the launch in workgroups, a multiple of 64 (0 = the library's choice; results do not depend on it)"""
         torch = _torch()
         n = seeds.n
         if buffers is None:
             buffers = {}
-        if buffers.get("n") != n:
-            buffers["n"] = n
+        qs = seeds.c_struct()
+        if buffers.get("n") != n or buffers.get("spr") != seeds.seeds_per_string:
+            buffers["n"], buffers["spr"] = n, seeds.seeds_per_string
+            # keys: only as many as there can be candidates are ever written; sized for the worst case like the residual arrays
             buffers["keys"] = torch.empty(n, dtype=torch.int64, device=self.device)
             buffers["ranges"] = torch.empty((n, 2), dtype=torch.int32, device=self.device)
             buffers["ids"] = torch.empty(n, dtype=torch.int32, device=self.device)
-            buffers["counts"] = torch.empty(2, dtype=torch.int32, device=self.device)
-        qs = seeds.c_struct()
-        _check(lib().nvbio_fm_match_seed_diagonals(self._h, ctypes.byref(qs), ctypes.c_uint32(flags), ctypes.c_uint32(read_len),
-                                                   ctypes.c_uint32(strand), _ptr(buffers["keys"]), _ptr(buffers["ranges"]),
-                                                   _ptr(buffers["ids"]), _ptr(buffers["counts"]), _stream_ptr(self.device)))
+            buffers["counts"] = torch.empty(4, dtype=torch.int32, device=self.device)     # [2:4]: FM_COUNT_SECTORS' uint64
+            nb = ctypes.c_uint64(0)
+            _check(lib().nvbio_fm_match_seed_diagonals_temp_bytes(ctypes.byref(qs), ctypes.byref(nb)))
+            buffers["temp"] = torch.empty(nb.value, dtype=torch.uint8, device=self.device)
+        assert grid_blocks % 64 == 0 and grid_blocks < (1 << 22)
+        _check(lib().nvbio_fm_match_seed_diagonals(self._h, ctypes.byref(qs), ctypes.c_uint32(flags | ((grid_blocks // 64) << 16)),
+                                                   ctypes.c_uint32(read_len), ctypes.c_uint32(strand), _ptr(buffers["keys"]),
+                                                   _ptr(buffers["ranges"]), _ptr(buffers["ids"]), _ptr(buffers["counts"]),
+                                                   _ptr(buffers["temp"]), ctypes.c_uint64(buffers["temp"].numel()),
+                                                   _stream_ptr(self.device)))
         return buffers
 
     def rank(self, rows, syms):
@@ -531,9 +548,10 @@ class AlignmentBatch:
     """The flattened stream of alignment jobs (see nvbio_alignment_batch)."""
 
     def __init__(self, reads, read_bits, read_offsets, text, text_bits, win_begin, win_end, quals=None, read_id=None,
-                 flags=None, device="cuda:0", max_read_len=0):
+                 flags=None, device="cuda:0", max_read_len=0, algo_flags=None):
         torch = _torch()
         self.device = device
+        self.algo_flags = DEFAULT_ALGO_FLAGS if algo_flags is None else int(algo_flags)
         self.read_bits, self.text_bits = int(read_bits), int(text_bits)
         self.reads = _dev_tensor(reads, torch.uint8 if read_bits == 8 else torch.int32, device)
         self.read_offsets = _dev_tensor(read_offsets, torch.int32, device)
@@ -552,7 +570,7 @@ class AlignmentBatch:
     def c_struct(self):
         return _Batch(_ptr(self.reads), self.read_bits, _ptr(self.read_offsets), _ptr(self.quals), _ptr(self.read_id),
                       _ptr(self.flags), _ptr(self.text), self.text_bits, _ptr(self.win_begin), _ptr(self.win_end),
-                      self.n, self.max_read_len)
+                      self.n, self.max_read_len, self.algo_flags)
 
 
 class BatchedBandedAlignmentScore:

@@ -28,7 +28,7 @@
 namespace nvbio_amd {
 
 nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out,
-                            uint32_t* isa, uint32_t* text);
+                            uint32_t* isa, uint32_t* text, uint32_t table_flags);
 
 namespace {
 
@@ -322,7 +322,8 @@ static nvbio_status sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* 
 }
 
 static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, const int device, const uint32_t kmer_len,
-                               const uint32_t sa_int, uint32_t max_lcp, const bool verify, hipStream_t s, nvbio_fm_index_t* out)
+                               const uint32_t sa_int, uint32_t max_lcp, const bool verify, const uint32_t table_flags, const uint32_t bucket_symbols,
+                               hipStream_t s, nvbio_fm_index_t* out)
 {
     Scratch scratch;
     if (max_lcp == 0) max_lcp = 4096;
@@ -334,11 +335,7 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     // ---- 1. bucketed sort of (32-mer key, position) ------------------------------------------
     uint32_t bsym = 0;                                          // symbols used for bucketing (<= 4 -> <= 256 buckets)
     while (bsym < 4 && ((uint64_t)n >> (2 * bsym)) > (1ull << 28)) ++bsym;
-    if (const char* e = getenv( "NVBIO_AMD_BUILD_BUCKET_SYMBOLS" ))       // test hook: force the bucketed path on small texts
-    {
-        const int v = atoi( e );
-        if (v >= 0 && v <= 4) bsym = (uint32_t)v;
-    }
+    if (bucket_symbols) bsym = bucket_symbols - 1u;              // nvbio_fm_build_options::bucket_symbols: force the bucketed path on small texts (tests)
     const uint32_t n_buckets = 1u << (2 * bsym);
     const uint32_t bshift    = 64u - 2u * bsym;
 
@@ -523,7 +520,7 @@ static nvbio_status build_impl(const uint32_t* text2_dev, const uint32_t n, cons
     scratch.forget( bwt_occ ); scratch.forget( ssa );           // ownership moves to the handle
     if (isa) scratch.forget( isa );
     if (text_copy) scratch.forget( text_copy );
-    return fm_index_adopt( &view, device, kmer_len, true, s, out, isa, text_copy );
+    return fm_index_adopt( &view, device, kmer_len, true, s, out, isa, text_copy, table_flags );
 }
 
 // BWT words (plain, 16 symbols per word) <-> the BWT half of the interleaved 32-byte records
@@ -615,7 +612,7 @@ static nvbio_status load_impl(const char* bwt_path, const char* sa_path, const i
         view.ssa_dev = ssa; view.ssa_words = sa_size; view.sa_int = K;
     }
     scratch.forget( bwt_occ ); if (ssa) scratch.forget( ssa );
-    return fm_index_adopt( &view, device, kmer_len, true, s, out, nullptr, nullptr );
+    return fm_index_adopt( &view, device, kmer_len, true, s, out, nullptr, nullptr, 0u );
 }
 
 static nvbio_status save_impl(const nvbio_fm_index_view& v, const char* bwt_path, const char* sa_path, hipStream_t s)
@@ -690,6 +687,7 @@ extern "C" nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t
     NVB_REQUIRE( sa_int <= 64 && (sa_int & (sa_int - 1u)) == 0, "sa_int must be a power of two in [1,64]" );
     const bool verify = options && options->verify;
     NVB_REQUIRE( !verify || sa_int == 1, "verify needs the full suffix array (sa_int = 1)" );
+    NVB_REQUIRE( !options || options->bucket_symbols <= 5u, "bucket_symbols must be 0 (automatic) or 1 + a value in 0..4" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    return build_impl( text2_dev, length, device, kmer_len, sa_int, max_lcp, verify, (hipStream_t)stream, out );
+    return build_impl( text2_dev, length, device, kmer_len, sa_int, max_lcp, verify, options ? options->table_flags : 0u, options ? options->bucket_symbols : 0u, (hipStream_t)stream, out );
 }

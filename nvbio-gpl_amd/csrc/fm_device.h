@@ -27,8 +27,11 @@ struct DevIndex
     const uint2*    ktab;     // optional: SA range of every kmer-mer (in scan order), or NULL
     uint32_t        kmer;
     const uint2*    dtab;     // optional (full SA + text): the table of the direct seed pass, one symbol longer than ktab (dkmer = kmer + 1):
-                              // SA range of every dkmer-mer, a ONE-row entry replaced by (SA[row], 0xFFFFFFFF)
+                              // SA range of every dkmer-mer, entries of k-mers with few occurrences rewritten to text positions
     uint32_t        dkmer;
+    const uint2*    side;     // optional: the direct table's groups for k-mers with 2..7 occurrences (fm_seed_device.h)
+    uint32_t        dmark;    // entries of dtab with hi >= dmark hold positions, not SA ranges (0xFFFFFFFF: format 1, no context)
+    uint32_t        dctx;     // text symbols to the left of the occurrence that such an entry carries (15 or 0)
     const uint32_t* isa;      // optional (with a full SA): isa[p] = row of suffix p, isa[length] = 0
     const uint32_t* text;     // optional: the 2-bit packed text the index was built from
 };
@@ -95,7 +98,7 @@ __device__ __forceinline__ uint32_t rank_row(const DevIndex& f, const uint32_t k
 // one backward-search step: (x,y) -> (L2[c] + rank(x-1,c) + 1, L2[c] + rank(y,c)).
 // *nblocks (optional) accumulates the distinct 32-byte records touched.
 template <bool COUNT>
-__device__ __forceinline__ void search_step(const DevIndex& f, uint32_t& x, uint32_t& y, const uint32_t c, uint32_t& nblocks)
+__device__ __forceinline__ void search_step(const DevIndex& f, uint32_t& x, uint32_t& y, const uint32_t c, uint32_t& nblocks, uint32_t* nsectors = nullptr)
 {
     uint32_t kl = 0, kh = 0, vl = 0, vh = 0;
     const bool ml = resolve_row( f, x - 1u, c, &kl, &vl );
@@ -112,6 +115,7 @@ __device__ __forceinline__ void search_step(const DevIndex& f, uint32_t& x, uint
     if (ml) vl = pick4( o_l.x, o_l.y, o_l.z, o_l.w, c ) + count_in_block( b_l, kl & 63u, c );
     if (mh) vh = pick4( o_h.x, o_h.y, o_h.z, o_h.w, c ) + count_in_block( b_h, kh & 63u, c );
     if (COUNT) nblocks += (ml ? 1u : 0u) + ((mh && !(ml && bh == bl)) ? 1u : 0u);
+    if (nsectors) *nsectors += (ml ? 1u : 0u) + ((mh && !(ml && (bh >> 1) == (bl >> 1))) ? 1u : 0u);   // distinct 64-byte sectors (two records each)
 
     const uint32_t base = L2_of( f, c );
     x = base + vl + 1u;

@@ -16,6 +16,7 @@
 // (k = 12 -> 128 MiB: served from the 256 MiB Infinity Cache / HBM; the table is exact, it stores
 // the reference's own early-exit values, so ranges are identical with and without it).
 #include "fm_device.h"
+#include "fm_seed_device.h"
 #include <hipcub/hipcub.hpp>
 #include <new>
 #include <stdlib.h>
@@ -31,8 +32,11 @@ struct FMIndexImpl
     nvbio_fm_index_view  view;        // host copy (device pointers inside)
     uint2*               ktab;        // owned
     uint32_t             kmer;
-    uint2*               dtab;        // owned, optional: the table of the direct seed pass (positions for one-row k-mers)
+    uint2*               dtab;        // owned, optional: the table of the direct seed pass (positions for k-mers with few occurrences)
     uint32_t             dkmer;
+    uint2*               side;        // owned, optional: its groups for k-mers with 2..7 occurrences
+    uint32_t             dmark, dctx;
+    uint32_t             table_flags; // NVBIO_FM_TABLE_* of the build
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
     uint32_t*            isa;         // owned, optional (verify mode)
@@ -47,6 +51,7 @@ struct FMIndexImpl
         d.ssa  = view.ssa_dev;
         d.sa_log = 0; while ((1u << d.sa_log) < (view.sa_int ? view.sa_int : 16u)) ++d.sa_log;
         d.ktab = ktab; d.kmer = kmer; d.dtab = dtab; d.dkmer = dkmer;
+        d.side = side; d.dmark = dmark; d.dctx = dctx;
         d.isa = isa; d.text = text;
         return d;
     }
@@ -91,62 +96,76 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
 // remaining symbol plus the SA lookup of a later locate).  Such a query reports its single hit as the TEXT
 // POSITION (ranges[i] = (pos, pos), direct[i] = 1) -- the position locate() would return for the final row;
 // a mismatch reports the empty range (1,0).  Needs the full SA and the text (handles built with sa_int = 1).
+// The direct table (fm_seed_device.h) shortens this further: its entries hold the position and the text to the
+// left of a k-mer's occurrence(s), so that most searches end with the table gather itself.
 #ifndef NVB_NT_TABLE
 #define NVB_NT_TABLE 1
 #endif
 constexpr bool NT_TABLE = NVB_NT_TABLE != 0;
 
-template <int BITS, bool COUNT, bool TABLE, bool DIRECT>
-__device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev& q, const uint32_t flags, const bool tab, const bool verify,
-                                          const uint32_t i, uint32_t& x_out, uint32_t& y_out, uint32_t& nblk_out, bool& is_pos_out)
+struct SearchState
 {
-    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
-    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
-    uint32_t begin, len;
-    string_bounds( q, i, begin, len );
-    SymbolReader<BITS> rd( q.symbols );
+    uint32_t x, y, s;          // SA range and number of symbols consumed
+    bool     have_pos;         // the search is down to one occurrence whose text position is known (tpos)
+    uint32_t tpos;
+    bool     have_ctx;         // ... and so are the DevIndex::dctx symbols to its left (ctx)
+    uint32_t ctx;
+    bool     is_pos;           // result: (x, y) = (pos, pos) is a text position
+    uint32_t sectors;          // accounting (seed pass, COUNT mode): distinct 64-byte sectors this search gathered from the index
+};
 
-    // symbol s in scan order
-    auto sym = [&](const uint32_t s) -> uint32_t {
-        const uint32_t c = rd.get( fwd ? begin + s : begin + len - 1u - s );
-        return (comp && c < 4u) ? 3u - c : c;
-    };
-
-    uint32_t x = 0, y = f.length, s = 0, nblk = 0;
-    bool     have_pos = false;                              // DIRECT: the k-mer table already gave the text position
-    uint32_t tpos = 0;
-
-    // DIRECT: the handle's second table (one symbol longer) holds, for a k-mer with ONE occurrence, that occurrence's text
-    // position instead of its SA row -- the tail below then needs the text only (one dependent gather, not two)
-    const bool     use_d = DIRECT && f.dtab != nullptr && len >= f.dkmer;
-    const uint32_t tk    = use_d ? f.dkmer : f.kmer;
-    if (tab && len >= tk)
+__device__ __forceinline__ uint2 load_table_entry(const uint2* __restrict__ tab, const uint64_t key, const bool nt)
+{
+    // a table entry has no reuse: a non-temporal load keeps it from displacing the text and bwt_occ lines the caches can hold
+    if (nt && NT_TABLE)
     {
-        uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
-        for (uint32_t t = 0; t < tk; ++t)
-        {
-            const uint32_t c = sym( t );
-            ok = ok && (c < 4u);
-            key = (key << 2) | (c & 3u);
-        }
-        if (ok)
-        {
-            // the table entry has no reuse: a non-temporal load keeps it from displacing the text and bwt_occ lines the caches can hold
-            uint2 r;
-            if (use_d && NT_TABLE)
-            {
-                const unsigned long long v = __builtin_nontemporal_load( (const unsigned long long*)f.dtab + key );
-                r = make_uint2( (uint32_t)v, (uint32_t)(v >> 32) );
-            }
-            else r = use_d ? f.dtab[key] : f.ktab[key];
-            s = tk;
-            if (use_d && r.y == 0xFFFFFFFFu) { have_pos = true; tpos = r.x; x = y = 0u; }
-            else { x = r.x; y = r.y; }
-        }
+        const unsigned long long v = __builtin_nontemporal_load( (const unsigned long long*)tab + key );
+        return make_uint2( (uint32_t)v, (uint32_t)(v >> 32) );
     }
+    return tab[key];
+}
 
-    bool is_pos = false;
-    for (; s < len && x <= y && !have_pos; ++s)
+// decode the direct-table entry `e` of the first st.s symbols (see fm_seed_device.h for the format)
+template <class Sym>
+__device__ __forceinline__ void direct_entry(const DevIndex& f, const uint2 e, Sym& sym, const uint32_t len, SearchState& st)
+{
+    if (e.y < f.dmark) { st.x = e.x; st.y = e.y; return; }                 // a plain SA range
+    if (e.x < f.dmark)                                                     // one occurrence
+    {
+        st.have_pos = true; st.tpos = e.x; st.x = st.y = 0u;
+        st.have_ctx = f.dctx != 0u; st.ctx = e.y - f.dmark;
+        return;
+    }
+    // 2..7 occurrences: header (x, y) + one (position, context) slot per row, in one or two sectors
+    const uint32_t m  = e.y - f.dmark;
+    const uint4*   g4 = (const uint4*)(f.side + 4ull * (e.x - f.dmark));
+    st.sectors += 1u;                                                      // a 32-byte group lies in one sector, a 64-byte group is one
+    const uint4 q0 = g4[0], q1 = g4[1];
+    uint4 q2 = make_uint4( 0, 0, 0, 0 ), q3 = q2;
+    if (m > 3u) { q2 = g4[2]; q3 = g4[3]; }
+    const uint32_t r = len - st.s;
+    st.x = q0.x; st.y = q0.y;                                              // the k-mer's SA range
+    if (r > f.dctx) return;                                                // longer than the stored context: rank steps
+    uint32_t rest = 0; bool clean = true;
+    for (uint32_t t = 0; t < r; ++t) { const uint32_t c = sym( st.s + t ); clean = clean && c < 4u; rest = (rest << 2) | (c & 3u); }
+    if (!clean) { st.x = 1u; st.y = 0u; return; }                          // an N: no match (fmindex_inl.h:227-228)
+    uint32_t hits = 0, pos = 0;
+#define NVB_SIDE_ROW(j, P, C) if ((j) <= m && context_matches( (P), (C) - f.dmark, rest, r )) { ++hits; pos = (P); }
+    NVB_SIDE_ROW( 1u, q0.z, q0.w ) NVB_SIDE_ROW( 2u, q1.x, q1.y ) NVB_SIDE_ROW( 3u, q1.z, q1.w )
+    NVB_SIDE_ROW( 4u, q2.x, q2.y ) NVB_SIDE_ROW( 5u, q2.z, q2.w ) NVB_SIDE_ROW( 6u, q3.x, q3.y ) NVB_SIDE_ROW( 7u, q3.z, q3.w )
+#undef NVB_SIDE_ROW
+    if (hits == 0u)      { st.x = 1u; st.y = 0u; }                         // no occurrence continues with the rest of the pattern
+    else if (hits == 1u) { st.x = st.y = pos - r; st.is_pos = true; st.s = len; }
+    // several occurrences continue (a repeat longer than the pattern): their final SA range needs the rank steps
+}
+
+// the search from state st on: rank steps, and with DIRECT the finish of a one-row range on the text
+template <bool COUNT, bool DIRECT, class Sym>
+__device__ __forceinline__ void search_tail(const DevIndex& f, Sym& sym, const uint32_t len, const bool verify, SearchState& st, uint32_t& nblk)
+{
+    uint32_t x = st.x, y = st.y, s = st.s;
+    if (st.is_pos) return;
+    for (; s < len && x <= y && !st.have_pos; ++s)
     {
         // DIRECT: a lane whose range has collapsed leaves the loop and waits for its neighbours, so that the
         // whole wave runs the two gathers of the tail below once, together, instead of once per collapse time
@@ -178,27 +197,36 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
         }
         const uint32_t c = sym( s );
         if (c > 3u) { x = 1u; y = 0u; break; }              // an N: no match (fmindex_inl.h:227-228)
-        search_step<COUNT>( f, x, y, c, nblk );
+        search_step<COUNT>( f, x, y, c, nblk, &st.sectors );
     }
-    if (DIRECT && ((s < len && x == y) || have_pos))
+    if (DIRECT && ((s < len && x == y) || st.have_pos))
     {
-        uint32_t p = tpos;
-        if (!have_pos)
+        uint32_t p = st.tpos;
+        if (!st.have_pos)
         {
             const uint32_t sv = NT_TABLE ? __builtin_nontemporal_load( f.ssa + x ) : f.ssa[x];
             p = (sv == 0xFFFFFFFFu) ? f.length : sv;                  // row 0 is the empty suffix
+            st.sectors += 1u;
         }
         const uint32_t r  = len - s;
         bool ok = (p >= r);
         if (ok && r > 0u)
         {
-            const uint32_t w0 = (p - r) >> 4, w1 = (p - 1u) >> 4;
-            if (r <= 16u && w0 + 2u <= ((f.length + 15u) >> 4))      // both words inside the text copy
+            const uint32_t w0 = (p - r) >> 4;
+            if (st.have_pos && st.have_ctx && r <= f.dctx)
+            {
+                // the table entry carries the text to the left of the occurrence: no further gather
+                uint32_t rest = 0;
+                for (uint32_t t = 0; t < r; ++t) { const uint32_t c = sym( s + t ); ok = ok && c < 4u; rest = (rest << 2) | (c & 3u); }
+                ok = ok && context_matches( p, st.ctx, rest, r );
+            }
+            else if (r <= 16u && w0 + 2u <= ((f.length + 15u) >> 4))  // both words inside the text copy
             {
                 // the r <= 16 symbols text[p-r, p) lie in at most two consecutive words: ONE 8-byte gather (4-byte aligned)
                 // instead of a second, dependent 4-byte one whenever they straddle a word boundary
                 struct __attribute__((packed, aligned(4))) W2 { uint32_t a, b; };
                 const W2 w = *(const W2*)(f.text + w0);
+                st.sectors += ((w0 & 15u) == 15u) ? 2u : 1u;
                 for (uint32_t t = 0; t < r && ok; ++t)
                 {
                     const uint32_t i  = p - 1u - t;
@@ -206,11 +234,11 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
                     const uint32_t c  = sym( s + t );
                     ok = (c < 4u) && (c == ((tw >> (30u - 2u * (i & 15u))) & 3u));
                 }
-                (void)w1;
             }
             else
             {
                 SymbolReader<2> tr( f.text );
+                st.sectors += ((p - 1u) >> 8) - ((p - r) >> 8) + 1u;        // 256 symbols per sector
                 for (uint32_t t = 0; t < r && ok; ++t)
                 {
                     const uint32_t c = sym( s + t );
@@ -218,10 +246,56 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
                 }
             }
         }
-        if (ok) { x = y = p - r; is_pos = true; }
+        if (ok) { x = y = p - r; st.is_pos = true; }
         else    { x = 1u; y = 0u; }
     }
-    x_out = x; y_out = y; nblk_out = nblk; is_pos_out = is_pos;
+    st.x = x; st.y = y; st.s = s;
+}
+
+template <int BITS, bool COUNT, bool TABLE, bool DIRECT>
+__device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev& q, const uint32_t flags, const bool tab, const bool verify,
+                                          const uint32_t i, uint32_t& x_out, uint32_t& y_out, uint32_t& nblk_out, bool& is_pos_out,
+                                          uint32_t* sectors_out = nullptr)
+{
+    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
+    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
+    uint32_t begin, len;
+    string_bounds( q, i, begin, len );
+    SymbolReader<BITS> rd( q.symbols );
+
+    // symbol s in scan order
+    auto sym = [&](const uint32_t s) -> uint32_t {
+        const uint32_t c = rd.get( fwd ? begin + s : begin + len - 1u - s );
+        return (comp && c < 4u) ? 3u - c : c;
+    };
+
+    SearchState st;
+    st.x = 0; st.y = f.length; st.s = 0; st.have_pos = false; st.tpos = 0; st.have_ctx = false; st.ctx = 0; st.is_pos = false; st.sectors = 0;
+    uint32_t nblk = 0;
+
+    // DIRECT: the handle's second table (one symbol longer) resolves a k-mer with few occurrences to text positions
+    const bool     use_d = DIRECT && f.dtab != nullptr && len >= f.dkmer;
+    const uint32_t tk    = use_d ? f.dkmer : f.kmer;
+    if (tab && len >= tk)
+    {
+        uint64_t key = 0; bool ok = true;                    // 34 bits at k = 17
+        for (uint32_t t = 0; t < tk; ++t)
+        {
+            const uint32_t c = sym( t );
+            ok = ok && (c < 4u);
+            key = (key << 2) | (c & 3u);
+        }
+        if (ok)
+        {
+            const uint2 e = load_table_entry( use_d ? f.dtab : f.ktab, key, use_d );
+            st.s = tk; st.sectors += 1u;
+            if (use_d) direct_entry( f, e, sym, len, st );
+            else       { st.x = e.x; st.y = e.y; }
+        }
+    }
+    search_tail<COUNT,DIRECT>( f, sym, len, verify, st, nblk );
+    x_out = st.x; y_out = st.y; nblk_out = nblk; is_pos_out = st.is_pos;
+    if (sectors_out) *sectors_out = st.sectors;
 }
 
 template <int BITS, bool COUNT, bool TABLE, bool DIRECT = false>
@@ -243,89 +317,151 @@ fm_match_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// Seed pass straight to candidate diagonals (nvbio_fm_match_seed_diagonals): fm_match_kernel<.., DIRECT> over the seeds
-// of a read set, followed -- in the same kernel -- by what FMIndexFilter::rank's scan, FMIndexFilter::locate,
-// hit_to_diagonal (examples/fmmap/fmmap.cu:92-117) and the adjacent-duplicate removal do for a seed with ONE hit:
-//   * a seed that ended on one SA row is resolved to its text position (already known when the search finished on the
-//     text; one SA gather otherwise -- the handle holds the full SA);
+// Seed pass straight to candidate diagonals (nvbio_fm_match_seed_diagonals): the direct search over the seeds of a read set,
+// followed -- in the same kernel -- by what FMIndexFilter::rank's scan, FMIndexFilter::locate, hit_to_diagonal
+// (examples/fmmap/fmmap.cu:92-117) and the adjacent-duplicate removal do for a seed with ONE hit:
+//   * a seed that ended on one SA row is resolved to its text position (known from the direct table for nearly all of them;
+//     one SA gather otherwise -- the handle holds the full SA);
 //   * its diagonal key (read << 34 | strand << 33 | position - offset of the seed in the read + 1024) is formed;
-//   * the keys of a block are compacted in LDS in seed order, keys equal to their predecessor are dropped (consecutive
-//     seeds of a read that agree on the diagonal), and the survivors are appended to keys_out with ONE atomic add per
-//     block and loop iteration.
+//   * keys equal to their predecessor are dropped (consecutive seeds of a read that agree on the diagonal).
+// One WAVE owns a tile of whole reads (64 / seeds_per_read of them, one seed per lane): the compaction is a ballot and a
+// popcount, the predecessor's key comes through ds_bpermute -- no LDS, no barrier -- and the surviving keys go to the tile's
+// own 64 slots of a scratch array with their count beside them.  An exclusive scan of the 1.4 M tile counts and one small
+// copy kernel then make the list dense, IN SEED ORDER (a deterministic output; a first version appended each block's keys
+// with one atomic add on a global counter: 350 k returning atomics on one address serialise at about 11 ns each, most of
+// that kernel's 4.7 ms).
 // Seeds that end on SEVERAL rows (repeats) are appended to a residual list (seed id, range) for the ordinary
-// scan + locate path.  The order of keys_out across blocks is arbitrary; nothing downstream depends on it (the per-read
-// reduction uses a total order).  counts[0] = keys written, counts[1] = residual seeds.
+// scan + locate path; that list's order is arbitrary.  counts[0] = keys written, counts[1] = residual seeds.
 // ---------------------------------------------------------------------------------------------
-template <int BITS>
-__global__ void __launch_bounds__(256)
-fm_seed_diagonals_kernel(const DevIndex f, const StringSetDev q, const uint32_t flags, const uint32_t read_len, const uint32_t strand,
-                         uint64_t* __restrict__ keys_out, uint2* __restrict__ res_ranges, uint32_t* __restrict__ res_ids,
-                         unsigned int* __restrict__ counts)
+struct SeedTiles
 {
-    __shared__ uint64_t s_keys[256];
-    __shared__ uint32_t s_wave[2][4];
-    __shared__ uint32_t s_base[2];
-    const bool tab = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t reads;            // strings in the set
+    uint32_t rpt;              // reads per tile (64 / seeds per read; 1 when a read has more than 64 seeds)
+    uint32_t n_tiles;
+};
 
-    for (uint32_t base = blockIdx.x * 256u; base < q.n; base += gridDim.x * 256u)
+// COUNT: an accounting launch (untimed; bench.py's roofline): additionally sums, into sectors_out[0], the distinct 64-byte
+// sectors every search gathers from the index (table entry, group, bwt_occ records, SA word, text words)
+template <int BITS, bool COUNT = false>
+__global__ void __launch_bounds__(256)
+fm_seed_tiles_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, const uint32_t flags, const uint32_t read_len, const uint32_t strand,
+                     uint64_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_counts, uint2* __restrict__ res_ranges,
+                     uint32_t* __restrict__ res_ids, unsigned int* __restrict__ counts, unsigned long long* __restrict__ sectors_out = nullptr)
+{
+    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
+    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
+    const bool tab  = (f.ktab != nullptr) && !(flags & NVBIO_FM_NO_KMER_TABLE);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t len = q.fixed_len;
+    // seeds of a read beyond the 64 lanes of a wave take further rounds of the same tile (rpt == 1 then)
+    const uint32_t rounds = (q.spr + 63u) / 64u;
+
+    for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < tl.n_tiles; tile += n_waves)
     {
-        const uint32_t i = base + threadIdx.x;
-        uint32_t x = 1u, y = 0u, nblk; bool is_pos = false;
-        if (i < q.n) match_one<BITS,false,true,true>( f, q, flags, tab, false, i, x, y, nblk, is_pos );
-        bool single = is_pos;
-        if (!is_pos && x == y)                                   // one row left when the pattern ran out: its position
+        uint32_t n_out = 0;                                           // keys of this tile written so far (wave-uniform)
+        uint64_t last_key = ~0ull;                                    // the tile's last surviving key (wave-uniform)
+        for (uint32_t round = 0; round < rounds; ++round)
         {
-            const uint32_t sv = f.ssa[x];
-            x = (sv == 0xFFFFFFFFu) ? f.length : sv; single = true;
+            const uint32_t lr  = lane / q.spr;                        // read of the lane within the tile (rounds == 1)
+            const uint32_t rid = tile * tl.rpt + (rounds == 1u ? lr : 0u);
+            const uint32_t j   = rounds == 1u ? lane - lr * q.spr : round * 64u + lane;
+            const bool valid   = (rounds == 1u ? lr < tl.rpt : true) && j < q.spr && rid < tl.reads;
+            const uint32_t i   = rid * q.spr + j;                     // seed id
+
+            uint32_t x = 1u, y = 0u, sectors = 0u; bool single = false;
+            if (valid)
+            {
+                const uint32_t begin = (q.offsets ? q.offsets[rid] : rid * q.stride) + j * q.interval;
+                uint64_t V = 0;
+                const bool fast = len <= 32u && f.dtab != nullptr && len >= f.dkmer && tab;
+                if (fast)
+                {
+                    if (seed_bits<BITS>( q.symbols, begin, len, fwd, comp, V ))       // a seed with an N matches nothing
+                    {
+                        auto sym = [&](const uint32_t s) -> uint32_t { return (uint32_t)(V >> (2u * (len - 1u - s))) & 3u; };
+                        SearchState st;
+                        st.x = 0; st.y = f.length; st.s = f.dkmer; st.have_pos = false; st.tpos = 0; st.have_ctx = false; st.ctx = 0; st.is_pos = false; st.sectors = 1u;
+                        const uint2 e = load_table_entry( f.dtab, V >> (2u * (len - f.dkmer)), true );
+                        direct_entry( f, e, sym, len, st );
+                        uint32_t nblk = 0;
+                        search_tail<false,true>( f, sym, len, false, st, nblk );
+                        x = st.x; y = st.y; single = st.is_pos; sectors = st.sectors;
+                    }
+                }
+                else
+                {
+                    uint32_t nblk;
+                    match_one<BITS,false,true,true>( f, q, flags, tab, false, i, x, y, nblk, single, &sectors );
+                }
+                if (!single && x == y)                               // one row left when the pattern ran out: its position
+                {
+                    const uint32_t sv = f.ssa[x];
+                    x = (sv == 0xFFFFFFFFu) ? f.length : sv; single = true; ++sectors;
+                }
+            }
+            if (COUNT)
+            {
+                uint32_t tot = sectors;
+                #pragma unroll
+                for (int d = 32; d > 0; d >>= 1) tot += (uint32_t)__shfl_xor( (int)tot, d );
+                if (lane == 0 && tot) atomicAdd( sectors_out, (unsigned long long)tot );
+            }
+            const bool multi = valid && !single && x < y;
+            uint64_t key = 0;
+            if (single)
+            {
+                uint32_t p = j * q.interval;
+                if (strand) p = read_len - p - len;
+                key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
+            }
+            // ---- the wave's keys in seed order, a key equal to its predecessor dropped ----
+            const uint64_t m1 = __ballot( single );
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint64_t prev_mask = m1 & below;
+            const int      prev_lane = prev_mask ? 63 - __clzll( (long long)prev_mask ) : 0;
+            const uint32_t pk_lo = (uint32_t)__shfl( (int)(uint32_t)key, prev_lane ), pk_hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), prev_lane );
+            const uint64_t prev_key = prev_mask ? (((uint64_t)pk_hi << 32) | pk_lo) : last_key;
+            const bool     keep = single && key != prev_key;
+            const uint64_t m3 = __ballot( keep );
+            if (keep) tile_keys[(uint64_t)tile * 64u * rounds + n_out + (uint32_t)__popcll( m3 & below )] = key;
+            n_out += (uint32_t)__popcll( m3 );
+            if (m1)                                                  // the last single key of this round, for the next round's first
+            {
+                const int hl = 63 - __clzll( (long long)m1 );
+                const uint32_t lo = (uint32_t)__shfl( (int)(uint32_t)key, hl ), hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), hl );
+                last_key = ((uint64_t)hi << 32) | lo;
+            }
+            // ---- seeds on several rows: one atomic per wave that has any ----
+            const uint64_t m2 = __ballot( multi );
+            if (m2)
+            {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd( &counts[1], (unsigned int)__popcll( m2 ) );
+                base = (uint32_t)__shfl( (int)base, 0 );
+                if (multi)
+                {
+                    const uint32_t r = base + (uint32_t)__popcll( m2 & below );
+                    res_ranges[r] = make_uint2( x, y ); res_ids[r] = i;
+                }
+            }
         }
-        const bool multi = !single && x < y;
-        uint64_t key = 0;
-        if (single)
-        {
-            const uint32_t rid = i / q.spr;
-            uint32_t       p   = (i - rid * q.spr) * q.interval;
-            if (strand) p = read_len - p - q.fixed_len;
-            key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
-        }
-        // ---- compaction 1: the block's keys in seed order ----
-        const uint64_t m1 = __ballot( single ), m2 = __ballot( multi );
-        const uint64_t below = (1ull << lane) - 1ull;
-        if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll( m1 ); s_wave[1][wave] = (uint32_t)__popcll( m2 ); }
-        __syncthreads();
-        uint32_t off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
-        #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w)
-        {
-            if (w < wave) { off1 += s_wave[0][w]; off2 += s_wave[1][w]; }
-            tot1 += s_wave[0][w]; tot2 += s_wave[1][w];
-        }
-        if (single) s_keys[off1 + (uint32_t)__popcll( m1 & below )] = key;
-        __syncthreads();
-        // ---- drop keys equal to their predecessor; compaction 2 ----
-        const bool     cand = threadIdx.x < tot1;
-        const uint64_t k2   = cand ? s_keys[threadIdx.x] : 0ull;
-        const bool     keep = cand && (threadIdx.x == 0u || s_keys[threadIdx.x - 1u] != k2);
-        const uint64_t m3   = __ballot( keep );
-        __syncthreads();                                         // s_wave / s_keys are reused
-        if (lane == 0) s_wave[0][wave] = (uint32_t)__popcll( m3 );
-        __syncthreads();
-        uint32_t off3 = 0, tot3 = 0;
-        #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w) { if (w < wave) off3 += s_wave[0][w]; tot3 += s_wave[0][w]; }
-        if (threadIdx.x == 0)
-        {
-            s_base[0] = tot3 ? atomicAdd( &counts[0], tot3 ) : 0u;
-            s_base[1] = tot2 ? atomicAdd( &counts[1], tot2 ) : 0u;
-        }
-        __syncthreads();
-        if (keep)  keys_out[s_base[0] + off3 + (uint32_t)__popcll( m3 & below )] = k2;
-        if (multi)
-        {
-            const uint32_t r = s_base[1] + off2 + (uint32_t)__popcll( m2 & below );
-            res_ranges[r] = make_uint2( x, y ); res_ids[r] = i;
-        }
-        __syncthreads();
+        if (lane == 0) tile_counts[tile] = n_out;
+    }
+}
+
+// keys of tile t -> keys_out[offsets[t] ...]; the last tile also writes the total
+__global__ void __launch_bounds__(256)
+fm_seed_compact_kernel(const uint64_t* __restrict__ tile_keys, const uint32_t* __restrict__ tile_counts, const uint32_t* __restrict__ tile_offsets,
+                       const uint32_t n_tiles, const uint32_t slots, uint64_t* __restrict__ keys_out, unsigned int* __restrict__ counts)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves)
+    {
+        const uint32_t n = tile_counts[tile], off = tile_offsets[tile];
+        for (uint32_t k = lane; k < n; k += 64u) keys_out[off + k] = tile_keys[(uint64_t)tile * slots + k];
+        if (tile == n_tiles - 1u && lane == 0) counts[0] = off + n;
     }
 }
 
@@ -626,7 +762,7 @@ static nvbio_status make_set(const nvbio_string_set* s, StringSetDev* d)
     return NVBIO_OK;
 }
 
-// in place: every one-row range of a table becomes (text position of that row, 0xFFFFFFFF)
+// in place: every one-row range of a table becomes (text position of that row, 0xFFFFFFFF)  [direct table, format 1]
 __global__ void __launch_bounds__(256)
 fm_dtab_kernel(uint2* __restrict__ tab, const uint32_t* __restrict__ sa, const uint32_t length, const uint64_t n)
 {
@@ -641,15 +777,171 @@ fm_dtab_kernel(uint2* __restrict__ tab, const uint32_t* __restrict__ sa, const u
     }
 }
 
+// ---- direct table, format 2 (fm_seed_device.h): positions + left context in the entries, groups for 2..7 rows ----
+constexpr uint32_t DT_TILE = 1024u;                           // entries per tile: 256 threads x 4 consecutive entries
+
+// 0: plain range (empty, or more than DTAB_SIDE_MAX rows)   1: one row   2: 2..3 rows (4 slots)   3: 4..7 rows (8 slots)
+__device__ __forceinline__ uint32_t dtab_class(const uint2 r, const bool groups)
+{
+    if (r.x > r.y) return 0u;
+    const uint32_t d = r.y - r.x;
+    if (d == 0u) return 1u;
+    if (!groups) return 0u;
+    return d <= 2u ? 2u : (d < DTAB_SIDE_MAX ? 3u : 0u);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    #pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1)
+    {
+        const uint32_t o = (uint32_t)__shfl_up( (int)v, d );
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// tile t: cnt_small[t] / cnt_large[t] = its k-mers with 2..3 / 4..7 rows
+__global__ void __launch_bounds__(256)
+fm_dtab_count_kernel(const uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles, uint32_t* __restrict__ cnt_small, uint32_t* __restrict__ cnt_large)
+{
+    __shared__ uint32_t s_a[4], s_b[4];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        const uint64_t e0 = (uint64_t)tile * DT_TILE + threadIdx.x * 4u;
+        uint32_t a = 0, b = 0;
+        #pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (e0 + k < n) { const uint32_t c = dtab_class( tab[e0 + k], true ); a += (c == 2u); b += (c == 3u); }
+        a = wave_inclusive_sum( a ); b = wave_inclusive_sum( b );
+        if ((threadIdx.x & 63u) == 63u) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) { cnt_small[tile] = s_a[0] + s_a[1] + s_a[2] + s_a[3]; cnt_large[tile] = s_b[0] + s_b[1] + s_b[2] + s_b[3]; }
+        __syncthreads();
+    }
+}
+
+// rewrite the entries in place and fill the groups; off_small / off_large = exclusive scans of the tile counts;
+// large groups occupy side slots [0, 8 tot_large), small ones follow
+__global__ void __launch_bounds__(256)
+fm_dtab_fill_kernel(uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles, const uint32_t* __restrict__ off_small,
+                    const uint32_t* __restrict__ off_large, const uint32_t tot_large, const uint32_t* __restrict__ sa,
+                    const uint32_t* __restrict__ text, const uint32_t length, uint2* __restrict__ side)
+{
+    __shared__ uint32_t s_a[4], s_b[4];
+    const bool groups = side != nullptr;
+    auto position = [&](const uint32_t row) -> uint32_t { const uint32_t sv = sa[row]; return sv == 0xFFFFFFFFu ? length : sv; };
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        const uint64_t e0 = (uint64_t)tile * DT_TILE + threadIdx.x * 4u;
+        uint2 r[4]; uint32_t c[4];
+        uint32_t a = 0, b = 0;
+        #pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            c[k] = 0u; r[k] = make_uint2( 1u, 0u );
+            if (e0 + k < n) { r[k] = tab[e0 + k]; c[k] = dtab_class( r[k], groups ); a += (c[k] == 2u); b += (c[k] == 3u); }
+        }
+        const uint32_t ia = wave_inclusive_sum( a ), ib = wave_inclusive_sum( b );
+        if ((threadIdx.x & 63u) == 63u) { s_a[threadIdx.x >> 6] = ia; s_b[threadIdx.x >> 6] = ib; }
+        __syncthreads();
+        uint32_t ga = ia - a, gb = ib - b;                       // groups of this tile before this thread's
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { ga += s_a[w]; gb += s_b[w]; }
+        if (groups) { ga += off_small[tile]; gb += off_large[tile]; }
+        __syncthreads();
+        #pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            if (c[k] == 1u)
+            {
+                const uint32_t p = position( r[k].x );
+                tab[e0 + k] = make_uint2( p, DTAB_MARK | left_context( text, p ) );
+            }
+            else if (c[k] >= 2u)
+            {
+                const uint32_t rows  = r[k].y - r[k].x + 1u;
+                const uint32_t slots = c[k] == 2u ? 4u : 8u;
+                const uint32_t idx4  = c[k] == 2u ? 2u * tot_large + ga++ : 2u * gb++;       // group address in units of 4 slots
+                uint2* g = side + 4ull * idx4;
+                g[0] = r[k];
+                for (uint32_t j = 1; j < slots; ++j)
+                {
+                    uint2 v = make_uint2( 0u, DTAB_MARK );
+                    if (j <= rows) { const uint32_t p = position( r[k].x + j - 1u ); v = make_uint2( p, DTAB_MARK | left_context( text, p ) ); }
+                    g[j] = v;
+                }
+                tab[e0 + k] = make_uint2( DTAB_MARK | idx4, DTAB_MARK | rows );
+            }
+        }
+    }
+}
+
+// rewrite level k of the table (in `tab`) into the direct table; format 2 when the text is short enough for the marker
+static nvbio_status build_direct_table(FMIndexImpl* idx, uint2* tab, const uint64_t entries, hipStream_t stream)
+{
+    const uint32_t length = idx->view.length;
+    idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0;
+    if ((uint64_t)length + 2u > DTAB_MARK || (idx->table_flags & NVBIO_FM_TABLE_NO_CONTEXT))
+    {
+        hipLaunchKernelGGL( fm_dtab_kernel, dim3( grid_for( entries ) ), dim3(256), 0, stream, tab, idx->view.ssa_dev, length, entries );
+        NVB_HIP( hipGetLastError() );
+        return NVBIO_OK;
+    }
+    const uint32_t n_tiles = (uint32_t)((entries + DT_TILE - 1u) / DT_TILE);
+    const dim3 grid( n_tiles < 256u * 64u ? n_tiles : 256u * 64u ), block( 256 );
+    uint32_t* cnt = nullptr; void* temp = nullptr; uint2* side = nullptr;
+    size_t temp_bytes = 0;
+    uint32_t tot_small = 0, tot_large = 0;
+    const bool want_groups = !(idx->table_flags & NVBIO_FM_TABLE_NO_GROUPS);
+    nvbio_status st = NVBIO_OK;
+    if (want_groups)
+    {
+        if (hipMalloc( (void**)&cnt, 4ull * n_tiles * sizeof(uint32_t) ) != hipSuccess) { (void)hipGetLastError(); set_error( "direct table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+        uint32_t *cs = cnt, *cl = cnt + n_tiles, *os = cnt + 2ull * n_tiles, *ol = cnt + 3ull * n_tiles;
+        hipLaunchKernelGGL( fm_dtab_count_kernel, grid, block, 0, stream, (const uint2*)tab, entries, n_tiles, cs, cl );
+        hipError_t e = hipcub::DeviceScan::ExclusiveSum( nullptr, temp_bytes, cs, os, (int)n_tiles, stream );
+        if (e == hipSuccess) e = hipMalloc( &temp, temp_bytes ? temp_bytes : 16 );
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( temp, temp_bytes, cs, os, (int)n_tiles, stream );
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( temp, temp_bytes, cl, ol, (int)n_tiles, stream );
+        uint32_t last[4] = { 0, 0, 0, 0 };
+        if (e == hipSuccess) e = hipMemcpyAsync( &last[0], cs + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+        if (e == hipSuccess) e = hipMemcpyAsync( &last[1], os + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+        if (e == hipSuccess) e = hipMemcpyAsync( &last[2], cl + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+        if (e == hipSuccess) e = hipMemcpyAsync( &last[3], ol + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+        if (e == hipSuccess) e = hipStreamSynchronize( stream );
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error( "direct table: counting pass failed: %s", hipGetErrorString( e ) ); st = NVBIO_ERR_HIP; }
+        tot_small = last[0] + last[1]; tot_large = last[2] + last[3];
+        const uint64_t units = 2ull * tot_large + tot_small;                  // groups in units of 4 slots (32 bytes)
+        if (st == NVBIO_OK && units > 0 && units < (1ull << 30))
+        {
+            if (hipMalloc( (void**)&side, units * 32ull ) != hipSuccess) { (void)hipGetLastError(); side = nullptr; }   // no memory: no groups
+        }
+    }
+    if (st == NVBIO_OK)
+    {
+        hipLaunchKernelGGL( fm_dtab_fill_kernel, grid, block, 0, stream, tab, entries, n_tiles, cnt ? cnt + 2ull * n_tiles : nullptr,
+                            cnt ? cnt + 3ull * n_tiles : nullptr, tot_large, idx->view.ssa_dev, (const uint32_t*)idx->text, length, side );
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess) { set_error( "direct table: fill pass failed" ); st = NVBIO_ERR_HIP; }
+    }
+    if (cnt)  (void)hipFree( cnt );
+    if (temp) (void)hipFree( temp );
+    if (st != NVBIO_OK) { if (side) (void)hipFree( side ); return st; }
+    idx->side = side; idx->dmark = DTAB_MARK; idx->dctx = DTAB_CTX;
+    if (side) idx->owned_bytes += (2ull * tot_large + tot_small) * 32ull;
+    return NVBIO_OK;
+}
+
 // The k-mer table is built level by level (level j from level j-1, one search step per entry), alternating between two
 // buffers.  A handle that holds the full SA and the text (direct-capable) keeps the LAST TWO levels: level k-1 stays the
-// plain table of match() (SA ranges), level k becomes the table of the direct seed pass, its one-row entries rewritten
-// in place to text positions.  Other handles keep level k as the plain table.  (k = 17: 32 + 128 GiB; k = 16: 8 + 32 GiB.)
+// plain table of match() (SA ranges), level k becomes the table of the direct seed pass, the entries of k-mers with few
+// occurrences rewritten in place to text positions (fm_seed_device.h).  Other handles keep level k as the plain table.
+// (k = 17: 32 + 128 GiB; k = 16: 8 + 32 GiB.)
 static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
 {
-    idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0;
+    idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0;
     if (k == 0) return NVBIO_OK;
-    const bool direct = idx->text && idx->view.ssa_dev && idx->view.sa_int == 1 && k >= 2 && !getenv( "NVBIO_AMD_NO_DIRECT_TABLE" );
+    const bool direct = idx->text && idx->view.ssa_dev && idx->view.sa_int == 1 && k >= 2 && !(idx->table_flags & NVBIO_FM_TABLE_NO_DIRECT);
     const uint64_t entries = 1ull << (2 * k);
     uint2 *a = nullptr, *b = nullptr;
     if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
@@ -666,13 +958,14 @@ static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t s
         uint2* t = cur; cur = oth; oth = t;
     }
     // cur == a (level k), oth == b (level k-1) by construction
-    if (direct)
-        hipLaunchKernelGGL( fm_dtab_kernel, dim3( grid_for( entries ) ), dim3(256), 0, stream, a, idx->view.ssa_dev, idx->view.length, entries );
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess)
+    nvbio_status st = NVBIO_OK;
+    if (hipGetLastError() != hipSuccess) { set_error( "k-mer table build failed" ); st = NVBIO_ERR_HIP; }
+    if (st == NVBIO_OK && direct) st = build_direct_table( idx, a, entries, stream );
+    if (st == NVBIO_OK && hipStreamSynchronize( stream ) != hipSuccess) { set_error( "k-mer table build failed" ); st = NVBIO_ERR_HIP; }
+    if (st != NVBIO_OK)
     {
         (void)hipFree( a ); (void)hipFree( b );
-        set_error( "k-mer table build failed" );
-        return NVBIO_ERR_HIP;
+        return st;
     }
     if (direct)
     {
@@ -689,11 +982,12 @@ static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t s
 }
 
 nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_t kmer_len, bool owns, hipStream_t stream, nvbio_fm_index_t* out,
-                            uint32_t* isa, uint32_t* text)
+                            uint32_t* isa, uint32_t* text, uint32_t table_flags)
 {
     FMIndexImpl* idx = new (std::nothrow) FMIndexImpl;
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
     idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->isa = nullptr; idx->text = nullptr;
+    idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0; idx->table_flags = table_flags;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     idx->isa = isa; idx->text = text;
@@ -732,7 +1026,7 @@ nvbio_status nvbio_fm_index_create(const nvbio_fm_index_view* view, int device, 
     NVB_REQUIRE( view->bwt_occ_words >= need, "bwt_occ_words too small for length" );
     NVB_REQUIRE( view->ssa_dev == nullptr || view->ssa_words >= (uint64_t)view->length / K + 1u, "ssa_words too small for length" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out, nullptr, nullptr );
+    return fm_index_adopt( view, device, kmer_len, false, (hipStream_t)stream, out, nullptr, nullptr, 0u );
 }
 
 nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
@@ -742,6 +1036,7 @@ nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     if (idx->ktab) (void)hipFree( idx->ktab );
     if (idx->dtab) (void)hipFree( idx->dtab );
+    if (idx->side) (void)hipFree( idx->side );
     if (idx->isa)  (void)hipFree( idx->isa );
     if (idx->text) (void)hipFree( idx->text );
     if (idx->owns_arrays) { (void)hipFree( (void*)idx->view.bwt_occ_dev ); (void)hipFree( (void*)idx->view.ssa_dev ); }
@@ -1005,9 +1300,40 @@ nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_stri
     return NVBIO_OK;
 }
 
+// scratch layout of nvbio_fm_match_seed_diagonals: tile keys | tile counts | tile offsets | scan temp
+struct SeedScratch { SeedTiles tl; uint32_t slots; uint64_t keys_bytes, counts_bytes, scan_bytes, total; };
+
+static nvbio_status seed_scratch_layout(const nvbio_string_set* seeds, SeedScratch* L)
+{
+    NVB_REQUIRE( seeds != nullptr, "seeds is NULL" );
+    const uint32_t spr = seeds->seeds_per_string;
+    NVB_REQUIRE( spr > 0, "the string set must enumerate seeds (seeds_per_string > 0)" );
+    NVB_REQUIRE( seeds->n % spr == 0, "n must be a multiple of seeds_per_string" );
+    L->tl.reads   = seeds->n / spr;
+    L->tl.rpt     = spr <= 64u ? 64u / spr : 1u;
+    L->tl.n_tiles = (L->tl.reads + L->tl.rpt - 1u) / L->tl.rpt;
+    L->slots      = 64u * ((spr + 63u) / 64u);
+    L->keys_bytes   = ((uint64_t)L->tl.n_tiles * L->slots * sizeof(uint64_t) + 255u) & ~255ull;
+    L->counts_bytes = ((uint64_t)(L->tl.n_tiles + 1u) * sizeof(uint32_t) + 255u) & ~255ull;
+    size_t scan = 0;
+    if (L->tl.n_tiles)
+        NVB_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)L->tl.n_tiles, (hipStream_t)0 ) );
+    L->scan_bytes = ((uint64_t)scan + 255u) & ~255ull;
+    L->total = L->keys_bytes + 2u * L->counts_bytes + L->scan_bytes + 256u;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_match_seed_diagonals_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes)
+{
+    NVB_REQUIRE( bytes != nullptr, "bytes is NULL" );
+    SeedScratch L; NVB_CHECK( seed_scratch_layout( seeds, &L ) );
+    *bytes = L.total;
+    return NVBIO_OK;
+}
+
 nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                            uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
-                                           uint32_t* counts_dev, void* stream)
+                                           uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes, void* stream)
 {
     NVB_REQUIRE( index != nullptr, "index is NULL" );
     FMIndexImpl* idx = (FMIndexImpl*)index;
@@ -1015,6 +1341,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     NVB_REQUIRE( counts_dev != nullptr, "counts_dev is NULL" );
     NVB_REQUIRE( q.spr > 0, "the string set must enumerate seeds (seeds_per_string > 0)" );
     NVB_REQUIRE( (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( q.fixed_len > 0, "empty seeds" );
     if (!(idx->text && idx->view.ssa_dev && idx->view.sa_int == 1))
     {
         set_error( "nvbio_fm_match_seed_diagonals needs the full suffix array and the text: build the index with sa_int = 1" );
@@ -1022,15 +1349,37 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     }
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    NVB_HIP( hipMemsetAsync( counts_dev, 0, 2 * sizeof(uint32_t), s ) );
+    const bool count = (flags & NVBIO_FM_COUNT_SECTORS) != 0;
+    NVB_REQUIRE( !count || ((uintptr_t)counts_dev & 7u) == 0, "counts_dev must be 8-byte aligned with NVBIO_FM_COUNT_SECTORS" );
+    NVB_HIP( hipMemsetAsync( counts_dev, 0, (count ? 4 : 2) * sizeof(uint32_t), s ) );
     if (q.n == 0) return NVBIO_OK;
     NVB_REQUIRE( keys_dev && residual_ranges_dev && residual_ids_dev, "NULL device pointer" );
+    SeedScratch L; NVB_CHECK( seed_scratch_layout( seeds, &L ) );
+    uint8_t* temp = (uint8_t*)temp_dev;
+    bool own_temp = false;
+    if (temp == nullptr)
+    {
+        if (hipMallocAsync( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
+        own_temp = true;
+    }
+    else NVB_REQUIRE( temp_bytes >= L.total, "temp_bytes too small (nvbio_fm_match_seed_diagonals_temp_bytes)" );
+    uint8_t* base = (uint8_t*)(((uintptr_t)temp + 255u) & ~(uintptr_t)255u);
+    uint64_t* tile_keys    = (uint64_t*)base;
+    uint32_t* tile_counts  = (uint32_t*)(base + L.keys_bytes);
+    uint32_t* tile_offsets = (uint32_t*)(base + L.keys_bytes + L.counts_bytes);
+    void*     scan_temp    = base + L.keys_bytes + 2u * L.counts_bytes;
     const DevIndex f = idx->dev();
-    unsigned cap = 256u * 256u;                               // measured: scripts/exp_occupancy.sh (8 k blocks: 5.58 ms, 64 k: 5.32, uncapped: 5.6)
-    if (const char* e = getenv( "NVBIO_AMD_SEED_GRID_BLOCKS" )) { const long v = atol( e ); if (v > 0) cap = (unsigned)v; }   // occupancy experiments
-    const dim3 grid( grid_for( q.n, 256, cap ) ), block( 256 );
-#define NVB_LAUNCH_SD(BITS) hipLaunchKernelGGL( (fm_seed_diagonals_kernel<BITS>), grid, block, 0, s, f, q, flags, read_len, strand, keys_dev, \
-                                                (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev )
+    // one wave per tile of whole reads; the grid keeps every wave slot of the chip busy a few times over (flags bits 16..31:
+    // workgroups in units of 64, a tuning/testing knob -- results do not depend on it)
+    unsigned blocks = (L.tl.n_tiles + 3u) / 4u;
+    const unsigned cap = (flags >> 16) ? (flags >> 16) * 64u : 256u * 64u;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid( blocks ), block( 256 );
+#define NVB_LAUNCH_SD(BITS) \
+    if (count) hipLaunchKernelGGL( (fm_seed_tiles_kernel<BITS,true>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
+                                   (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev, (unsigned long long*)(counts_dev + 2) );       \
+    else       hipLaunchKernelGGL( (fm_seed_tiles_kernel<BITS,false>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
+                                   (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev, (unsigned long long*)nullptr )
     switch (seeds->symbol_bits)
     {
     case 2: NVB_LAUNCH_SD(2); break;
@@ -1038,7 +1387,17 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     default: NVB_LAUNCH_SD(8); break;
     }
 #undef NVB_LAUNCH_SD
-    NVB_HIP( hipGetLastError() );
+    hipError_t e = hipGetLastError();
+    size_t scan_bytes = L.scan_bytes;
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( blocks ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+                            (const uint32_t*)tile_offsets, L.tl.n_tiles, L.slots, keys_dev, (unsigned int*)counts_dev );
+        e = hipGetLastError();
+    }
+    if (own_temp) (void)hipFreeAsync( temp, s );
+    if (e != hipSuccess) { set_error( "seed pass failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }
 

@@ -815,7 +815,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
 {
     const uint32_t pairs = (b.n + 1u) / 2u;
     int32_t P = 0;
-    if (TYPE == NVBIO_SEMI_GLOBAL && ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" ))
+    if (TYPE == NVBIO_SEMI_GLOBAL && ungapped_ok( sc, b, &P ) && !(b.algo & NVBIO_ALN_NO_UNGAPPED_SCORE))
     {
         // 1. settle the jobs whose best diagonal beats every gapped alignment; 2. compact the rest; 3. DP over the list
         const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
@@ -824,7 +824,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        const bool third = !getenv( "NVBIO_AMD_NO_THIRD_CHANCE" );
+        const bool third = !(b.algo & NVBIO_ALN_NO_THIRD_CHANCE);
         void* aux = nullptr;
         if (hipMallocAsync( &aux, flags_bytes + 2u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
@@ -871,7 +871,7 @@ template <int BAND, int TYPE>
 static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
                                 int32_t* scores, uint2* sinks, hipStream_t s)
 {
-    if (BAND == 31 && plain_gotoh( sc ) && packed_ok( TYPE, sc, b.max_read_len ) && !getenv( "NVBIO_AMD_NO_PACKED_DP" ))
+    if (BAND == 31 && plain_gotoh( sc ) && packed_ok( TYPE, sc, b.max_read_len ) && !(b.algo & NVBIO_ALN_NO_PACKED_DP))
     {
         if      (rbits == 4 && tbits == 2) return launch_pk<TYPE,4>( b, sc, scores, sinks, s );
         else if (rbits == 2 && tbits == 2) return launch_pk<TYPE,2>( b, sc, scores, sinks, s );
@@ -916,7 +916,7 @@ nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
     }
     b->reads = in->reads_dev; b->read_offsets = in->read_offsets_dev; b->quals = in->quals_dev;
     b->read_id = in->read_id_dev; b->flags = in->flags_dev; b->text = in->text_dev;
-    b->win_begin = in->win_begin_dev; b->win_end = in->win_end_dev; b->n = in->n; b->max_read_len = in->max_read_len;
+    b->win_begin = in->win_begin_dev; b->win_end = in->win_end_dev; b->n = in->n; b->max_read_len = in->max_read_len; b->algo = in->algo_flags;
     return NVBIO_OK;
 }
 

@@ -17,6 +17,7 @@ struct BatchDev
     const uint32_t* win_end;
     uint32_t        n;
     uint32_t        max_read_len;
+    uint32_t        algo;              // NVBIO_ALN_* (host-side kernel selection only)
 };
 
 // Scoring scheme as the kernels see it.  The reference's Gotoh kernels take BOTH gap recurrences from the pattern-gap terms and

@@ -728,10 +728,10 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
     uint32_t *list_a = nullptr, *count_a = nullptr, *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
     int32_t P = 0;
     const bool packable_bits = batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2);
-    const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && plain_gotoh( sc ) && full_ungapped_ok( sc, b, &P ) && !getenv( "NVBIO_AMD_NO_UNGAPPED_SCORE" );
+    const bool shortcut = type == NVBIO_SEMI_GLOBAL && packable_bits && plain_gotoh( sc ) && full_ungapped_ok( sc, b, &P ) && !(b.algo & NVBIO_ALN_NO_UNGAPPED_SCORE);
     // (two jobs per lane only pay when the lanes still fill the chip: 100 k jobs of the sw-benchmark shape ran 15-20 % slower packed)
-    const bool packed   = !text_blocking && packable_bits && (b.n >= 262144u || getenv( "NVBIO_AMD_FORCE_PACKED_DP" )) && plain_gotoh( sc ) && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
-                          !getenv( "NVBIO_AMD_NO_PACKED_DP" );
+    const bool packed   = !text_blocking && packable_bits && (b.n >= 262144u || (b.algo & NVBIO_ALN_FORCE_PACKED_DP)) && plain_gotoh( sc ) && full_packed_ok( type, sc, max_pattern_len, max_text_len ) &&
+                          !(b.algo & NVBIO_ALN_NO_PACKED_DP);
     if (shortcut || packed)
     {
         size_t sel_bytes = 0;

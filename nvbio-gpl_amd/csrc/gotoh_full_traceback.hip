@@ -427,7 +427,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     const uint32_t rb = batch->read_bits, tbits = batch->text_bits;
 
     // ---- 1. scoring pass (pattern blocking) unless handed over; 2. the ungapped shortcut; 3. job list ----
-    const bool shortcut = !getenv( "NVBIO_AMD_NO_UNGAPPED_TRACEBACK" );
+    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
     uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
     if (shortcut)
     {

@@ -500,7 +500,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     SchemeDev sc = scheme_dev( scheme );
 
     // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
-    const bool shortcut = !getenv( "NVBIO_AMD_NO_UNGAPPED_TRACEBACK" );
+    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
     uint8_t*  need_dp   = nullptr;      // [n] flags
     uint32_t* job_list  = nullptr;      // [n] compacted job ids
     uint32_t* job_count = nullptr;      // [1]

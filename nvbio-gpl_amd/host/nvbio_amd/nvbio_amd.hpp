@@ -125,7 +125,7 @@ public:
     fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0, uint32_t sa_int = 16)
         : m_h( nullptr ), m_device( device )
     {
-        const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u, 0u };
+        const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u, 0u, 0u, 0u };
         check( nvbio_fm_index_build( text2_dev, length, device, &opts, stream, &m_h ) );
     }
     // load the reference's on-disk index files (<prefix>.bwt / .sa as written by nvBWT, read by io::FMIndexDataHost::load,

@@ -38,6 +38,7 @@ class SeedExtendParams:
         self.mapq = False                           # also keep nvBowtie's second-best alignment per read and compute the
                                                     # mapping quality (score_reduce + BowtieMapq2); results go to `extras`
         self.mapq_version = 2
+        self.algo_flags = 0                         # nvbio_alignment_batch::algo_flags of the extension (ALN_*: A/B of the exact shortcuts)
 
     @classmethod
     def end_to_end(cls, constant_quality=True, **kw):
@@ -124,7 +125,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         tock(e)
         e = tick("extend" + tag)
         batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, read_id=rid,
-                               flags=flags, device=dev, max_read_len=M)
+                               flags=flags, device=dev, max_read_len=M, algo_flags=params.algo_flags or None)
         scores, sinks = BatchedBandedAlignmentScore(params.band, aligner).enact(batch)
         tock(e)
         e = tick("reduce")
@@ -158,7 +159,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             tock(e)
             if "host" not in b:
                 b["host"] = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            b["host"].copy_(b["counts"], non_blocking=True)
+            b["host"].copy_(b["counts"][:2], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             pending.append((strand, b, ev))
@@ -271,7 +272,7 @@ def traceback_best(genome2, genome_len, reads, params, best_score, best_rc, best
     from . import BatchedBandedAlignmentTraceback
     dev = best_score.device
     R, M = reads.n, reads.read_len
-    ids = torch.nonzero(best_wb >= 0).view(-1)
+    ids = torch.nonzero((best_wb >= 0) & (best_score >= params.min_score_for(M))).view(-1)      # aligned reads only
     wb = best_wb[ids]
     we = torch.clamp(wb + params.band + M, max=genome_len)
     flags = (best_rc[ids].to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8)

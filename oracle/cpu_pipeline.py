@@ -107,7 +107,7 @@ def seed_and_extend_ref(Rf, O, ridx, genome2, genome_len, reads, seed_len=22, se
 
 
 def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_len=22, seed_interval=None, band=31,
-                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, want_loci=False,
+                        aln_type=LOCAL, scheme=None, quals=None, genome_is_packed=False, traceback_stride=0, traceback_min_score=None, want_loci=False,
                         max_seed_hits=None, second=None):
     """reads: uint8 [R, M] (values 0..4).  Returns (best_score, best_pos, best_rc, n_candidates); with
     second = dict(min_score, perfect_score, monotone, version) also a dict with nvBowtie's second-best alignment per read
@@ -206,6 +206,8 @@ def seed_and_extend_cpu(O, hidx, genome_syms_or_packed, genome_len, reads, seed_
         win = packed == top[rid]
         np.maximum.at(best_wb, rid[win], wb[win].astype(np.int64))
         ids = np.nonzero(best_wb >= 0)[0]
+        if traceback_min_score is not None:               # only reads that are aligned (nvBowtie traces valid alignments only)
+            ids = np.nonzero((best_wb >= 0) & (best_score >= traceback_min_score))[0]
         twb = best_wb[ids]
         twe = np.minimum(twb + band + M, genome_len)
         sc, src, snk, cig, ln = O.banded_gotoh_traceback_packed_batch(

@@ -29,6 +29,14 @@ def test_bench_json_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # a roofline fraction is a fraction: the bytes are those the TIMED launch moves (sector-granular, counted by the kernel)
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["reference_algorithm"]["frac"] <= 1.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["gathered_sectors_per_launch"] > 0 and 0.5 < r["sectors_per_seed"] < 40.0       # about 1.07 on the 3 Gbp / k = 17 workload; rank steps dominate on this toy index
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]          # counter traffic comes from a named profile, never from thin air
+    assert "i16" in d["dtype"] and d["extend"]["gcups"] > 0 and d["extend"]["effective_gcups"] >= d["extend"]["gcups"] * 0.5
+    assert d["traceback"]["cigars_truncated"] == 0
+    assert d["left_out_of_the_step"]["build"]["index_and_tables_s"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

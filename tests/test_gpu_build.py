@@ -26,9 +26,9 @@ def _texts():
     yield "A-tail", t
 
 
-def _check(amd, orc, name, text, max_lcp=0):
+def _check(amd, orc, name, text, max_lcp=0, bucket_symbols=None):
     want = orc.build_index(text)
-    fmi = amd.FMIndex.build(orc.pack2(text), len(text), kmer_len=0, max_lcp=max_lcp)
+    fmi = amd.FMIndex.build(orc.pack2(text), len(text), kmer_len=0, max_lcp=max_lcp, bucket_symbols=bucket_symbols)
     v = fmi.view()
     assert v.length == want.n, name
     assert v.primary == want.primary, name
@@ -49,13 +49,9 @@ def test_build_bucketed_path(amd, orc):
     rng = np.random.default_rng(10)
     text = rng.integers(0, 4, 300000, dtype=np.uint8)
     text[1000:1200] = 0
-    for b in ("1", "2", "4"):
-        os.environ["NVBIO_AMD_BUILD_BUCKET_SYMBOLS"] = b
-        try:
-            _check(amd, orc, "bucket-" + b, text)
-            _check(amd, orc, "bucket-tiny-" + b, text[:70])
-        finally:
-            del os.environ["NVBIO_AMD_BUILD_BUCKET_SYMBOLS"]
+    for b in (1, 2, 4):                                  # nvbio_fm_build_options::bucket_symbols
+        _check(amd, orc, "bucket-%d" % b, text, bucket_symbols=b)
+        _check(amd, orc, "bucket-tiny-%d" % b, text[:70], bucket_symbols=b)
 
 
 def test_build_rejects_long_repeats_when_asked(amd, orc):
@@ -159,8 +155,8 @@ def test_sa_isa_verification_shortcut_is_exact(amd, orc, k):
         amd.FMIndex.build(orc.pack2(text), n, sa_int=16, verify=True)
 
 
-@pytest.mark.parametrize("k", [0, 6, 9])
-def test_match_direct_gives_the_same_hits(amd, orc, k):
+@pytest.mark.parametrize("k,table_flags", [(0, 0), (6, 0), (9, 0), (9, 2), (9, 4), (7, 1)])
+def test_match_direct_gives_the_same_hits(amd, orc, k, table_flags):
     """nvbio_fm_match_direct: searches that collapse to one SA row finish on the text and report the position.
     Checked against the reference algorithm: range sizes, and the hits of the filter expansion (value and
     order), for hits, misses at every position, N's, patterns running off either end of the text, both scan
@@ -171,7 +167,12 @@ def test_match_direct_gives_the_same_hits(amd, orc, k):
     text = rng.integers(0, 4, n, dtype=np.uint8)
     text[5000:5600] = np.tile(np.array([1, 1, 2, 0, 3], dtype=np.uint8), 120)
     hidx = orc.build_index(text)
-    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1)
+    text[9000:9200] = text[20000:20200]                      # 2 and 4 copies: the direct table's groups
+    for c in range(3):
+        text[40000 + 300 * c:40250 + 300 * c] = text[30000:30250]
+    hidx = orc.build_index(text)
+    # table_flags: every form of the direct table (format 2 with groups, without context, without groups, plain table only)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=table_flags)
     assert fmi.supports_direct()
     Q = 30000
     syms, offs = make_queries(rng, text, Q, 2, 40, hit_every=1)

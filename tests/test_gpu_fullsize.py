@@ -98,3 +98,103 @@ def test_config4_band31_local_slice(amd, ref3g):
     sub = amd.AlignmentBatch(reads4, 4, roffs, words, 2, wb[:200_000], we[:200_000])
     sc2, sk2 = amd.batch_banded_alignment_score(31, al, sub)
     assert torch.equal(sc2, sc[:200_000]) and torch.equal(sk2, sk[:200_000])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The headline configuration of bench.py (BASELINE.json configs[2]): 3 Gbp reference, k = 17 direct table (34-bit keys, 128 GiB,
+# groups), full suffix array (sa_int = 1), one-call seed pass -- checked against the reference's algorithm run by the plain
+# operators on the same index (match() without any table + locate()), which the small-scale tests pin on the reference's
+# own outputs.  The shape of nvbio-test/fmindex_test.cu:603-709: match -> locate -> compare, here over 1 M reads x 18 seeds.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def headline(amd):
+    import importlib
+    import torch
+    import bench
+    n = 3_000_000_000
+    genome = bench.make_reference(n, "cuda:0", seed=1234)
+    try:
+        fmi = amd.FMIndex.build(genome, n, kmer_len=17, sa_int=1)
+    except amd.NvbioError as e:
+        pytest.skip("the k = 17 tables do not fit on this device: %s" % e)
+    R, M = 1_000_000, 150
+    reads_sym, truth_pos, truth_rc = bench.make_reads(genome, n, R, M, "cuda:0", seed=77)
+    reads_sym[5::1000, 40] = 4                                  # a few N's
+    reads4 = bench.pack4(reads_sym.view(-1))
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    yield dict(n=n, genome=genome, fmi=fmi, R=R, M=M, reads4=reads4, truth_pos=truth_pos, truth_rc=truth_rc, pipeline=pipeline)
+    fmi.close()
+    torch.cuda.empty_cache()
+
+
+def test_headline_seed_pass_equals_reference_algorithm(amd, headline):
+    """fm_seed_tiles_kernel over the k = 17 direct table == match() through the reference's algorithm (no table) + locate(),
+    key for key and in order, and seed for seed on the residual list, both strands"""
+    import torch
+    h = headline
+    fmi, R, M = h["fmi"], h["R"], h["M"]
+    L, S = 22, 15
+    spr = (M - L) // S + 1
+    qs = amd.PackedStringSet(h["reads4"], 4, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
+    v = fmi.view()
+    assert v.sa_int == 1 and fmi.supports_direct() and fmi.device_bytes() > 150e9      # 32 + 128 GiB of tables, full SA
+    sid = torch.arange(R * spr, device="cuda:0", dtype=torch.int64)
+    n_single = n_multi = 0
+    for strand, flags in ((0, 0), (1, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT)):
+        ref = fmi.match(qs, flags | amd.FM_NO_KMER_TABLE)                              # the reference's algorithm, symbol by symbol
+        assert torch.equal(fmi.match(qs, flags), ref)                                  # ... the k = 16 plain table changes nothing
+        ru = ref.to(torch.int64) & 0xFFFFFFFF
+        x, y = ru[:, 0], ru[:, 1]
+        single, multi = x == y, x < y
+        pos = fmi.locate(x[single].to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
+        rid, j = sid[single] // spr, sid[single] % spr
+        p = j * S
+        if strand:
+            p = M - p - L
+        keys = (rid << 34) | (strand << 33) | (pos + 1024 - p)
+        keep = torch.ones_like(keys, dtype=torch.bool)
+        keep[1:] = keys[1:] != keys[:-1]
+        want = keys[keep]
+        b = fmi.match_seed_diagonals(qs, flags, M, strand)
+        nk, nr = [int(c) for c in b["counts"][:2].cpu()]
+        assert nk == want.numel() and torch.equal(b["keys"][:nk], want)
+        # residual seeds: exactly the multi-row ones, with the reference's ranges
+        order = torch.argsort(b["ids"][:nr])
+        assert torch.equal(b["ids"][:nr][order].to(torch.int64), sid[multi])
+        assert torch.equal(b["ranges"][:nr][order], ref[multi])
+        # match_direct agrees too: sizes, and positions where it finished on the text
+        rng_d, direct = fmi.match_direct(qs, flags)
+        du = rng_d.to(torch.int64) & 0xFFFFFFFF
+        d = direct.bool()
+        assert torch.equal((du[:, 1] + 1 - du[:, 0]).clamp(min=0), (y + 1 - x).clamp(min=0))
+        assert bool((single[d]).all()) and torch.equal(du[d, 0], fmi.locate(x[d].to(torch.int32)).to(torch.int64) & 0xFFFFFFFF)
+        n_single += int(single.sum()); n_multi += int(multi.sum())
+        del ref, ru, b
+    assert n_single > 3 * R and 0 < n_multi < n_single // 100      # ~40 % of 18 M seeds hit once; a handful of true repeats
+
+
+def test_headline_pipeline_three_ways(amd, headline):
+    """seed_and_extend on the headline index: one-call seed pass == separate direct operators == plain match() + locate(),
+    and every planted read comes back to its locus and strand"""
+    import torch
+    h = headline
+    pipeline, fmi = h["pipeline"], h["fmi"]
+    batch = pipeline.ReadBatch(h["reads4"], h["R"], h["M"])
+    outs = []
+    for fused, direct in ((True, True), (False, True), (False, False)):
+        params = pipeline.SeedExtendParams.end_to_end()
+        params.fused_seed_pass, params.direct = fused, direct
+        outs.append(pipeline.seed_and_extend(fmi, h["genome"], h["n"], batch, params))
+    (bs, bp, brc, nc) = outs[0]
+    for o in outs[1:]:
+        assert torch.equal(o[0], bs) and torch.equal(o[1], bp) and torch.equal(o[2], brc)
+        assert nc <= o[3] <= nc * 1.10                            # the separate operators dedupe less
+    params = pipeline.SeedExtendParams.end_to_end()
+    aligned = bs >= params.min_score_for(h["M"])
+    near = (bp - (h["truth_pos"] + h["M"])).abs() <= 40
+    assert float(aligned.float().mean()) > 0.999
+    assert float((aligned & near & (brc.bool() == h["truth_rc"])).float().mean()) > 0.999
+    # the DP-for-everything variant of the extension agrees (nvbio_alignment_batch::algo_flags)
+    params.algo_flags = amd.ALN_NO_UNGAPPED_SCORE
+    o = pipeline.seed_and_extend(fmi, h["genome"], h["n"], batch, params)
+    assert torch.equal(o[0], bs) and torch.equal(o[1], bp) and torch.equal(o[2], brc)

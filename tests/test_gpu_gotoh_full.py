@@ -150,7 +150,7 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
     mismatches, indels, N's, reversed / complemented mates, windows up to and beyond the shortcut's 528 symbols,
     windows shorter than the read, both blockings"""
     if not shortcut:
-        monkeypatch.setenv("NVBIO_AMD_NO_UNGAPPED_SCORE", "1")
+        monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_UNGAPPED_SCORE)
     rng = np.random.default_rng(23)
     G = 300000
     text = rng.integers(0, 4, G, dtype=np.uint8)
@@ -223,7 +223,7 @@ def test_packed_pattern_blocking_kernel(amd, orc, typ, monkeypatch):
     reads, qualities, N's, per-job min_score (early exit of one job of a pair only), with and without the
     end-to-end shortcut in front -- every score and sink equals the reference algorithm's"""
     typ = getattr(oracle, typ)
-    monkeypatch.setenv("NVBIO_AMD_FORCE_PACKED_DP", "1")           # the library keeps small batches on the int32 kernel
+    monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_FORCE_PACKED_DP)    # the library keeps small batches on the int32 kernel
     rng = np.random.default_rng(41)
     G = 200000
     text = rng.integers(0, 4, G, dtype=np.uint8)

@@ -72,20 +72,20 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     reads[-20:] = rng.integers(0, 4, (20, M))            # unalignable reads
     if mode == "local":
         params = pipeline.SeedExtendParams()
-        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, traceback_stride=24)
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, traceback_stride=24, traceback_min_score=params.min_score_for(M))
     elif mode == "e2e-quals":                             # end-to-end with the quality ramp (mismatch -2..-6 by base quality)
         quals = rng.integers(0, 50, R * M, dtype=np.uint8)
         params = pipeline.SeedExtendParams.end_to_end(constant_quality=False)
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
-                                                scheme=oracle.Scheme(0, 2, 6, -8, -3, -8, -3), quals=quals, traceback_stride=24)
+                                                scheme=oracle.Scheme(0, 2, 6, -8, -3, -8, -3), quals=quals, traceback_stride=24, traceback_min_score=params.min_score_for(M))
     elif mode == "fmmap-ed":                              # examples/fmmap: semi-global edit distance (fmmap.cu:346-359)
         params = pipeline.SeedExtendParams(aln_type=oracle.SEMI_GLOBAL, scheme=amd.EditDistanceScheme(), min_score=-15)
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
-                                                scheme=oracle.Scheme(*oracle.ED_SCHEME), traceback_stride=24)
+                                                scheme=oracle.Scheme(*oracle.ED_SCHEME), traceback_stride=24, traceback_min_score=params.min_score_for(M))
     else:                                                 # nvBowtie default mode, constant quality
         params = pipeline.SeedExtendParams.end_to_end()
         want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, reads, aln_type=oracle.SEMI_GLOBAL,
-                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3), traceback_stride=24)
+                                                scheme=oracle.Scheme(0, 6, 6, -8, -3, -8, -3), traceback_stride=24, traceback_min_score=params.min_score_for(M))
         assert params.min_score_for(150) == -90
     rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(reads.reshape(-1)).view(np.int32)).cuda(), R, M,
                             quals=torch.from_numpy(quals).cuda() if mode == "e2e-quals" else None)

@@ -17,10 +17,10 @@ def _i64(t):
 
 
 @pytest.fixture(params=["shortcut", "dp-only"])
-def tb_mode(request, monkeypatch):
+def tb_mode(request, monkeypatch, amd):
     """the ungapped shortcut (default) and the plain DP-for-every-job path must both equal the reference"""
     if request.param == "dp-only":
-        monkeypatch.setenv("NVBIO_AMD_NO_UNGAPPED_TRACEBACK", "1")
+        monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_UNGAPPED_TRACEBACK)
     return request.param
 
 
