@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
 TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
-SEED_KERNEL_TAG = "fm_seed_tiles_kernel<4>"
+SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"
 
 
 def log(msg):

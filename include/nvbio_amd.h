@@ -183,7 +183,9 @@ enum
                                     (mapping_inl.h:264-279)                                                   */
     NVBIO_FM_NO_KMER_TABLE = 4,  /* step every symbol through rank() even if the handle has a table         */
     NVBIO_FM_NO_VERIFY     = 8,  /* never take the SA/ISA verification shortcut even if the handle has it   */
-    NVBIO_FM_COUNT_SECTORS = 16  /* nvbio_fm_match_seed_diagonals only: an accounting launch (see there)        */
+    NVBIO_FM_COUNT_SECTORS = 16, /* nvbio_fm_match_seed_diagonals only: an accounting launch (see there)        */
+    NVBIO_FM_NO_PIPELINE   = 32  /* nvbio_fm_match_seed_diagonals only: the plain kernel, one tile at a time,
+                                    also where the software-pipelined one applies (A/B; same results)         */
 };
 
 /* ranges_dev[i] = SA range (inclusive; empty iff x > y) of query i: nvbio::match / match_reverse
@@ -322,6 +324,50 @@ nvbio_status nvbio_hits_to_diagonals(int device, const nvbio_uint2* hits_dev, ui
 nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, uint32_t read_len,
                                         uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
                                         uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * nvBowtie's scoring stream, as data: what a specialisation of aln::BatchedBandedAlignmentScore for
+ * bowtie2::cuda::BestScoreStream (nvBowtie/bowtie2/cuda/score_inl.h:44-136) hands over instead of per-item callbacks.
+ * The arrays are the members of the stream's pipeline object (pipeline_states.h:49-115, scoring_queues.h:211-289), all in HBM:
+ *   idx_queue_dev    pipeline.idx_queue: work item i scores hit idx_queue[i] (NULL: hit i)            (score_inl.h:89)
+ *   hit_read_id_dev  pipeline.scoring_queues.hits.read_id
+ *   hit_seed_dev     pipeline.scoring_queues.hits.seed, one packed_seed word per hit (defs.h:162-172: pos_in_read:12,
+ *                    index_dir:1, rc:1, top_flag:1 from bit 0; only rc is read)
+ *   hit_loc_dev      pipeline.scoring_queues.hits.loc                                                  (score_inl.h:100)
+ *   hit_score_dev / hit_sink_dev   pipeline.scoring_queues.hits.score / .sink: the stream's output   (score_inl.h:127-129)
+ *   n                pipeline.hits_queue_size = stream.size()
+ * ------------------------------------------------------------------------------------------- */
+typedef struct
+{
+    const uint32_t* idx_queue_dev;
+    const uint32_t* hit_read_id_dev;
+    const uint32_t* hit_seed_dev;
+    const uint32_t* hit_loc_dev;
+    int32_t*        hit_score_dev;
+    uint32_t*       hit_sink_dev;
+    uint32_t        n;
+} nvbio_hit_queues;
+
+/* BestScoreStream::init_context + the orientation of load_strings for every work item (score_inl.h:85-115, alignment_utils.h:277-302):
+ * the four per-job arrays of an nvbio_alignment_batch.  read_index_dev = the read batch's sequence_index (n_reads + 1 symbol
+ * offsets, io::SequenceData); band_len = the stream's m_band_len; genome_len = pipeline.genome_length; reads_reversed = 1 when
+ * the read batch was loaded with io::REVERSE, as nvBowtie does (nvBowtie.cpp:322,337,356): a forward hit then reads the stored
+ * stream backwards (NVBIO_READ_REVERSE) and a reverse-complemented one forwards, complemented (NVBIO_READ_COMPLEMENT).
+ * (context->min_score = max(second best, score_limit) is not needed: whole-pattern banded scoring never reads it,
+ * gotoh_banded_inl.h:610-622 is the windowed form only.) */
+nvbio_status nvbio_score_stream_flatten(int device, const nvbio_hit_queues* hits, const uint32_t* read_index_dev, uint32_t band_len,
+                                        uint32_t genome_len, uint32_t reads_reversed, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                        uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream);
+/* BestScoreStream::output for every work item (score_inl.h:119-133): hit.score = max( score, worst_score ) (scheme_type::worst_score
+ * = -65536, scoring.h:223-224), hit.sink = window begin + sink.x, scattered through idx_queue. */
+nvbio_status nvbio_score_stream_output(int device, const nvbio_hit_queues* hits, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                       const uint32_t* win_begin_dev, int32_t worst_score, void* stream);
+
+/* Two conversions a binding of sw-benchmark's stream needs (sw-benchmark/sw-benchmark.cu:70-209): its reference text is packed
+ * 2-bit LITTLE-endian (REF_BIG_ENDIAN = false, :64-65; the library reads the big-endian layout of io::SequenceData<DNA>), and its
+ * output() stores `sink.score` into an int16 array (:197). */
+nvbio_status nvbio_text_2bit_le_to_be(int device, const uint32_t* in_dev, uint32_t n_words, uint32_t* out_dev, void* stream);
+nvbio_status nvbio_scores_to_int16(int device, const int32_t* scores_dev, uint32_t n, int16_t* out_dev, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Gotoh scoring

@@ -27,7 +27,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
-FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS = 1, 2, 4, 8, 16
+FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS, FM_NO_PIPELINE = 1, 2, 4, 8, 16, 32
 FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS = 1, 2, 4      # nvbio_fm_build_options::table_flags
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
@@ -82,6 +82,12 @@ class _Batch(ctypes.Structure):
                 ("text_dev", ctypes.c_void_p), ("text_bits", ctypes.c_uint32),
                 ("win_begin_dev", ctypes.c_void_p), ("win_end_dev", ctypes.c_void_p), ("n", ctypes.c_uint32),
                 ("max_read_len", ctypes.c_uint32), ("algo_flags", ctypes.c_uint32)]
+
+
+class _HitQueues(ctypes.Structure):
+    _fields_ = [("idx_queue_dev", ctypes.c_void_p), ("hit_read_id_dev", ctypes.c_void_p), ("hit_seed_dev", ctypes.c_void_p),
+                ("hit_loc_dev", ctypes.c_void_p), ("hit_score_dev", ctypes.c_void_p), ("hit_sink_dev", ctypes.c_void_p),
+                ("n", ctypes.c_uint32)]
 
 
 _lib = None
@@ -859,3 +865,47 @@ def diagonals_to_windows(keys, band, read_len, genome_len):
 def u32(t):
     """int32 device/host tensor -> numpy uint32 (results are uint32 bit patterns)"""
     return t.detach().cpu().numpy().view(np.uint32)
+
+
+# ---- nvBowtie's scoring stream as data (nvbio_hit_queues) ------------------------------------------------------------------------
+class HitQueues:
+    """the members of nvBowtie's scoring pipeline a BestScoreStream reads and writes (pipeline_states.h:49-115,
+    scoring_queues.h:211-289), as int32 device tensors: idx_queue (or None), read_id, seed (packed_seed words), loc, score, sink"""
+
+    def __init__(self, read_id, seed, loc, idx_queue=None, device="cuda:0"):
+        torch = _torch()
+        self.device = device
+        self.read_id = _dev_tensor(read_id, torch.int32, device)
+        self.seed = _dev_tensor(seed, torch.int32, device)
+        self.loc = _dev_tensor(loc, torch.int32, device)
+        self.idx_queue = _dev_tensor(idx_queue, torch.int32, device)
+        self.n = int(self.idx_queue.numel() if self.idx_queue is not None else self.read_id.numel())
+        self.score = torch.zeros(self.read_id.numel(), dtype=torch.int32, device=device)
+        self.sink = torch.zeros(self.read_id.numel(), dtype=torch.int32, device=device)
+
+    def c_struct(self):
+        return _HitQueues(_ptr(self.idx_queue), _ptr(self.read_id), _ptr(self.seed), _ptr(self.loc), _ptr(self.score), _ptr(self.sink), self.n)
+
+
+def score_stream_flatten(hits, read_index, band_len, genome_len, reads_reversed=True):
+    """BestScoreStream::init_context + load_strings' orientation for the whole stream (nvbio_score_stream_flatten) ->
+    (read_id, flags, win_begin, win_end): the per-job arrays of an AlignmentBatch"""
+    torch = _torch()
+    dev = hits.device
+    ri = _dev_tensor(read_index, torch.int32, dev)
+    rid = torch.empty(hits.n, dtype=torch.int32, device=dev)
+    flags = torch.empty(hits.n, dtype=torch.uint8, device=dev)
+    wb = torch.empty(hits.n, dtype=torch.int32, device=dev)
+    we = torch.empty(hits.n, dtype=torch.int32, device=dev)
+    hq = hits.c_struct()
+    _check(lib().nvbio_score_stream_flatten(FMIndex._dev_index(dev), ctypes.byref(hq), _ptr(ri), ctypes.c_uint32(band_len),
+                                            ctypes.c_uint32(genome_len), ctypes.c_uint32(1 if reads_reversed else 0), _ptr(rid), _ptr(flags),
+                                            _ptr(wb), _ptr(we), _stream_ptr(dev)))
+    return rid, flags, wb, we
+
+
+def score_stream_output(hits, scores, sinks, win_begin, worst_score=-65536):
+    """BestScoreStream::output for the whole stream (nvbio_score_stream_output): fills hits.score / hits.sink"""
+    hq = hits.c_struct()
+    _check(lib().nvbio_score_stream_output(FMIndex._dev_index(hits.device), ctypes.byref(hq), _ptr(scores), _ptr(sinks), _ptr(win_begin),
+                                           ctypes.c_int32(worst_score), _stream_ptr(hits.device)))

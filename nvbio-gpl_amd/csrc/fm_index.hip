@@ -340,6 +340,53 @@ struct SeedTiles
     uint32_t n_tiles;
 };
 
+// One round of a tile's output: every lane's search result (single: x = text position; several rows: the range (x, y)) to
+//   * the tile's keys, in seed order, a key equal to its predecessor dropped -- ballot + popcount, the predecessor's key
+//     through ds_bpermute: no LDS, no barrier;
+//   * the residual list, one atomic per wave that has any seed on several rows.
+__device__ __forceinline__ void emit_seed_results(const StringSetDev& q, const uint32_t len, const uint32_t read_len, const uint32_t strand, const uint32_t lane,
+                                                  const bool valid, const bool single, const uint32_t x, const uint32_t y, const uint32_t rid, const uint32_t j,
+                                                  const uint32_t i, uint64_t* __restrict__ tile_slots, uint32_t& n_out, uint64_t& last_key,
+                                                  uint2* __restrict__ res_ranges, uint32_t* __restrict__ res_ids, unsigned int* __restrict__ counts)
+{
+    const bool multi = valid && !single && x < y;
+    uint64_t key = 0;
+    if (single)
+    {
+        uint32_t p = j * q.interval;
+        if (strand) p = read_len - p - len;
+        key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
+    }
+    const uint64_t m1 = __ballot( single );
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint64_t prev_mask = m1 & below;
+    const int      prev_lane = prev_mask ? 63 - __clzll( (long long)prev_mask ) : 0;
+    const uint32_t pk_lo = (uint32_t)__shfl( (int)(uint32_t)key, prev_lane ), pk_hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), prev_lane );
+    const uint64_t prev_key = prev_mask ? (((uint64_t)pk_hi << 32) | pk_lo) : last_key;
+    const bool     keep = single && key != prev_key;
+    const uint64_t m3 = __ballot( keep );
+    if (keep) tile_slots[n_out + (uint32_t)__popcll( m3 & below )] = key;
+    n_out += (uint32_t)__popcll( m3 );
+    if (m1)                                                  // the last single key of this round, for the next round's first
+    {
+        const int hl = 63 - __clzll( (long long)m1 );
+        const uint32_t lo = (uint32_t)__shfl( (int)(uint32_t)key, hl ), hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), hl );
+        last_key = ((uint64_t)hi << 32) | lo;
+    }
+    const uint64_t m2 = __ballot( multi );
+    if (m2)
+    {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd( &counts[1], (unsigned int)__popcll( m2 ) );
+        base = (uint32_t)__shfl( (int)base, 0 );
+        if (multi)
+        {
+            const uint32_t r = base + (uint32_t)__popcll( m2 & below );
+            res_ranges[r] = make_uint2( x, y ); res_ids[r] = i;
+        }
+    }
+}
+
 // COUNT: an accounting launch (untimed; bench.py's roofline): additionally sums, into sectors_out[0], the distinct 64-byte
 // sectors every search gathers from the index (table entry, group, bwt_occ records, SA word, text words)
 template <int BITS, bool COUNT = false>
@@ -407,61 +454,134 @@ fm_seed_tiles_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl,
                 for (int d = 32; d > 0; d >>= 1) tot += (uint32_t)__shfl_xor( (int)tot, d );
                 if (lane == 0 && tot) atomicAdd( sectors_out, (unsigned long long)tot );
             }
-            const bool multi = valid && !single && x < y;
-            uint64_t key = 0;
-            if (single)
-            {
-                uint32_t p = j * q.interval;
-                if (strand) p = read_len - p - len;
-                key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
-            }
-            // ---- the wave's keys in seed order, a key equal to its predecessor dropped ----
-            const uint64_t m1 = __ballot( single );
-            const uint64_t below = (1ull << lane) - 1ull;
-            const uint64_t prev_mask = m1 & below;
-            const int      prev_lane = prev_mask ? 63 - __clzll( (long long)prev_mask ) : 0;
-            const uint32_t pk_lo = (uint32_t)__shfl( (int)(uint32_t)key, prev_lane ), pk_hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), prev_lane );
-            const uint64_t prev_key = prev_mask ? (((uint64_t)pk_hi << 32) | pk_lo) : last_key;
-            const bool     keep = single && key != prev_key;
-            const uint64_t m3 = __ballot( keep );
-            if (keep) tile_keys[(uint64_t)tile * 64u * rounds + n_out + (uint32_t)__popcll( m3 & below )] = key;
-            n_out += (uint32_t)__popcll( m3 );
-            if (m1)                                                  // the last single key of this round, for the next round's first
-            {
-                const int hl = 63 - __clzll( (long long)m1 );
-                const uint32_t lo = (uint32_t)__shfl( (int)(uint32_t)key, hl ), hi = (uint32_t)__shfl( (int)(uint32_t)(key >> 32), hl );
-                last_key = ((uint64_t)hi << 32) | lo;
-            }
-            // ---- seeds on several rows: one atomic per wave that has any ----
-            const uint64_t m2 = __ballot( multi );
-            if (m2)
-            {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd( &counts[1], (unsigned int)__popcll( m2 ) );
-                base = (uint32_t)__shfl( (int)base, 0 );
-                if (multi)
-                {
-                    const uint32_t r = base + (uint32_t)__popcll( m2 & below );
-                    res_ranges[r] = make_uint2( x, y ); res_ids[r] = i;
-                }
-            }
+            emit_seed_results( q, len, read_len, strand, lane, valid, single, x, y, rid, j, i, tile_keys + (uint64_t)tile * 64u * rounds, n_out, last_key,
+                               res_ranges, res_ids, counts );
         }
         if (lane == 0) tile_counts[tile] = n_out;
     }
 }
 
-// keys of tile t -> keys_out[offsets[t] ...]; the last tile also writes the total
+// The same pass as a three-stage software pipeline over the tiles a wave owns (seeds of up to 32 symbols whose remainder after
+// the table's k fits the stored context; at most 64 seeds per read): while tile t is resolved from its table entries -- the
+// group gather of the few seeds whose k-mer has 2..7 occurrences is issued first -- the table entries of tile t+1 are
+// requested from the seed bits decoded out of words loaded one iteration earlier, and the packed words of tile t+2 are
+// loaded.  The three dependent round trips of a seed (read words -> table entry -> group) thus overlap across tiles: one
+// memory latency per iteration instead of three.
+template <int BITS>
+__global__ void __launch_bounds__(256)
+fm_seed_pipe_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, const uint32_t flags, const uint32_t read_len, const uint32_t strand,
+                    uint64_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_counts, uint2* __restrict__ res_ranges,
+                    uint32_t* __restrict__ res_ids, unsigned int* __restrict__ counts)
+{
+    const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
+    const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t len = q.fixed_len, r = len - f.dkmer;
+    const uint32_t lr = lane / q.spr, j = lane - lr * q.spr;          // the lane's read within a tile and its seed: the same for every tile
+    const bool lane_ok = lr < tl.rpt;
+
+    auto seed_begin = [&](const uint32_t rid) -> uint32_t { return (q.offsets ? q.offsets[rid] : rid * q.stride) + j * q.interval; };
+
+    uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= tl.n_tiles) return;
+    // prologue: words of this tile and of the next one, table entry of this tile
+    SeedWords W = { 0, 0, 0, 0, 0 }; uint32_t w_begin = 0; bool w_valid = false;     // stage 1 -> 2: tile + n_waves after the prologue
+    uint64_t V = 0; uint2 e = make_uint2( 1u, 0u ); bool e_valid = false;            // stage 2 -> 3: the current tile
+    {
+        const uint32_t rid = tile * tl.rpt + lr;
+        if (lane_ok && rid < tl.reads)
+        {
+            const uint32_t b0 = seed_begin( rid );
+            const SeedWords W0 = load_seed_words<BITS>( q.symbols, b0, len );
+            e_valid = seed_bits_from_words<BITS>( W0, b0, len, fwd, comp, V );
+            if (e_valid) e = load_table_entry( f.dtab, V >> (2u * r), true );
+        }
+        const uint32_t t1 = tile + n_waves, rid1 = t1 * tl.rpt + lr;
+        if (t1 < tl.n_tiles && lane_ok && rid1 < tl.reads) { w_begin = seed_begin( rid1 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); w_valid = true; }
+    }
+    for (; tile < tl.n_tiles; tile += n_waves)
+    {
+        const uint32_t rid = tile * tl.rpt + lr;
+        const bool valid = lane_ok && rid < tl.reads;
+        // ---- stage 3a: what kind of entry; request the group of a 2..7-occurrence k-mer ----
+        const uint32_t rest = (uint32_t)(V & ((1ull << (2u * r)) - 1ull));
+        const bool is_rng   = e_valid && e.y < f.dmark;
+        const bool is_one   = e_valid && e.y >= f.dmark && e.x < f.dmark;
+        const bool is_group = e_valid && e.y >= f.dmark && e.x >= f.dmark;
+        uint4 q0 = make_uint4( 0, 0, 0, 0 ), q1 = q0, q2 = q0, q3 = q0;
+        const uint32_t m = e.y - f.dmark;
+        if (is_group)
+        {
+            const uint4* g4 = (const uint4*)(f.side + 4ull * (e.x - f.dmark));
+            q0 = g4[0]; q1 = g4[1];
+            if (m > 3u) { q2 = g4[2]; q3 = g4[3]; }
+        }
+        // ---- stage 2 for the next tile: seed bits from the words loaded one iteration ago, its table entry requested ----
+        uint64_t Vn = 0; uint2 en = make_uint2( 1u, 0u ); bool en_valid = false;
+        if (w_valid)
+        {
+            en_valid = seed_bits_from_words<BITS>( W, w_begin, len, fwd, comp, Vn );
+            if (en_valid) en = load_table_entry( f.dtab, Vn >> (2u * r), true );
+        }
+        // ---- stage 1 for the tile after next: its packed words ----
+        {
+            const uint32_t t2 = tile + 2u * n_waves, rid2 = t2 * tl.rpt + lr;
+            w_valid = t2 < tl.n_tiles && lane_ok && rid2 < tl.reads;
+            if (w_valid) { w_begin = seed_begin( rid2 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); }
+        }
+        // ---- stage 3b: resolve the current tile ----
+        uint32_t x = 1u, y = 0u; bool single = false;
+        if (is_one)
+        {
+            if (context_matches( e.x, e.y - f.dmark, rest, r )) { x = y = e.x - r; single = true; }
+        }
+        else if (is_rng) { x = e.x; y = e.y; }
+        else if (is_group)
+        {
+            uint32_t hits = 0, pos = 0;
+#define NVB_SIDE_ROW(jj, P, C) if ((jj) <= m && context_matches( (P), (C) - f.dmark, rest, r )) { ++hits; pos = (P); }
+            NVB_SIDE_ROW( 1u, q0.z, q0.w ) NVB_SIDE_ROW( 2u, q1.x, q1.y ) NVB_SIDE_ROW( 3u, q1.z, q1.w )
+            NVB_SIDE_ROW( 4u, q2.x, q2.y ) NVB_SIDE_ROW( 5u, q2.z, q2.w ) NVB_SIDE_ROW( 6u, q3.x, q3.y ) NVB_SIDE_ROW( 7u, q3.z, q3.w )
+#undef NVB_SIDE_ROW
+            if (hits == 1u)     { x = y = pos - r; single = true; }
+            else if (hits > 1u) { x = q0.x; y = q0.y; }             // a repeat longer than the seed: its SA range needs the rank steps
+        }
+        if (!single && x <= y)                                       // k-mers with many occurrences (and true repeats): rank steps, then the text
+        {
+            auto sym = [&](const uint32_t s) -> uint32_t { return (uint32_t)(V >> (2u * (len - 1u - s))) & 3u; };
+            SearchState st;
+            st.x = x; st.y = y; st.s = f.dkmer; st.have_pos = false; st.tpos = 0; st.have_ctx = false; st.ctx = 0; st.is_pos = false; st.sectors = 0;
+            uint32_t nblk = 0;
+            search_tail<false,true>( f, sym, len, false, st, nblk );
+            x = st.x; y = st.y; single = st.is_pos;
+            if (!single && x == y)                                   // one row left when the pattern ran out: its position
+            {
+                const uint32_t sv = f.ssa[x];
+                x = (sv == 0xFFFFFFFFu) ? f.length : sv; single = true;
+            }
+        }
+        uint32_t n_out = 0; uint64_t last_key = ~0ull;
+        emit_seed_results( q, len, read_len, strand, lane, valid, single, x, y, rid, j, rid * q.spr + j, tile_keys + (uint64_t)tile * 64u, n_out, last_key,
+                           res_ranges, res_ids, counts );
+        if (lane == 0) tile_counts[tile] = n_out;
+        V = Vn; e = en; e_valid = en_valid;
+    }
+}
+
+// keys of tile t -> keys_out[offsets[t] ...]; the last tile also writes the total.  One LANE per tile: a tile holds a handful of
+// keys (3.8 on the benchmark), so a lane copies its tile's keys one by one while counts and offsets are read coalesced
+// (one wave per tile, the first version, spent 0.2 ms per launch starting 1.4 M waves that copied four keys each).
 __global__ void __launch_bounds__(256)
 fm_seed_compact_kernel(const uint64_t* __restrict__ tile_keys, const uint32_t* __restrict__ tile_counts, const uint32_t* __restrict__ tile_offsets,
                        const uint32_t n_tiles, const uint32_t slots, uint64_t* __restrict__ keys_out, unsigned int* __restrict__ counts)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * 4u;
-    for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves)
+    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += gridDim.x * blockDim.x)
     {
         const uint32_t n = tile_counts[tile], off = tile_offsets[tile];
-        for (uint32_t k = lane; k < n; k += 64u) keys_out[off + k] = tile_keys[(uint64_t)tile * slots + k];
-        if (tile == n_tiles - 1u && lane == 0) counts[0] = off + n;
+        const uint64_t* src = tile_keys + (uint64_t)tile * slots;
+        for (uint32_t k = 0; k < n; ++k) keys_out[off + k] = src[k];
+        if (tile == n_tiles - 1u) counts[0] = off + n;
     }
 }
 
@@ -1375,8 +1495,13 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     const unsigned cap = (flags >> 16) ? (flags >> 16) * 64u : 256u * 64u;
     if (blocks > cap) blocks = cap;
     const dim3 grid( blocks ), block( 256 );
+    // the pipelined kernel serves the production shape: packed seeds of up to 32 symbols resolved by the direct table's contexts
+    const bool pipe = !count && !(flags & NVBIO_FM_NO_PIPELINE) && seeds->symbol_bits != 8 && q.spr <= 64u && q.fixed_len <= 32u && f.dtab != nullptr &&
+                      f.ktab != nullptr && !(flags & NVBIO_FM_NO_KMER_TABLE) && f.dctx != 0u && q.fixed_len >= f.dkmer && q.fixed_len - f.dkmer <= f.dctx;
 #define NVB_LAUNCH_SD(BITS) \
-    if (count) hipLaunchKernelGGL( (fm_seed_tiles_kernel<BITS,true>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
+    if (pipe)  hipLaunchKernelGGL( (fm_seed_pipe_kernel<(BITS == 8 ? 4 : BITS)>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
+                                   (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev );                                              \
+    else if (count) hipLaunchKernelGGL( (fm_seed_tiles_kernel<BITS,true>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
                                    (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev, (unsigned long long*)(counts_dev + 2) );       \
     else       hipLaunchKernelGGL( (fm_seed_tiles_kernel<BITS,false>), grid, block, 0, s, f, q, L.tl, flags & 0xFFFFu, read_len, strand, tile_keys, tile_counts, \
                                    (uint2*)residual_ranges_dev, residual_ids_dev, (unsigned int*)counts_dev, (unsigned long long*)nullptr )
@@ -1392,7 +1517,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( blocks ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, L.slots, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }

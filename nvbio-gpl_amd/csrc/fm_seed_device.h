@@ -73,19 +73,34 @@ __device__ __forceinline__ uint64_t reverse_symbols(uint64_t v, const uint32_t l
     return v >> (64u - 2u * len);
 }
 
+// the (up to 5) packed words that hold a seed: loaded in one go, decoded later (the pipelined seed pass loads the words of
+// the tile after next while it works on the current one)
+struct SeedWords { uint32_t w0, w1, w2, w3, w4; };
+
 template <int BITS>
-__device__ __forceinline__ bool seed_bits(const void* __restrict__ symbols, const uint32_t begin, const uint32_t len, const bool fwd, const bool comp,
-                                          uint64_t& V)
+__device__ __forceinline__ SeedWords load_seed_words(const void* __restrict__ symbols, const uint32_t begin, const uint32_t len)
+{
+    constexpr uint32_t LOG = (BITS == 4) ? 3u : 4u;                          // symbols per word: 8 (4-bit) or 16 (2-bit)
+    const uint32_t* w = (const uint32_t*)symbols + (begin >> LOG);
+    const uint32_t nw = ((begin + len - 1u) >> LOG) - (begin >> LOG) + 1u;   // words that hold the seed: only those are touched
+    SeedWords W;
+    W.w0 = w[0];
+    W.w1 = nw > 1u ? w[1] : 0u;
+    W.w2 = nw > 2u ? w[2] : 0u;
+    W.w3 = (BITS == 4 && nw > 3u) ? w[3] : 0u;
+    W.w4 = (BITS == 4 && nw > 4u) ? w[4] : 0u;
+    return W;
+}
+
+template <int BITS>
+__device__ __forceinline__ bool seed_bits_from_words(const SeedWords& W, const uint32_t begin, const uint32_t len, const bool fwd, const bool comp, uint64_t& V)
 {
     // stream order first: symbol j of the seed at bits [2(len-1-j), +2)
-    uint64_t P = 0; bool clean = true;
+    uint64_t P; bool clean = true;
     if (BITS == 4)
     {
-        const uint32_t* w = (const uint32_t*)symbols + (begin >> 3);
         const uint32_t sh = (begin & 7u) * 4u;
-        const uint32_t nw = ((begin + len - 1u) >> 3) - (begin >> 3) + 1u;     // 1..5 words hold the seed
-        const uint32_t w0 = w[0], w1 = nw > 1u ? w[1] : 0u, w2 = nw > 2u ? w[2] : 0u, w3 = nw > 3u ? w[3] : 0u, w4 = nw > 4u ? w[4] : 0u;
-        const uint64_t A = ((uint64_t)w0 << 32) | w1, B = ((uint64_t)w2 << 32) | w3, C = (uint64_t)w4 << 32;
+        const uint64_t A = ((uint64_t)W.w0 << 32) | W.w1, B = ((uint64_t)W.w2 << 32) | W.w3, C = (uint64_t)W.w4 << 32;
         const uint64_t X = sh ? (A << sh) | (B >> (64u - sh)) : A;             // nibbles 0..15 of the seed
         const uint64_t Y = sh ? (B << sh) | (C >> (64u - sh)) : B;             // nibbles 16..31
         const uint64_t mx = len >= 16u ? ~0ull : ~0ull << (64u - 4u * len);
@@ -93,23 +108,32 @@ __device__ __forceinline__ bool seed_bits(const void* __restrict__ symbols, cons
         clean = (((X & mx) | (Y & my)) & 0xCCCCCCCCCCCCCCCCull) == 0ull;
         P = ((squeeze_nibbles( X ) << 32) | squeeze_nibbles( Y )) >> (64u - 2u * len);
     }
-    else if (BITS == 2)
-    {
-        const uint32_t* w = (const uint32_t*)symbols + (begin >> 4);
-        const uint32_t sh = (begin & 15u) * 2u;
-        const uint32_t nw = ((begin + len - 1u) >> 4) - (begin >> 4) + 1u;     // 1..3 words
-        const uint32_t w0 = w[0], w1 = nw > 1u ? w[1] : 0u, w2 = nw > 2u ? w[2] : 0u;
-        const uint64_t A = ((uint64_t)w0 << 32) | w1, C = (uint64_t)w2 << 32;
-        P = (sh ? (A << sh) | (C >> (64u - sh)) : A) >> (64u - 2u * len);
-    }
     else
     {
-        const uint8_t* b = (const uint8_t*)symbols + begin;
-        for (uint32_t j = 0; j < len; ++j) { const uint32_t c = b[j]; clean = clean && c < 4u; P = (P << 2) | (c & 3u); }
+        const uint32_t sh = (begin & 15u) * 2u;
+        const uint64_t A = ((uint64_t)W.w0 << 32) | W.w1, C = (uint64_t)W.w2 << 32;
+        P = (sh ? (A << sh) | (C >> (64u - sh)) : A) >> (64u - 2u * len);
     }
     V = fwd ? P : reverse_symbols( P, len );
     if (comp) V ^= (len >= 32u) ? ~0ull : ((1ull << (2u * len)) - 1ull);
     return clean;
+}
+
+template <int BITS>
+__device__ __forceinline__ bool seed_bits(const void* __restrict__ symbols, const uint32_t begin, const uint32_t len, const bool fwd, const bool comp,
+                                          uint64_t& V)
+{
+    if (BITS == 8)
+    {
+        uint64_t P = 0; bool clean = true;
+        const uint8_t* b = (const uint8_t*)symbols + begin;
+        for (uint32_t j = 0; j < len; ++j) { const uint32_t c = b[j]; clean = clean && c < 4u; P = (P << 2) | (c & 3u); }
+        V = fwd ? P : reverse_symbols( P, len );
+        if (comp) V ^= (len >= 32u) ? ~0ull : ((1ull << (2u * len)) - 1ull);
+        return clean;
+    }
+    const SeedWords W = load_seed_words<(BITS == 8 ? 4 : BITS)>( symbols, begin, len );
+    return seed_bits_from_words<(BITS == 8 ? 4 : BITS)>( W, begin, len, fwd, comp, V );
 }
 
 // the r symbols that follow the first `done` ones in scan order, first one most significant (the layout of a left context

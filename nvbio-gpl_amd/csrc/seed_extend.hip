@@ -255,9 +255,118 @@ opposite_mate_windows_kernel(const uint32_t* __restrict__ g_pos, const uint8_t* 
     }
 }
 
+// nvBowtie's scoring stream, flattened: BestScoreStream::init_context for every work item of the stream
+// (nvBowtie/bowtie2/cuda/score_inl.h:85-115) -- the hit to score is hits[ idx_queue[i] ]; its read, strand (packed_seed::rc, bit 13
+// of the word: defs.h:162-172 `pos_in_read:12, index_dir:1, rc:1, top_flag:1`) and locus give the banded window
+// [ loc > band/2 ? loc - band/2 : 0,  min( begin + band + read_len, genome_length ) ) -- and the orientation load_strings asks the
+// read loader for (alignment_utils.h:291-296: nvBowtie stores its reads REVERSED, so a forward hit reads the stream backwards
+// and a reverse-complemented one reads it forwards, complemented).
+__global__ void __launch_bounds__(256)
+score_stream_flatten_kernel(const uint32_t* __restrict__ idx_queue, const uint32_t n, const uint32_t* __restrict__ hit_read_id,
+                            const uint32_t* __restrict__ hit_seed, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ read_index,
+                            const uint32_t band, const uint32_t genome_len, const uint32_t reads_reversed,
+                            uint32_t* __restrict__ read_id, uint8_t* __restrict__ flags, uint32_t* __restrict__ wb, uint32_t* __restrict__ we)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t idx = idx_queue ? idx_queue[i] : i;
+        const uint32_t rid = hit_read_id[idx];
+        const uint32_t rc  = (hit_seed[idx] >> 13) & 1u;
+        const uint32_t g   = hit_loc[idx];
+        const uint32_t len = read_index[rid + 1u] - read_index[rid];
+        const uint32_t b   = g > band / 2u ? g - band / 2u : 0u;
+        const uint32_t e   = b + band + len;                                   // uint32 arithmetic, as the reference's
+        read_id[i] = rid;
+        flags[i]   = reads_reversed ? (rc ? (uint8_t)NVBIO_READ_COMPLEMENT : (uint8_t)NVBIO_READ_REVERSE)
+                                    : (rc ? (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT) : (uint8_t)0);
+        wb[i] = b;
+        we[i] = e < genome_len ? e : genome_len;
+    }
+}
+
+// BestScoreStream::output (score_inl.h:119-133): hit.score = max( sink.score, worst_score ); hit.sink = genome_begin + sink.sink.x
+__global__ void __launch_bounds__(256)
+score_stream_output_kernel(const uint32_t* __restrict__ idx_queue, const uint32_t n, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                           const uint32_t* __restrict__ wb, const int32_t worst, int32_t* __restrict__ hit_score, uint32_t* __restrict__ hit_sink)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t idx = idx_queue ? idx_queue[i] : i;
+        const int32_t  s   = scores[i];
+        hit_score[idx] = s > worst ? s : worst;
+        hit_sink[idx]  = wb[i] + sinks[i].x;
+    }
+}
+
+// sw-benchmark keeps its reference text 2-bit LITTLE-endian (sw-benchmark/sw-benchmark.cu:64-65: symbol i at bits [2(i&15), +2)
+// of word i >> 4) and its scores as int16 (:197); the kernels here read big-endian text (io::SequenceData<DNA>) and write int32
+__global__ void __launch_bounds__(256)
+text_le_to_be_kernel(const uint32_t* __restrict__ in, const uint32_t n_words, uint32_t* __restrict__ out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x)
+    {
+        uint32_t v = __brev( in[i] );                                      // symbol order reversed, the two bits of each swapped
+        out[i] = ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);
+    }
+}
+__global__ void __launch_bounds__(256)
+scores_to_int16_kernel(const int32_t* __restrict__ in, const uint32_t n, int16_t* __restrict__ out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int16_t)in[i];   // as `m_scores[i] = sink.score`
+}
+
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;
+
+extern "C" nvbio_status nvbio_text_2bit_le_to_be(int device, const uint32_t* in_dev, uint32_t n_words, uint32_t* out_dev, void* stream)
+{
+    if (n_words == 0) return NVBIO_OK;
+    NVB_REQUIRE( in_dev && out_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( text_le_to_be_kernel, dim3( grid_for( n_words ) ), dim3(256), 0, (hipStream_t)stream, in_dev, n_words, out_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_scores_to_int16(int device, const int32_t* scores_dev, uint32_t n, int16_t* out_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( scores_dev && out_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( scores_to_int16_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, scores_dev, n, out_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_score_stream_flatten(int device, const nvbio_hit_queues* hits, const uint32_t* read_index_dev, uint32_t band_len,
+                                                   uint32_t genome_len, uint32_t reads_reversed, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                                   uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream)
+{
+    NVB_REQUIRE( hits != nullptr, "hits is NULL" );
+    if (hits->n == 0) return NVBIO_OK;
+    NVB_REQUIRE( hits->hit_read_id_dev && hits->hit_seed_dev && hits->hit_loc_dev && read_index_dev, "NULL device pointer in the hit queues" );
+    NVB_REQUIRE( read_id_dev && flags_dev && win_begin_dev && win_end_dev, "NULL output pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( score_stream_flatten_kernel, dim3( grid_for( hits->n ) ), dim3(256), 0, (hipStream_t)stream, hits->idx_queue_dev, hits->n,
+                        hits->hit_read_id_dev, hits->hit_seed_dev, hits->hit_loc_dev, read_index_dev, band_len, genome_len, reads_reversed,
+                        read_id_dev, flags_dev, win_begin_dev, win_end_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_score_stream_output(int device, const nvbio_hit_queues* hits, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                  const uint32_t* win_begin_dev, int32_t worst_score, void* stream)
+{
+    NVB_REQUIRE( hits != nullptr, "hits is NULL" );
+    if (hits->n == 0) return NVBIO_OK;
+    NVB_REQUIRE( hits->hit_score_dev && hits->hit_sink_dev && scores_dev && sinks_dev && win_begin_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( score_stream_output_kernel, dim3( grid_for( hits->n ) ), dim3(256), 0, (hipStream_t)stream, hits->idx_queue_dev, hits->n,
+                        scores_dev, (const uint2*)sinks_dev, win_begin_dev, worst_score, hits->hit_score_dev, hits->hit_sink_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
 
 extern "C" nvbio_status nvbio_opposite_mate_windows(int device, const uint32_t* g_pos_dev, const uint8_t* anchor_rc_dev, uint32_t n,
                                                     uint32_t anchor_len, uint32_t opposite_gapped_len, uint32_t anchor, uint32_t policy,

@@ -324,3 +324,39 @@ def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_
                                                    min_score_of(o.shape[1]))
         put(om, r, begin + src[0], cig)
     return out
+
+
+# ---- nvBowtie's scoring stream, restated (test infrastructure; parity unpinned: score_inl.h is device-only CUDA) ------------------
+def score_stream_flatten(idx_queue, hit_read_id, hit_seed, hit_loc, read_index, band_len, genome_len, reads_reversed=True):
+    """BestScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:85-115) and the read orientation load_strings requests
+    (alignment_utils.h:291-296: `read_rc ? FORWARD : REVERSE`, `read_rc ? COMPLEMENT : STANDARD` over reads stored reversed),
+    one work item at a time.  packed_seed (defs.h:162-172): pos_in_read:12, index_dir:1, rc:1, top_flag:1 from bit 0.
+    Returns (read_id, flags, genome_begin, genome_end) as the per-job arrays of an alignment batch
+    (flags: 1 = read the stored stream reversed, 2 = complemented)."""
+    n = len(idx_queue) if idx_queue is not None else len(hit_read_id)
+    rid = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint8)
+    wb = np.zeros(n, dtype=np.uint32); we = np.zeros(n, dtype=np.uint32)
+    for i in range(n):
+        idx = int(idx_queue[i]) if idx_queue is not None else i                      # context->idx = idx_queue[i]             (:89)
+        read_id = int(hit_read_id[idx])                                               # hit.read_id                            (:97)
+        read_rc = (int(hit_seed[idx]) >> 13) & 1                                      # hit.seed.rc                            (:96)
+        g_pos = int(hit_loc[idx])                                                     # hit.loc                                (:100)
+        read_len = int(read_index[read_id + 1]) - int(read_index[read_id])            # read_range.y - read_range.x            (:102)
+        begin = g_pos - band_len // 2 if g_pos > band_len // 2 else 0                 # genome_begin                           (:103)
+        end = min((begin + band_len + read_len) & 0xFFFFFFFF, genome_len)             # genome_end (uint32 arithmetic)         (:104)
+        if reads_reversed:
+            f = 2 if read_rc else 1                                                   # FORWARD + COMPLEMENT : REVERSE + STANDARD
+        else:
+            f = 3 if read_rc else 0
+        rid[i], flags[i], wb[i], we[i] = read_id, f, begin, end
+    return rid, flags, wb, we
+
+
+def score_stream_output(idx_queue, n_hits, scores, sinks, genome_begin, worst_score=-65536):
+    """BestScoreStream::output (score_inl.h:119-133): hit.score = max(sink.score, worst_score); hit.sink = genome_begin + sink.sink.x"""
+    hit_score = np.zeros(n_hits, dtype=np.int32); hit_sink = np.zeros(n_hits, dtype=np.uint32)
+    for i in range(len(scores)):
+        idx = int(idx_queue[i]) if idx_queue is not None else i
+        hit_score[idx] = max(int(scores[i]), worst_score)
+        hit_sink[idx] = (int(genome_begin[i]) + int(sinks[i][0])) & 0xFFFFFFFF
+    return hit_score, hit_sink

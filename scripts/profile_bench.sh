@@ -22,4 +22,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU 
 echo "sq done"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_tcc -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_tcc.json 2> $OUT/${TAG}_tcc.err
 echo "tcc done"
+# 6. address translation (UTCL1) and 7. fabric read requests by size, each in its own pass
+FAST="$ARGS --no-plain-ab --no-traceback"
+rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum --output-format csv -d $OUT/${TAG}_utcl -- python3 $REPO/bench.py $FAST > $OUT/${TAG}_utcl.json 2> $OUT/${TAG}_utcl.err || echo "utcl pass failed"
+echo "utcl done"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum --output-format csv -d $OUT/${TAG}_ea -- python3 $REPO/bench.py $FAST > $OUT/${TAG}_ea.json 2> $OUT/${TAG}_ea.err || echo "ea pass failed"
+echo "ea done"
 find $OUT -name "*.csv" | head -50

@@ -188,7 +188,8 @@ def test_headline_pipeline_three_ways(amd, headline):
     (bs, bp, brc, nc) = outs[0]
     for o in outs[1:]:
         assert torch.equal(o[0], bs) and torch.equal(o[1], bp) and torch.equal(o[2], brc)
-        assert nc <= o[3] <= nc * 1.10                            # the separate operators dedupe less
+        assert abs(o[3] - nc) <= nc // 100                        # the two routes drop slightly different duplicates (a repeat's hits
+                                                                  # are deduplicated in line by one, on their own list by the other)
     params = pipeline.SeedExtendParams.end_to_end()
     aligned = bs >= params.min_score_for(h["M"])
     near = (bp - (h["truth_pos"] + h["M"])).abs() <= 40

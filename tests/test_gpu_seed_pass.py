@@ -40,10 +40,10 @@ def _expected(orc, hidx, reads, M, L, S, strand):
     return ks[keep], {int(s): (int(a), int(b)) for s, a, b in zip(sid[multi], x[multi], y[multi])}
 
 
-def _run(amd, fmi, packed, bits, R, M, L, S, strand, grid_blocks=0):
+def _run(amd, fmi, packed, bits, R, M, L, S, strand, grid_blocks=0, extra_flags=0):
     spr = (M - L) // S + 1
     qs = amd.PackedStringSet(packed, bits, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
-    flags = (amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT) if strand else 0
+    flags = ((amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT) if strand else 0) | extra_flags
     b = fmi.match_seed_diagonals(qs, flags, M, strand, grid_blocks=grid_blocks)
     nk, nr = [int(v) for v in b["counts"][:2].cpu().numpy()]
     keys = b["keys"][:nk].cpu().numpy()
@@ -67,7 +67,7 @@ def _text(rng, n):
 
 def _reads(rng, text, R, M):
     n = len(text)
-    starts = rng.integers(0, n - M, R)
+    starts = rng.integers(0, n - M, max(R, 440))
     starts[0:8] = 0                                                # seeds at text position 0 (nothing to their left)
     starts[8:16] = np.arange(8)
     starts[16:32] = n - M - np.arange(16)                          # ... and in the last words of the text
@@ -75,6 +75,7 @@ def _reads(rng, text, R, M):
     starts[200:300] = 100000 + 700 * rng.integers(0, 3, 100) + rng.integers(0, 50, 100)
     starts[300:400] = 120000 + 900 * rng.integers(0, 5, 100) + rng.integers(0, 50, 100)
     starts[400:440] = 140000 + rng.integers(0, 200, 40)
+    starts = np.minimum(starts[:R], n - M)
     reads = np.stack([text[s:s + M] for s in starts]).copy()
     mut = rng.random(reads.shape) < 0.01
     reads[mut] = (reads[mut] + 1 + rng.integers(0, 3, int(mut.sum()))) % 4
@@ -99,9 +100,11 @@ def test_seed_pass_equals_the_operators(amd, orc, k, table_flags):
         for strand in (0, 1):
             want_keys, want_res = _expected(orc, hidx, reads, M, L, S, strand)
             for bits, packed in ((4, orc.pack4(flat)),):
-                keys, res = _run(amd, fmi, packed, bits, R, M, L, S, strand)
-                assert np.array_equal(keys, want_keys), (k, table_flags, L, S, strand, bits)
-                assert res == want_res, (k, table_flags, L, S, strand, bits)
+                # the default kernel choice (software-pipelined where it applies), the plain kernel, the accounting one
+                for extra in (0, amd.FM_NO_PIPELINE, amd.FM_COUNT_SECTORS):
+                    keys, res = _run(amd, fmi, packed, bits, R, M, L, S, strand, extra_flags=extra)
+                    assert np.array_equal(keys, want_keys), (k, table_flags, L, S, strand, bits, extra)
+                    assert res == want_res, (k, table_flags, L, S, strand, bits, extra)
             n_multi += len(want_res)
     assert n_multi > 500                                           # the residual route was really taken
     # a grid of 64 workgroups (256 waves) over 429 tiles: every wave loops
