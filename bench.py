@@ -361,8 +361,8 @@ def main():
         params.direct = prev_direct
         pst = {k: float(np.mean(event_ms(v))) for k, v in pt.items()}
         plain = {"ms_per_step": pdt * 1e3, "match_ms_per_launch": 0.5 * (pst.get("match_fw", 0.0) + pst.get("match_rc", 0.0)),
-                 "locate_ms_per_launch": pst.get("locate", 0.0), "extend_ms": pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0),
-                 "extend_gcups": float(pnc) * params.band * M / ((pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0)) * 1e-3) / 1e9,
+                 "locate_ms_per_launch": pst.get("locate", 0.0), "extend_ms": pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0) + pst.get("extend", 0.0),
+                 "extend_gcups": float(pnc) * params.band * M / ((pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0) + pst.get("extend", 0.0)) * 1e-3) / 1e9,
                  "kmer_table": (args.kmer - 1) if (fmi.supports_direct() and args.kmer >= 2) else args.kmer,   # the handle's plain table
                  "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
     match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
@@ -395,7 +395,7 @@ def main():
             if gj.get("footprint_bytes") == 128 << 30 and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
                 ceiling = gj.get("G_gathers_per_s")
     cells = float(nc) * params.band * M
-    extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0)
+    extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0) + stage_ms.get("extend", 0.0)
     step_ms = elapsed / args.steps * 1e3
     build = {"index_and_tables_s": build_s}
     if index_only_s is not None:

@@ -318,6 +318,13 @@ nvbio_status nvbio_hits_to_diagonals(int device, const nvbio_uint2* hits_dev, ui
                                      uint32_t seed_interval, uint32_t seed_len, uint32_t read_len, uint32_t strand,
                                      uint64_t* keys_dev, void* stream);
 
+/* Sort candidate keys and drop duplicates, in place: what fmmap does with its diagonals before extending them
+ * (examples/fmmap/fmmap.cu:320-344: sort_by_key + unique), for host compositions that have no device sort of their own.
+ * *n_out_dev (device) = number of distinct keys, left at the front of keys_dev in ascending order.
+ * temp_dev / temp_bytes: optional caller scratch (nvbio_sort_unique_keys_temp_bytes). */
+nvbio_status nvbio_sort_unique_keys_temp_bytes(uint64_t n, uint64_t* bytes);
+nvbio_status nvbio_sort_unique_keys(int device, uint64_t* keys_dev, uint64_t n, uint32_t* n_out_dev, void* temp_dev, uint64_t temp_bytes, void* stream);
+
 /* genome_infixes (examples/fmmap/fmmap.cu:169-196) with nvBowtie's window rule (BestScoreStream::init_context,
  * nvBowtie/bowtie2/cuda/score_inl.h:100-106): g_pos = max(diagonal,0); begin = g_pos > band/2 ? g_pos - band/2 : 0;
  * end = min(begin + band + read_len, genome_len); flags = strand ? REVERSE|COMPLEMENT : 0.                */

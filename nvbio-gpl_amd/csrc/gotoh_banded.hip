@@ -47,7 +47,9 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
     const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
     const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
     const uint32_t tb    = b.win_begin[job];
-    const uint32_t N     = b.win_end[job] - tb;
+    // a pattern longer than the batch's declared max_read_len is rejected -- nothing reported, as for a text shorter than the
+    // pattern -- in every kernel alike: the packed kernels rely on that bound for their 16-bit scores
+    const uint32_t N     = (b.max_read_len && M > b.max_read_len) ? 0u : b.win_end[job] - tb;
 
     int32_t  best   = NVBIO_SCORE_MIN;
     uint32_t best_x = 0xFFFFFFFFu, best_y = 0xFFFFFFFFu;
@@ -254,7 +256,7 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
         rev[u]  = (fl & NVBIO_READ_REVERSE) != 0;
         comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
         tb[u]   = b.win_begin[jj];
-        N[u]    = b.win_end[jj] - tb[u];
+        N[u]    = (b.max_read_len && M[u] > b.max_read_len) ? 0u : b.win_end[jj] - tb[u];     // too long for the declared bound: rejected
         // rows this alignment really computes: none when the text is shorter than the pattern (nothing reported)
         rows_all[u] = (valid[u] && N[u] >= M[u]) ? M[u] : 0u;
     }
@@ -521,7 +523,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
     const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
     const uint32_t tb    = b.win_begin[job];
-    const uint32_t N     = b.win_end[job] - tb;
+    const uint32_t N     = (b.max_read_len && M > b.max_read_len) ? 0u : b.win_end[job] - tb;       // too long for the declared bound: rejected
 
     if (N < M)                                                   // nothing reported (gotoh_banded_inl.h:422-423)
     {

@@ -7,6 +7,7 @@
 //   read orientation flags           nvBowtie/bowtie2/cuda/alignment_utils.h:291-296
 // Both kernels are pure streaming (coalesced 8-16 B per element in, 8-13 B out): HBM-bound.
 #include "common.h"
+#include <hipcub/hipcub.hpp>
 
 namespace nvbio_amd {
 
@@ -464,5 +465,44 @@ extern "C" nvbio_status nvbio_mapq(int device, const uint64_t* best_dev, const u
                         (const unsigned long long*)best_dev, (const unsigned long long*)second_dev, n_reads, (int)params->version,
                         params->monotone != 0, (float)params->perfect_score, (float)params->min_score, second_scores_dev, mapq_dev );
     NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+// sort + unique of candidate keys: what fmmap does with its diagonals before extending them (examples/fmmap/fmmap.cu:320-344:
+// sort_by_key on the diagonal, unique) for callers that have no device sort of their own (a C++ host composition over this ABI)
+extern "C" nvbio_status nvbio_sort_unique_keys_temp_bytes(uint64_t n, uint64_t* bytes)
+{
+    NVB_REQUIRE( bytes != nullptr, "bytes is NULL" );
+    NVB_REQUIRE( n < (1ull << 31), "n too large" );
+    size_t a = 0, b = 0;
+    NVB_HIP( hipcub::DeviceRadixSort::SortKeys( nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 64, (hipStream_t)0 ) );
+    NVB_HIP( hipcub::DeviceSelect::Unique( nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t)0 ) );
+    *bytes = (((a > b ? a : b) + 255u) & ~(uint64_t)255u) + n * sizeof(uint64_t) + 512u;
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_sort_unique_keys(int device, uint64_t* keys_dev, uint64_t n, uint32_t* n_out_dev, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( n_out_dev != nullptr, "n_out_dev is NULL" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { NVB_HIP( hipMemsetAsync( n_out_dev, 0, sizeof(uint32_t), s ) ); return NVBIO_OK; }
+    NVB_REQUIRE( keys_dev != nullptr, "keys_dev is NULL" );
+    uint64_t need = 0; NVB_CHECK( nvbio_sort_unique_keys_temp_bytes( n, &need ) );
+    uint8_t* temp = (uint8_t*)temp_dev; bool own = false;
+    if (!temp)
+    {
+        if (hipMallocAsync( (void**)&temp, need, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "sort_unique_keys: out of device memory" ); return NVBIO_ERR_NOMEM; }
+        own = true;
+    }
+    else NVB_REQUIRE( temp_bytes >= need, "temp_bytes too small (nvbio_sort_unique_keys_temp_bytes)" );
+    uint8_t*  base   = (uint8_t*)(((uintptr_t)temp + 255u) & ~(uintptr_t)255u);
+    uint64_t* sorted = (uint64_t*)base;
+    void*     work   = base + ((n * sizeof(uint64_t) + 255u) & ~(uint64_t)255u);
+    size_t    work_bytes = (size_t)(need - 512u - n * sizeof(uint64_t));
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys( work, work_bytes, (const uint64_t*)keys_dev, sorted, (int)n, 0, 64, s );
+    if (e == hipSuccess) e = hipcub::DeviceSelect::Unique( work, work_bytes, (const uint64_t*)sorted, keys_dev, n_out_dev, (int)n, s );
+    if (own) (void)hipFreeAsync( temp, s );
+    if (e != hipSuccess) { set_error( "sort_unique_keys failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }

@@ -172,6 +172,38 @@ inline void locate_ssa_iterator(const fm_index& fmi, const uint32_t* rows_dev, u
 inline void lookup_ssa_iterator(const fm_index& fmi, const nvbio_uint2* jt_dev, uint32_t n, uint32_t* pos_dev, hipStream_t stream = 0)
 { check( nvbio_fm_locate_lookup( fmi.handle(), jt_dev, n, pos_dev, stream ) ); }
 
+// the whole seed pass of one strand in one call (nvbio_fm_match_seed_diagonals): owner of its output arrays and scratch.
+// keys(): the diagonal keys of the seeds that end on one SA row, in seed order, duplicates within a read dropped;
+// residual_ranges() / residual_ids(): the seeds on several rows, for nvbio_fm_filter_scan + nvbio_fm_filter_locate_diagonals;
+// counts(): device pointer to { number of keys, number of residual seeds }
+class SeedPass
+{
+public:
+    explicit SeedPass(const string_set& seeds) : m_seeds( seeds )
+    {
+        const size_t n = seeds.size();
+        m_keys.resize( n ); m_ranges.resize( n ); m_ids.resize( n ); m_counts.resize( 4 );
+        uint64_t bytes = 0;
+        check( nvbio_fm_match_seed_diagonals_temp_bytes( &m_seeds.c, &bytes ) );
+        m_temp.resize( bytes );
+    }
+    void enact(const fm_index& fmi, uint32_t flags, uint32_t read_len, uint32_t strand, hipStream_t stream = 0)
+    {
+        check( nvbio_fm_match_seed_diagonals( fmi.handle(), &m_seeds.c, flags, read_len, strand, m_keys.data(), m_ranges.data(), m_ids.data(),
+                                              m_counts.data(), m_temp.data(), m_temp.size(), stream ) );
+    }
+    const uint64_t*    keys()            const { return m_keys.data(); }
+    const nvbio_uint2* residual_ranges() const { return m_ranges.data(); }
+    const uint32_t*    residual_ids()    const { return m_ids.data(); }
+    const uint32_t*    counts()          const { return m_counts.data(); }
+private:
+    string_set                 m_seeds;
+    device_vector<uint64_t>    m_keys;
+    device_vector<nvbio_uint2> m_ranges;
+    device_vector<uint32_t>    m_ids, m_counts;
+    device_vector<uint8_t>     m_temp;
+};
+
 template <typename system_tag> class FMIndexFilter;
 
 template <>

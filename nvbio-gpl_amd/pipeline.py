@@ -38,6 +38,8 @@ class SeedExtendParams:
         self.mapq = False                           # also keep nvBowtie's second-best alignment per read and compute the
                                                     # mapping quality (score_reduce + BowtieMapq2); results go to `extras`
         self.mapq_version = 2
+        self.merge_strands = True                   # one-call seed pass: extend the candidates of both strands in ONE batch (half the
+                                                    # launches, better-filled kernels) instead of strand by strand
         self.algo_flags = 0                         # nvbio_alignment_batch::algo_flags of the extension (ALN_*: A/B of the exact shortcuts)
 
     @classmethod
@@ -163,6 +165,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             ev = torch.cuda.Event()
             ev.record()
             pending.append((strand, b, ev))
+        merged = []
         for strand, b, ev in pending:
             ev.synchronize()
             n_keys, n_res = int(b["host"][0]), int(b["host"][1])
@@ -186,7 +189,12 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             if keys.numel() == 0:
                 continue
             n_cand += keys.numel()
-            results.append(extend(keys, "_rc" if strand else "_fw"))
+            if params.merge_strands:
+                merged.append(keys)
+            else:
+                results.append(extend(keys, "_rc" if strand else "_fw"))
+        if merged:
+            results.append(extend(merged[0] if len(merged) == 1 else torch.cat(merged), ""))
     for strand, flags in (() if fused else ((0, 0), (1, FM_SCAN_FORWARD | FM_COMPLEMENT))):
         # 2. exact-match every seed: SA ranges + inclusive scan of their sizes
         #    (FMIndexFilter::rank = match + scan; the two halves are called separately so that the

@@ -312,3 +312,35 @@ def test_end_to_end_shortcut_edge_cases(amd, orc):
         assert np.array_equal(amd.u32(sk), wsk), sv
     # the indel reads really are cases where a gapped alignment beats a 2-3 mismatch diagonal
     assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
+
+
+@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
+def test_jobs_longer_than_the_declared_bound_are_rejected(amd, orc, typ):
+    """nvbio_alignment_batch::max_read_len is what lets the library pick 16-bit kernels: a job whose pattern is longer than a
+    non-zero bound is rejected (score NVBIO_SCORE_MIN, sink (-1,-1)) by every kernel alike instead of being scored in registers
+    that could wrap; the other jobs are unaffected"""
+    typ = getattr(oracle, typ)
+    rng = np.random.default_rng(90)
+    G, R = 100000, 600
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = np.where(np.arange(R) % 7 == 0, 150, 100)                    # every 7th read is longer than the bound declared below
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(20, G - 200, R)
+    reads = np.concatenate([text[s:s + l] for s, l in zip(starts, lens)]).copy()
+    reads[rng.random(len(reads)) < 0.02] = rng.integers(0, 4)
+    wb = (starts - 15).astype(np.uint32); we = (wb + lens + 31).astype(np.uint32)
+    scheme = amd.GotohScheme(2, 6, 6, -8, -3, -8, -3) if typ == oracle.LOCAL else amd.GotohScheme(0, 6, 6, -8, -3, -8, -3)
+    osc = oracle.Scheme(*[int(getattr(scheme.c, f)) for f, _ in scheme.c._fields_])
+    want_s, want_k = orc.banded_gotoh_packed_batch(31, typ, osc, orc.pack4(reads), roffs, orc.pack2(text), wb, we)
+    long_ = lens > 100
+    for flags in (0, amd.ALN_NO_PACKED_DP, amd.ALN_NO_UNGAPPED_SCORE):
+        batch = amd.AlignmentBatch(orc.pack4(reads), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=100, algo_flags=flags)
+        sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, scheme), batch)
+        sc, sk = sc.cpu().numpy(), amd.u32(sk)
+        assert (sc[long_] == amd.SCORE_MIN).all() and (sk[long_] == 0xFFFFFFFF).all()
+        assert np.array_equal(sc[~long_], want_s[~long_]) and np.array_equal(sk[~long_], want_k[~long_])
+    # with an honest bound (or none) every job is scored
+    for mrl in (150, 0):
+        batch = amd.AlignmentBatch(orc.pack4(reads), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=mrl)
+        sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, scheme), batch)
+        assert np.array_equal(sc.cpu().numpy(), want_s) and np.array_equal(amd.u32(sk), want_k)
