@@ -391,6 +391,41 @@ class Oracle:
                                   ctypes.c_uint32(read_len), ctypes.c_int32(worst_score), out.ctypes.data_as(ctypes.c_void_p))
         return tuple(int(v) for v in out)
 
+    def hit_deque_run(self, ops, begins, bits, max_hits):
+        """a sequence of operations on nvBowtie's per-read seed-hit deque (0 push under the max_hits rule, 1 pop_top, 2 pop_bottom,
+        3 select's in-place row pop) -> (heap array [size, 2] as it lies in memory, rows returned by the select ops)"""
+        ops, begins, bits = _c32(ops), _c32(begins), _c32(bits)
+        n = len(ops)
+        heap = np.zeros((n + 1, 2), dtype=np.uint32); size = ctypes.c_uint32(0); rows = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.orc_hit_deque_run(_p(ops, _u32p), _p(begins, _u32p), _p(bits, _u32p), ctypes.c_uint32(n), ctypes.c_uint32(max_hits),
+                    _p(heap, _u32p), ctypes.byref(size), _p(rows, _u32p))
+        return heap[:size.value].copy(), rows[:n].copy()
+    def map_exact_read(self, fw, rc, seed_off, read_len, seed_len, max_hits, rep_seeds):
+        """seed_mapper<EXACT_MAPPING> + map_kernel bookkeeping for one read (mapping_inl.h:193-282,485-556) -> (deque [n, 2], reseed)"""
+        fw = np.ascontiguousarray(fw, dtype=np.uint32); rc = np.ascontiguousarray(rc, dtype=np.uint32); seed_off = _c32(seed_off)
+        deque = np.zeros((max(2 * len(seed_off), 1), 2), dtype=np.uint32); size = ctypes.c_uint32(0)
+        reseed = self.lib.orc_map_exact_read(_p(fw, _u32p), _p(rc, _u32p), _p(seed_off, _u32p), ctypes.c_uint32(len(seed_off)),
+                                             ctypes.c_uint32(read_len), ctypes.c_uint32(seed_len), ctypes.c_uint32(max_hits),
+                                             ctypes.c_uint32(rep_seeds), _p(deque, _u32p), ctypes.byref(size))
+        return deque[:size.value].copy(), bool(reseed)
+
+    def select_read(self, deque, top_flag):
+        """select_kernel for one read (select_inl.h:62-130); deque [n, 2] is updated in place (returned with its new size)
+        -> (selected, sa_pos, packed_seed, top_flag, deque)"""
+        buf = np.zeros((len(deque) + 1, 2), dtype=np.uint32); buf[:len(deque)] = deque
+        size = ctypes.c_uint32(len(deque)); tf = ctypes.c_uint32(top_flag); row = ctypes.c_uint32(0); seed = ctypes.c_uint32(0)
+        ok = self.lib.orc_select_read(_p(buf, _u32p), ctypes.byref(size), ctypes.byref(tf), ctypes.byref(row), ctypes.byref(seed))
+        return bool(ok), row.value, seed.value, tf.value, buf[:size.value].copy()
+
+    def score_reduce_effort(self, best, trys, score, g_pos, read_rc, top_flag, read_len, ext, max_effort, min_ext, max_ext):
+        """score_reduce_kernel for one hit with ReduceBestApproxContext (reduce_inl.h:65-140, reduce.h:55-99); best = [a1 score, a1 pos,
+        a1 rc, a2 score, a2 pos, a2 rc] -> (best, trys, erase)"""
+        b = np.array(best, dtype=np.int64); t = ctypes.c_uint32(trys)
+        erase = self.lib.orc_score_reduce_effort(b.ctypes.data_as(ctypes.c_void_p), ctypes.byref(t), ctypes.c_int32(score), ctypes.c_uint32(g_pos),
+                                                 ctypes.c_uint32(read_rc), ctypes.c_uint32(top_flag), ctypes.c_uint32(read_len), ctypes.c_uint32(ext),
+                                                 ctypes.c_uint32(max_effort), ctypes.c_uint32(min_ext), ctypes.c_uint32(max_ext))
+        return [int(v) for v in b], t.value, bool(erase)
+
     def mapq(self, version, monotone, perfect_score, min_score, best_score, has_second, second_score):
         """BowtieMapq2 / BowtieMapq3, single-end (nvBowtie/bowtie2/cuda/mapq.h)"""
         return int(self.lib.orc_mapq(ctypes.c_int(version), ctypes.c_int(1 if monotone else 0), ctypes.c_int32(perfect_score),
@@ -450,6 +485,16 @@ class Reference:
         L.ref_fm_words.restype = ctypes.c_uint32
         L.ref_fm_ssa_words.restype = ctypes.c_uint32
         L.ref_fm_rank.restype = ctypes.c_uint32
+
+    def hit_deque_run(self, ops, begins, bits, max_hits):
+        """a sequence of operations on nvBowtie's per-read seed-hit deque (0 push under the max_hits rule, 1 pop_top, 2 pop_bottom,
+        3 select's in-place row pop) -> (heap array [size, 2] as it lies in memory, rows returned by the select ops)"""
+        ops, begins, bits = _c32(ops), _c32(begins), _c32(bits)
+        n = len(ops)
+        heap = np.zeros((n + 1, 2), dtype=np.uint32); size = ctypes.c_uint32(0); rows = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.ref_hit_deque_run(_p(ops, _u32p), _p(begins, _u32p), _p(bits, _u32p), ctypes.c_uint32(n), ctypes.c_uint32(max_hits),
+                    _p(heap, _u32p), ctypes.byref(size), _p(rows, _u32p))
+        return heap[:size.value].copy(), rows[:n].copy()
 
     def build_index(self, text):
         text = _c8(text)

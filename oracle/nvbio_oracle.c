@@ -1352,3 +1352,205 @@ int orc_mapq(int version, int monotone, int32_t perfect_score, int32_t minimum_s
     else if (bd > 0)            return (best_over >= diff * 0.5f) ? 11 : 2;
     return (best_over >= diff * 0.5f) ? 1 : 0;
 }
+
+
+/* =====================================================================================================================
+ * nvBowtie's seed-hit deques, hit selection and effort-limited reduction.
+ *
+ * SeedHit (nvBowtie/bowtie2/cuda/seed_hit.h:45-218): 8 bytes, word 0 = range_begin, word 1 = range_delta:20 | pos:10 | rc:1 | indexdir:1
+ * (bit 0 up), the SA range EXCLUSIVE at its end.  A read's hits live in a priority_deque<SeedHit, ., hit_compare>
+ * (seed_hit_deque_array.h:145, seed_hit.h:220-229: f goes before s iff size(f) > size(s)), the interval heap of
+ * nvbio/basic/priority_deque.h + interval_heap.h: element 0 is the "minimum" under that order -- the LARGEST range, what
+ * pop_bottom() drops when the deque is full -- and top() = element 1 (element 0 of a one-element deque) the SMALLEST range, what
+ * select pops rows from.  Elements of equal size are ordered by the heap's own moves, so those moves are restated one by one
+ * (pinned on the reference's priority_deque itself: oracle/ref ref_hit_deque_run, tests/golden/deque_golden.npz).
+ * ===================================================================================================================== */
+static uint32_t hit_size(const orc_seed_hit* h) { return h->bits & 0xFFFFFu; }
+static int hit_before(const orc_seed_hit* f, const orc_seed_hit* s) { return hit_size( f ) > hit_size( s ); }      /* hit_compare */
+static void hit_swap(orc_seed_hit* a, uint32_t i, uint32_t j) { const orc_seed_hit t = a[i]; a[i] = a[j]; a[j] = t; }
+
+/* sift_up<left_bound> (interval_heap.h:370-391): towards the root along the low (left) or high ends */
+static void heap_up(orc_seed_hit* a, uint32_t i, int low, uint32_t limit)
+{
+    while (i >= limit)
+    {
+        const uint32_t par = ((i / 2u - 1u) | 1u) ^ (low ? 1u : 0u);
+        if (low ? hit_before( &a[i], &a[par] ) : hit_before( &a[par], &a[i] )) { hit_swap( a, i, par ); i = par; }
+        else break;
+    }
+}
+/* sift_leaf_max / sift_leaf_min (:394-439): a leaf first against the other end of its interval, then up */
+static void heap_leaf_high(orc_seed_hit* a, uint32_t n, uint32_t i, uint32_t limit)
+{
+    const uint32_t co = (i * 2u < n) ? i * 2u : (i ^ 1u);
+    if (hit_before( &a[i], &a[co] )) { hit_swap( a, i, co ); heap_up( a, co, 1, limit ); }
+    else heap_up( a, i, 0, limit );
+}
+static void heap_leaf_low(orc_seed_hit* a, uint32_t n, uint32_t i, uint32_t limit)
+{
+    uint32_t co = i | 1u;
+    if (co >= n)
+    {
+        if (co == 1u) return;                                             /* a single element */
+        co = (co / 2u - 1u) | 1u;
+    }
+    if (hit_before( &a[co], &a[i] )) { hit_swap( a, i, co ); heap_up( a, co, 0, limit ); }
+    else heap_up( a, i, 1, limit );
+}
+/* sift_down<left_bound> (:442-503): the hole moves to a leaf along the smaller low / larger high children, then the leaf rules */
+static void heap_down(orc_seed_hit* a, uint32_t n, uint32_t i, int low, uint32_t limit)
+{
+    const int32_t ep = (int32_t)(n / 2u) - ((low && (n & 3u) == 0u) ? 2 : 1);     /* one past the last element with two children (signed: -1 for tiny heaps) */
+    while ((int32_t)i < ep)
+    {
+        uint32_t c = i * 2u + (low ? 2u : 1u);
+        if (hit_before( &a[c + (low ? 2u : 0u)], &a[c + (low ? 0u : 2u)] )) c += 2u;
+        hit_swap( a, i, c ); i = c;
+    }
+    if ((int32_t)i <= ep + (low ? 0 : 1))
+    {
+        uint32_t c = i * 2u + (low ? 2u : 1u);
+        if (c < n)
+        {
+            if (!low && c + 1u < n && hit_before( &a[c], &a[c + 1u] ))
+            {
+                ++c; hit_swap( a, i, c ); i = c;
+                heap_leaf_low( a, n, i, limit );
+                return;
+            }
+            hit_swap( a, i, c ); i = c;
+        }
+    }
+    if (low) heap_leaf_low( a, n, i, limit ); else heap_leaf_high( a, n, i, limit );
+}
+
+void orc_hit_deque_push(orc_seed_hit* a, uint32_t* n, orc_seed_hit x)           /* priority_deque::push -> push_interval_heap */
+{
+    a[*n] = x; ++*n;
+    const uint32_t i = *n - 1u;
+    if (i & 1u) heap_leaf_high( a, *n, i, 2u ); else heap_leaf_low( a, *n, i, 2u );
+}
+void orc_hit_deque_pop_bottom(orc_seed_hit* a, uint32_t* n)                      /* pop_interval_heap_min: drops the LARGEST range */
+{
+    const uint32_t last = *n - 1u;
+    hit_swap( a, 0u, last );
+    heap_down( a, last, 0u, 1, 2u );
+    *n = last;
+}
+void orc_hit_deque_pop_top(orc_seed_hit* a, uint32_t* n)                         /* pop_interval_heap_max: drops the SMALLEST range */
+{
+    if (*n > 2u)
+    {
+        const uint32_t last = *n - 1u;
+        hit_swap( a, 1u, last );
+        heap_down( a, last, 1u, 0, 2u );
+    }
+    --*n;
+}
+uint32_t orc_hit_deque_top(uint32_t n) { return n > 1u ? 1u : 0u; }              /* priority_deque::maximum */
+
+/* map_kernel's loop over the seeds of ONE read with seed_mapper<EXACT_MAPPING> (mapping_inl.h:485-556,193-282; USE_REVERSE_INDEX 0),
+ * given what match_range returned for every seed: fw[j] = the forward scan over the stored (reversed) read, rc[j] = the reverse
+ * scan complemented, both INCLUSIVE ranges, empty iff x > y (a seed with an N has both empty, :235-236).
+ * seed j starts `seed_off[j]` symbols into the stored read.  Returns the reseeding decision (:547-556). */
+int orc_map_exact_read(const uint32_t* fw, const uint32_t* rc, const uint32_t* seed_off, uint32_t n_seeds, uint32_t read_len, uint32_t seed_len,
+                       uint32_t max_hits, uint32_t rep_seeds, orc_seed_hit* deque, uint32_t* deque_size)
+{
+    uint32_t n = 0, range_sum = 0, range_count = 0;
+    for (uint32_t j = 0; j < n_seeds; ++j)
+    {
+        for (int strand = 0; strand < 2; ++strand)
+        {
+            const uint32_t x = strand ? rc[2 * j] : fw[2 * j], y = strand ? rc[2 * j + 1] : fw[2 * j + 1];
+            if (x > y) continue;
+            /* SeedHit::build_flags( STANDARD, FORWARD, read_range.y - pos - seed_len ) / ( COMPLEMENT, FORWARD, pos - read_range.x ) */
+            const uint32_t pos = strand ? seed_off[j] : read_len - seed_off[j] - seed_len;
+            orc_seed_hit h;
+            h.begin = x;
+            h.bits  = ((y + 1u - x) & 0xFFFFFu) | ((pos & 0x3FFu) << 20) | ((uint32_t)strand << 30);     /* inclusive_to_exclusive */
+            if (n == max_hits) orc_hit_deque_pop_bottom( deque, &n );
+            orc_hit_deque_push( deque, &n, h );
+            range_sum += y - x + 1u; ++range_count;
+        }
+    }
+    *deque_size = n;
+    return (range_count == 0u || range_sum >= rep_seeds * range_count) ? 1 : 0;
+}
+
+/* select_kernel for ONE active read (select_inl.h:62-130): the next SA row of the read's top hit.
+ * Returns 0 when the read leaves the active queue (no hits left); else 1 with *sa_pos, *packed_seed
+ * (defs.h:162-172: pos_in_read:12 | index_dir:1 | rc:1 | top_flag:1) and the updated *top_flag.  (context.stop, i.e. trys == 0,
+ * is the caller's test.) */
+int orc_select_read(orc_seed_hit* deque, uint32_t* size, uint32_t* top_flag, uint32_t* sa_pos, uint32_t* packed_seed)
+{
+    if (*size == 0u) return 0;
+    orc_seed_hit* hit = &deque[orc_hit_deque_top( *size )];
+    if (hit_size( hit ) == 0u)                                           /* get_range().x >= get_range().y: exhausted */
+    {
+        orc_hit_deque_pop_top( deque, size );
+        if (*size == 0u) return 0;
+        hit = &deque[orc_hit_deque_top( *size )];
+        *top_flag = 0u;
+    }
+    *sa_pos = hit->begin;                                                /* pop_front(): begin++, delta-- */
+    hit->begin += 1u;
+    hit->bits = (hit->bits & ~0xFFFFFu) | ((hit_size( hit ) - 1u) & 0xFFFFFu);
+    const uint32_t pos = (hit->bits >> 20) & 0x3FFu, rcf = (hit->bits >> 30) & 1u, dir = (hit->bits >> 31) & 1u;
+    *packed_seed = pos | (dir << 12) | (rcf << 13) | (*top_flag << 14);
+    return 1;
+}
+
+/* score_reduce_kernel for ONE hit of one read with ReduceBestApproxContext (reduce_inl.h:65-140, reduce.h:55-99).
+ * best = { a1 score, a1 pos, a1 rc, a2 score, a2 pos, a2 rc } (positions 0xFFFFFFFF = unaligned, scores start at worst_score:
+ * aligner.h:279-301); *trys the read's effort counter; ext = extensions done before this pass + index of the hit in the pass.
+ * Returns 1 if the read's deque must be erased (pipeline.hits.erase: the search stops). */
+int orc_score_reduce_effort(int64_t best[6], uint32_t* trys, int32_t score, uint32_t g_pos, uint32_t read_rc, uint32_t top_flag, uint32_t read_len,
+                            uint32_t ext, uint32_t max_effort, uint32_t min_ext, uint32_t max_ext)
+{
+    if ((read_rc == (uint32_t)best[2] && g_pos == (uint32_t)best[1]) || (read_rc == (uint32_t)best[5] && g_pos == (uint32_t)best[4])) return 0;
+    if (score > (int32_t)best[0])
+    {
+        *trys = max_effort;                                              /* context.best_score */
+        best[3] = best[0]; best[4] = best[1]; best[5] = best[2];
+        best[0] = score; best[1] = g_pos; best[2] = read_rc;
+    }
+    else if (score > (int32_t)best[3] && distinct_alignments( (uint32_t)best[1], (int)best[2], g_pos, (int)read_rc, read_len / 2u ))
+    {
+        *trys = max_effort;                                              /* context.second_score */
+        best[3] = score; best[4] = g_pos; best[5] = read_rc;
+    }
+    else if (*trys > 0u)                                                 /* context.failure */
+    {
+        if ((ext >= min_ext && top_flag == 0u && --*trys == 0u) || ext >= max_ext) return 1;
+    }
+    return 0;
+}
+
+/* a sequence of deque operations (the driver of oracle/ref ref_hit_deque_run, same op codes: 0 push under the max_hits rule,
+ * 1 pop_top, 2 pop_bottom, 3 select's in-place row pop) -- for pinning the heap moves on the reference's container */
+void orc_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32_t* bits, uint32_t n_ops, uint32_t max_hits,
+                       uint32_t* heap_out, uint32_t* size_out, uint32_t* out_rows)
+{
+    orc_seed_hit* a = (orc_seed_hit*)malloc( ((size_t)n_ops + 1u) * sizeof(orc_seed_hit) );
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < n_ops; ++k)
+    {
+        out_rows[k] = 0xFFFFFFFFu;
+        if (ops[k] == 0u)
+        {
+            const orc_seed_hit h = { begins[k], bits[k] };
+            if (n == max_hits) orc_hit_deque_pop_bottom( a, &n );
+            orc_hit_deque_push( a, &n, h );
+        }
+        else if (ops[k] == 1u) { if (n) orc_hit_deque_pop_top( a, &n ); }
+        else if (ops[k] == 2u) { if (n) orc_hit_deque_pop_bottom( a, &n ); }
+        else
+        {
+            uint32_t top_flag = 1u, row = 0xFFFFFFFFu, seed = 0u;
+            if (orc_select_read( a, &n, &top_flag, &row, &seed )) out_rows[k] = row;
+        }
+    }
+    *size_out = n;
+    for (uint32_t k = 0; k < n; ++k) { heap_out[2 * k] = a[k].begin; heap_out[2 * k + 1] = a[k].bits; }
+    free( a );
+}

@@ -213,6 +213,22 @@ void orc_score_reduce(const int32_t* scores, const uint32_t* pos, const uint8_t*
                       int64_t out[8]);
 int  orc_mapq(int version, int monotone, int32_t perfect_score, int32_t min_score, int32_t best_score, int has_second, int32_t second_score);
 
+/* nvBowtie's seed-hit deques (seed_hit.h, seed_hit_deque_array.h, nvbio/basic/priority_deque.h + interval_heap.h), exact seed mapper
+ * bookkeeping (mapping_inl.h:193-282,485-556), select_kernel (select_inl.h:62-130) and the effort-limited score_reduce
+ * (reduce_inl.h:65-140 with ReduceBestApproxContext, reduce.h:55-99); see nvbio_oracle.c */
+typedef struct { uint32_t begin; uint32_t bits; } orc_seed_hit;     /* bits: range_delta:20 | pos:10 | rc:1 | indexdir:1 */
+void     orc_hit_deque_push(orc_seed_hit* a, uint32_t* n, orc_seed_hit x);
+void     orc_hit_deque_pop_bottom(orc_seed_hit* a, uint32_t* n);
+void     orc_hit_deque_pop_top(orc_seed_hit* a, uint32_t* n);
+uint32_t orc_hit_deque_top(uint32_t n);
+int      orc_map_exact_read(const uint32_t* fw, const uint32_t* rc, const uint32_t* seed_off, uint32_t n_seeds, uint32_t read_len, uint32_t seed_len,
+                            uint32_t max_hits, uint32_t rep_seeds, orc_seed_hit* deque, uint32_t* deque_size);
+int      orc_select_read(orc_seed_hit* deque, uint32_t* size, uint32_t* top_flag, uint32_t* sa_pos, uint32_t* packed_seed);
+void     orc_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32_t* bits, uint32_t n_ops, uint32_t max_hits,
+                           uint32_t* heap_out, uint32_t* size_out, uint32_t* out_rows);
+int      orc_score_reduce_effort(int64_t best[6], uint32_t* trys, int32_t score, uint32_t g_pos, uint32_t read_rc, uint32_t top_flag, uint32_t read_len,
+                                 uint32_t ext, uint32_t max_effort, uint32_t min_ext, uint32_t max_ext);
+
 #ifdef __cplusplus
 }
 #endif

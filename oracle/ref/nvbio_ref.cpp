@@ -17,6 +17,11 @@
 //   aln::banded_alignment_score<BAND>                 nvbio/alignment/gotoh/gotoh_banded_inl.h:397-688
 //   aln::alignment_score (text / pattern blocking)    nvbio/alignment/gotoh/gotoh_inl.h:444-1256
 //   aln::BestSink<int32>                              nvbio/alignment/sink_inl.h:31-49
+//   priority_deque + interval heap                    nvbio/basic/priority_deque.h, interval_heap.h (the container of nvBowtie's
+//                                                     seed-hit deques, seed_hit_deque_array.h:145; the element type SeedHit and its
+//                                                     comparator live in nvBowtie/bowtie2/cuda/seed_hit.h, which pulls thrust device
+//                                                     vectors and does not compile host-only: the driver passes a user-side element
+//                                                     with the same two words and the same ordering, size(f) > size(s))
 //
 // The sampled suffix array type is a template parameter of nvbio::fm_index
 // (interface: nvbio/fmindex/ssa.h:67-74).  nvbio/fmindex/ssa.h itself pulls in
@@ -34,6 +39,7 @@
 #include <nvbio/fmindex/fmindex.h>
 #include <nvbio/fmindex/backtrack.h>
 #include <nvbio/alignment/alignment.h>
+#include <nvbio/basic/priority_deque.h>
 #include <vector>
 #include <cstring>
 #include <cstdint>
@@ -810,6 +816,52 @@ void ref_full_gotoh_batch(int type, int blocking, int match, int mm, int gap_ope
             txts + txt_off[i], txt_off[i+1] - txt_off[i],
             min_score, scores + i, sinks + 2*i );
     }
+}
+
+
+// A sequence of operations on nvBowtie's per-read hit deque, run on the reference's own priority_deque:
+//   op 0: push (begin, bits) the way seed_mapper<EXACT_MAPPING>::enact does (mapping_inl.h:242-244: pop_bottom first when the
+//         deque holds max_hits elements)
+//   op 1: pop_top     op 2: pop_bottom
+//   op 3: what select_kernel does to the top hit (select_inl.h:96-118): pop an exhausted top first, then take a row off its
+//         front in place -- begin + 1, size - 1, no re-heapify; out_rows receives the row (0xFFFFFFFF if the deque was empty)
+// heap_out / *size_out: the underlying array afterwards.
+struct RefSeedHit { uint32 begin; uint32 bits; uint32 get_range_size() const { return bits & 0xFFFFFu; } };
+struct ref_hit_compare { bool operator() (const RefSeedHit& f, const RefSeedHit& s) { return f.get_range_size() > s.get_range_size(); } };
+
+void ref_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32_t* bits, uint32_t n_ops, uint32_t max_hits,
+                       uint32_t* heap_out, uint32_t* size_out, uint32_t* out_rows)
+{
+    std::vector<RefSeedHit> storage( n_ops + 1u );
+    typedef vector_view<RefSeedHit*> vec_t;
+    priority_deque<RefSeedHit, vec_t, ref_hit_compare> heap( vec_t( 0, &storage[0] ), true );
+    for (uint32 k = 0; k < n_ops; ++k)
+    {
+        out_rows[k] = 0xFFFFFFFFu;
+        if (ops[k] == 0u)
+        {
+            RefSeedHit h = { begins[k], bits[k] };
+            if (heap.size() == max_hits) heap.pop_bottom();
+            heap.push( h );
+        }
+        else if (ops[k] == 1u) { if (heap.size()) heap.pop_top(); }
+        else if (ops[k] == 2u) { if (heap.size()) heap.pop_bottom(); }
+        else
+        {
+            if (heap.size() == 0) continue;
+            RefSeedHit* hit = const_cast<RefSeedHit*>( &heap.top() );
+            if (hit->get_range_size() == 0u)
+            {
+                heap.pop_top();
+                if (heap.size() == 0) continue;
+                hit = const_cast<RefSeedHit*>( &heap.top() );
+            }
+            out_rows[k] = hit->begin;
+            hit->begin += 1u; hit->bits = (hit->bits & ~0xFFFFFu) | ((hit->get_range_size() - 1u) & 0xFFFFFu);
+        }
+    }
+    *size_out = uint32( heap.size() );
+    for (uint32 k = 0; k < heap.size(); ++k) { heap_out[2*k] = storage[k].begin; heap_out[2*k+1] = storage[k].bits; }
 }
 
 } // extern "C"

@@ -403,6 +403,42 @@ def make_bt(R):
     print("bt_golden.npz: %d queries, %d..%d ranges" % (Q, nrs.min(), nrs.max()))
 
 
+def deque_cases(seed=2026, n_cases=600):
+    """operation sequences on a read's seed-hit deque: nvBowtie's order (pushes under the max_hits rule, then selects) and mixed ones;
+    many ties (most seeds have one occurrence), a few large ranges"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(n_cases):
+        n = int(rng.integers(1, 80)); mh = int(rng.integers(1, 24)) if t % 4 else 100
+        npush = int(rng.integers(1, n + 1))
+        ops = np.zeros(n, dtype=np.uint32)
+        if t % 3 == 0:
+            ops[:] = rng.choice([0, 0, 0, 1, 2, 3], n)
+        else:
+            ops[npush:] = rng.choice([3, 3, 3, 3, 1, 2], n - npush)
+        begins = rng.integers(0, 3_000_000_000, n).astype(np.uint32)
+        sizes = rng.choice([1, 1, 1, 1, 2, 3, 5, 40, 1000], n).astype(np.uint32)
+        bits = (sizes | (rng.integers(0, 1024, n).astype(np.uint32) << 20) | (rng.integers(0, 2, n).astype(np.uint32) << 30)).astype(np.uint32)
+        cases.append((ops, begins, bits, mh))
+    return cases
+
+
+def make_deque(R):
+    """the reference's own priority_deque (nvbio/basic/priority_deque.h + interval_heap.h, the container of nvBowtie's seed-hit deques)
+    driven through those sequences: the heap array as it lies in memory afterwards, and the rows the select steps returned"""
+    cases = deque_cases()
+    off = np.zeros(len(cases) + 1, dtype=np.int64); hoff = np.zeros(len(cases) + 1, dtype=np.int64)
+    ops_all, beg_all, bit_all, rows_all, heaps, mhs = [], [], [], [], [], []
+    for k, (ops, begins, bits, mh) in enumerate(cases):
+        heap, rows = R.hit_deque_run(ops, begins, bits, mh)
+        ops_all.append(ops); beg_all.append(begins); bit_all.append(bits); rows_all.append(rows); heaps.append(heap.reshape(-1, 2)); mhs.append(mh)
+        off[k + 1] = off[k] + len(ops); hoff[k + 1] = hoff[k] + len(heap)
+    np.savez_compressed(os.path.join(HERE, "deque_golden.npz"), ops=np.concatenate(ops_all), begins=np.concatenate(beg_all),
+                        bits=np.concatenate(bit_all), rows=np.concatenate(rows_all), off=off, heaps=np.concatenate(heaps), hoff=hoff,
+                        max_hits=np.array(mhs, dtype=np.uint32))
+    print("deque_golden.npz: %d sequences, %d operations" % (len(cases), off[-1]))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -415,3 +451,4 @@ if __name__ == "__main__":
     make_sw(R)
     make_best2(R)
     make_bt(R)
+    make_deque(R)

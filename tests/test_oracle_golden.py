@@ -434,3 +434,68 @@ def test_score_reduce_in_descending_order_is_best_and_best_distinct(orc):
     assert orc.mapq(2, True, 0, -90, -90, False, 0) == 0 and orc.mapq(2, True, 0, -90, -91, False, 0) == 0
     assert orc.mapq(2, True, 0, -90, -6, True, -6) == 1 and orc.mapq(2, True, 0, -90, 0, True, -90) == 39
     assert orc.mapq(2, False, 300, 50, 300, False, 0) == 44 and orc.mapq(2, False, 300, 50, 300, True, 300) == 1
+
+
+def test_seed_hit_deque_golden(orc, deque_golden):
+    """nvBowtie's per-read seed-hit deque: the oracle's restatement of the interval heap leaves the array exactly as the reference's
+    own priority_deque does (nvbio/basic/priority_deque.h, driven by oracle/ref ref_hit_deque_run) after 600 operation sequences
+    -- pushes under the max_hits rule, pop_top / pop_bottom, select's in-place row pops -- and returns the same rows"""
+    g = deque_golden
+    for k in range(len(g["max_hits"])):
+        a, b = int(g["off"][k]), int(g["off"][k + 1])
+        heap, rows = orc.hit_deque_run(g["ops"][a:b], g["begins"][a:b], g["bits"][a:b], int(g["max_hits"][k]))
+        assert np.array_equal(heap, g["heaps"][int(g["hoff"][k]):int(g["hoff"][k + 1])]), k
+        assert np.array_equal(rows, g["rows"][a:b]), k
+
+
+def test_exact_mapper_select_and_effort_rules(orc):
+    """the bookkeeping around the deque, restated from device-only code (parity unpinned beyond the container): the exact mapper keeps
+    the max_hits smallest ranges and asks for reseeding on repetitive reads; select walks the ranges smallest first, row by row;
+    the effort counter stops a read after max_effort failures in a row past min_ext"""
+    # 5 seeds: fw ranges of sizes 1, 3, -, 50, 1 and rc ranges -, 2, -, -, 1000 (inclusive); max_hits = 4
+    fw = np.array([[10, 10], [20, 22], [1, 0], [100, 149], [7, 7]], dtype=np.uint32)
+    rc = np.array([[1, 0], [30, 31], [1, 0], [1, 0], [1000, 1999]], dtype=np.uint32)
+    off = np.arange(5) * 15
+    deque, reseed = orc.map_exact_read(fw, rc, off, 150, 22, 4, 1000)
+    sizes = sorted(int(b & 0xFFFFF) for b in deque[:, 1])
+    # a full deque drops its LARGEST range before every push, whatever the newcomer's size (mapping_inl.h:242-244): the 50-row range
+    # goes when the fifth hit arrives, the 3-row one when the 1000-row range arrives last -- and that one stays
+    assert sizes == [1, 1, 2, 1000] and not reseed                    # mean range size 1057 / 6 < rep_seeds
+    assert orc.map_exact_read(fw, rc, off, 150, 22, 4, 100)[1]        # rep_seeds = 100: 1057 >= 100 * 6 -> reseed
+    assert orc.map_exact_read(fw * 0 + [1, 0], rc * 0 + [1, 0], off, 150, 22, 4, 1000)[1]     # no hit at all -> reseed
+    # positions: forward hits carry read_len - offset - seed_len, reverse-complemented ones the offset; rc in bit 30
+    for begin, bits in deque:
+        pos, is_rc = (int(bits) >> 20) & 0x3FF, (int(bits) >> 30) & 1
+        j = [k for k in range(5) if (rc if is_rc else fw)[k, 0] == begin][0]
+        assert pos == (off[j] if is_rc else 150 - off[j] - 22)
+    # select: rows come out smallest range first, each range front to back; the top flag drops once the first range is exhausted
+    rows, flags, top = [], [], 1
+    for _ in range(8):
+        ok, row, seed, top, deque = orc.select_read(deque, top)
+        assert ok
+        rows.append(row); flags.append((seed >> 14) & 1)
+    assert set(rows[:2]) == {7, 10} and rows[2:4] == [30, 31] and rows[4:] == [1000, 1001, 1002, 1003]
+    assert flags[0] == 1 and flags[1:] == [0] * 7
+    one = np.array([[5, 2 | (3 << 20)]], dtype=np.uint32)              # a single two-row hit: two rows, then the read leaves the queue
+    ok, row, _, _, one = orc.select_read(one, 1); assert ok and row == 5
+    ok, row, _, _, one = orc.select_read(one, 1); assert ok and row == 6
+    assert not orc.select_read(one, 1)[0]
+    # effort: worst score -91; a hit improves the best, a distinct worse one becomes second, repeats of either are skipped for free,
+    # failures past min_ext count down from max_effort
+    best, trys = [-91, 0xFFFFFFFF, 0, -91, 0xFFFFFFFF, 0], 3
+    best, trys, erase = orc.score_reduce_effort(best, trys, -12, 5000, 0, 0, 150, 0, 3, 2, 400)
+    assert best[:3] == [-12, 5000, 0] and trys == 3 and not erase
+    best, trys, erase = orc.score_reduce_effort(best, trys, -30, 9000, 1, 0, 150, 1, 3, 2, 400)
+    assert best[3:] == [-30, 9000, 1] and trys == 3
+    best, trys, erase = orc.score_reduce_effort(best, trys, -50, 5000, 0, 0, 150, 2, 3, 2, 400)      # the best locus again: skipped
+    assert trys == 3 and not erase
+    best, trys, erase = orc.score_reduce_effort(best, trys, -50, 5040, 0, 0, 150, 1, 3, 2, 400)      # a failure before min_ext: not counted
+    assert trys == 3 and not erase
+    for k, want in ((2, 2), (3, 1)):
+        best, trys, erase = orc.score_reduce_effort(best, trys, -50, 5040, 0, 0, 150, k, 3, 2, 400)
+        assert trys == want and not erase
+    best, trys, erase = orc.score_reduce_effort(best, trys, -50, 5040, 0, 0, 150, 4, 3, 2, 400)
+    assert trys == 0 and erase                                        # third failure in a row: the read is done
+    best, trys, erase = orc.score_reduce_effort(best, 2, -50, 5040, 0, 1, 150, 4, 3, 2, 400)        # top-seed hits never count
+    assert trys == 2 and not erase
+    assert orc.score_reduce_effort(best, 2, -50, 5040, 0, 1, 150, 400, 3, 2, 400)[2]               # max_ext reached: stop regardless

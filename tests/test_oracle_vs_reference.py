@@ -102,3 +102,17 @@ def test_whole_path_oracle_equals_reference_code(orc, ref):
         assert np.array_equal(x, y)
     assert a[3] == b[3]
     ref.destroy(ridx)
+
+
+def test_seed_hit_deque_fuzz(orc, ref):
+    """live: the oracle's interval heap against the reference's priority_deque on fresh random operation sequences"""
+    rng = np.random.default_rng(77)
+    for t in range(1500):
+        n = int(rng.integers(1, 120)); mh = int(rng.integers(1, 40))
+        ops = rng.choice([0, 0, 0, 1, 2, 3, 3], n).astype(np.uint32)
+        begins = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        sizes = rng.choice([1, 1, 1, 2, 7, 300], n).astype(np.uint32)
+        bits = (sizes | (rng.integers(0, 1024, n).astype(np.uint32) << 20)).astype(np.uint32)
+        h1, r1 = orc.hit_deque_run(ops, begins, bits, mh)
+        h2, r2 = ref.hit_deque_run(ops, begins, bits, mh)
+        assert np.array_equal(h1, h2) and np.array_equal(r1, r2), t
