@@ -347,9 +347,9 @@ nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* keys_dev, ui
 typedef struct
 {
     const uint32_t* idx_queue_dev;
-    const uint32_t* hit_read_id_dev;
-    const uint32_t* hit_seed_dev;
-    const uint32_t* hit_loc_dev;
+    uint32_t*       hit_read_id_dev;   /* written by nvbio_seed_hits_select, read by the scoring stream calls */
+    uint32_t*       hit_seed_dev;
+    uint32_t*       hit_loc_dev;
     int32_t*        hit_score_dev;
     uint32_t*       hit_sink_dev;
     uint32_t        n;
@@ -369,6 +369,65 @@ nvbio_status nvbio_score_stream_flatten(int device, const nvbio_hit_queues* hits
  * = -65536, scoring.h:223-224), hit.sink = window begin + sink.x, scattered through idx_queue. */
 nvbio_status nvbio_score_stream_output(int device, const nvbio_hit_queues* hits, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
                                        const uint32_t* win_begin_dev, int32_t worst_score, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * nvBowtie's seed-hit bookkeeping (the data-parallel kernels of its best-approx extension loop, aligner_best_approx.h:453-666):
+ * per-read deques of seed hits, the selection of the next SA row, the effort-limited best / second-best reduction.
+ * One SeedHit = 8 bytes: x = range_begin, y = range_delta:20 | pos_in_read:10 | rc:1 | indexdir:1 (seed_hit.h:45-218; the SA range is
+ * exclusive at its end).  A read's deque is the reference's priority_deque over an interval heap (nvbio/basic/priority_deque.h):
+ * element 0 the largest range, element 1 the smallest; `capacity` entries per read, deque r at deques_dev + r * capacity.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct
+{
+    uint32_t seeds_per_read;   /* seeds mapped per read and strand                                                               */
+    uint32_t first_offset;     /* stored offset of seed 0: retry * (seed_freq / (max_reseed + 1))         (mapping_inl.h:520,528) */
+    uint32_t seed_interval;    /* seed_freq( read_len )                                                                          */
+    uint32_t seed_len;
+    uint32_t read_len;         /* reads of one length (< 1024: SeedHit keeps positions in 10 bits)                               */
+    uint32_t max_hits;         /* cap of the deque: a full deque drops its largest range before every push  (:242-244; default 100) */
+    uint32_t rep_seeds;        /* reseed when the mean range size reaches this                              (:549; default 1000)    */
+    uint32_t max_effort;       /* failed extensions in a row that end a read's search                       (reduce.h:72-97; 15)   */
+    uint32_t min_ext;          /* ... counted only from this many extensions on                             (default 30)           */
+    uint32_t max_ext;          /* hard limit of extensions per read                                         (default 400)          */
+} nvbio_seed_hits_params;
+
+/* entries per read a deque array needs for these parameters: min( 2 x seeds_per_read, max_hits ) + 1 */
+nvbio_status nvbio_seed_hits_capacity(uint32_t seeds_per_read, uint32_t max_hits, uint32_t* capacity);
+
+/* seed_mapper<EXACT_MAPPING>::enact + the bookkeeping of map_kernel (nvBowtie/bowtie2/cuda/mapping_inl.h:193-282,485-556) for reads whose
+ * seeds have been matched: fw_ranges_dev / rc_ranges_dev [n_reads x seeds_per_read] = nvbio_fm_match over the seeds of the STORED
+ * (reversed) reads with NVBIO_FM_SCAN_FORWARD, and with NVBIO_FM_COMPLEMENT (reverse scan) -- the two match_range calls of the
+ * mapper (USE_REVERSE_INDEX 0).  Work item t is read read_queue_dev[t] (NULL: read t).  For every seed, forward hit then
+ * reverse-complemented hit are pushed in the reference's order under its max_hits rule; sizes_dev[r] = hits kept;
+ * reseed_dev[r] (optional) = the reseeding decision `range_count == 0 || range_sum >= rep_seeds * range_count`. */
+nvbio_status nvbio_seed_hits_map(int device, const nvbio_uint2* fw_ranges_dev, const nvbio_uint2* rc_ranges_dev, const uint32_t* read_queue_dev,
+                                 uint32_t n_reads, const nvbio_seed_hits_params* params, nvbio_uint2* deques_dev, uint32_t* sizes_dev,
+                                 uint8_t* reseed_dev, void* stream);
+
+/* select_kernel (select_inl.h:62-130): every active read (active_in_dev[t] = read id | top_flag << 31, the reference's packed_read) whose
+ * search has not stopped (trys_dev[read] != 0; NULL = never) and which has a hit left takes a slot of the output queue: its next SA row
+ * goes to hits->hit_loc_dev[slot], with hits->hit_read_id_dev[slot], hits->hit_seed_dev[slot] = packed_seed( pos_in_read, index_dir, rc,
+ * top_flag ) and active_out_dev[slot]; the row is popped off the front of the read's top (smallest) range in place, an exhausted top
+ * range being dropped first (which clears the top flag).  *count_dev = slots written (slot order is arbitrary, as in the reference). */
+nvbio_status nvbio_seed_hits_select(int device, const uint32_t* active_in_dev, uint32_t n_active, const uint32_t* trys_dev, uint32_t capacity,
+                                    nvbio_uint2* deques_dev, uint32_t* sizes_dev, uint32_t* active_out_dev, const nvbio_hit_queues* hits,
+                                    uint32_t* count_dev, void* stream);
+
+/* the tail of nvBowtie's locate kernels (locate_inl.h:127-136,188-198): hit.loc = located position - seed.pos_in_read, uint32 arithmetic,
+ * for the hits->n selected hits (positions_dev from nvbio_fm_locate over hits->hit_loc_dev) */
+nvbio_status nvbio_seed_hits_loc(int device, const uint32_t* positions_dev, const nvbio_hit_queues* hits, void* stream);
+
+/* score_reduce_kernel with ReduceBestApproxContext (reduce_inl.h:65-140, reduce.h:55-99), one hit per active read: slot i of the scoring
+ * queue (hits->hit_score_dev / hit_loc_dev / hit_seed_dev [i]) belongs to read active_dev[i] & 0x7FFFFFFF.
+ *   best_dev[4 r ..]  = { a1 score, a1 locus, a2 score, a2 locus } (io::BestAlignments: scores start at the read's worst score, loci at
+ *                       0xFFFFFFFF = unaligned, aligner.h:279-301); best_rc_dev[r] = a1 strand | a2 strand << 1
+ *   a hit at a locus already held is skipped; a better one becomes a1 (a1 moves to a2); a worse one that beats a2 and is `distinct`
+ *   from a1 (other strand or more than read_len / 2 away, nvbio/io/alignments_inl.h:26-38) becomes a2 -- either resets trys_dev[r] to
+ *   max_effort; anything else is a failure: from min_ext extensions on (n_ext = extensions before this pass) a hit that is not from
+ *   the top seed decrements trys_dev[r], and at zero, or at max_ext extensions, the read's deque is erased (sizes_dev[r] = 0). */
+nvbio_status nvbio_score_reduce_effort(int device, const uint32_t* active_dev, const nvbio_hit_queues* hits, uint32_t read_len, uint32_t n_ext,
+                                       const nvbio_seed_hits_params* params, int32_t* best_dev, uint8_t* best_rc_dev, uint32_t* trys_dev,
+                                       uint32_t* sizes_dev, void* stream);
 
 /* Two conversions a binding of sw-benchmark's stream needs (sw-benchmark/sw-benchmark.cu:70-209): its reference text is packed
  * 2-bit LITTLE-endian (REF_BIG_ENDIAN = false, :64-65; the library reads the big-endian layout of io::SequenceData<DNA>), and its

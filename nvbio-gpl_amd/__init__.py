@@ -90,6 +90,11 @@ class _HitQueues(ctypes.Structure):
                 ("n", ctypes.c_uint32)]
 
 
+class _SeedHitsParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("seeds_per_read", "first_offset", "seed_interval", "seed_len", "read_len", "max_hits",
+                                                "rep_seeds", "max_effort", "min_ext", "max_ext")]
+
+
 _lib = None
 
 
@@ -879,7 +884,7 @@ class HitQueues:
         self.seed = _dev_tensor(seed, torch.int32, device)
         self.loc = _dev_tensor(loc, torch.int32, device)
         self.idx_queue = _dev_tensor(idx_queue, torch.int32, device)
-        self.n = int(self.idx_queue.numel() if self.idx_queue is not None else self.read_id.numel())
+        self.n = int(self.idx_queue.numel() if self.idx_queue is not None else self.read_id.numel())     # may be lowered: the first n slots count
         self.score = torch.zeros(self.read_id.numel(), dtype=torch.int32, device=device)
         self.sink = torch.zeros(self.read_id.numel(), dtype=torch.int32, device=device)
 
@@ -909,3 +914,49 @@ def score_stream_output(hits, scores, sinks, win_begin, worst_score=-65536):
     hq = hits.c_struct()
     _check(lib().nvbio_score_stream_output(FMIndex._dev_index(hits.device), ctypes.byref(hq), _ptr(scores), _ptr(sinks), _ptr(win_begin),
                                            ctypes.c_int32(worst_score), _stream_ptr(hits.device)))
+
+
+# ---- nvBowtie's seed-hit deques, selection and effort-limited reduction (include/nvbio_amd.h: nvbio_seed_hits_*) -----------------
+class SeedHitsParams:
+    """nvbio_seed_hits_params with nvBowtie's defaults (bowtie2_cuda_driver.cu:86-141)"""
+
+    def __init__(self, seeds_per_read, seed_interval, seed_len, read_len, first_offset=0, max_hits=100, rep_seeds=1000, max_effort=15,
+                 min_ext=30, max_ext=400):
+        self.c = _SeedHitsParams(seeds_per_read, first_offset, seed_interval, seed_len, read_len, max_hits, rep_seeds, max_effort, min_ext, max_ext)
+
+    def capacity(self):
+        cap = ctypes.c_uint32(0)
+        _check(lib().nvbio_seed_hits_capacity(self.c.seeds_per_read, self.c.max_hits, ctypes.byref(cap)))
+        return cap.value
+
+
+def seed_hits_map(fw_ranges, rc_ranges, params, n_reads, deques, sizes, reseed=None, read_queue=None):
+    """the exact seed mapper's deque bookkeeping (nvbio_seed_hits_map): fills deques [R, capacity, 2], sizes [R], reseed [R] for the
+    n_reads reads of read_queue (None: reads 0..n_reads-1)"""
+    dev = deques.device
+    _check(lib().nvbio_seed_hits_map(FMIndex._dev_index(dev), _ptr(fw_ranges), _ptr(rc_ranges), _ptr(read_queue), ctypes.c_uint32(n_reads),
+                                     ctypes.byref(params.c), _ptr(deques), _ptr(sizes), _ptr(reseed), _stream_ptr(dev)))
+
+
+def seed_hits_select(active, trys, params, deques, sizes, hits, active_out, count):
+    """select_kernel (nvbio_seed_hits_select): active int32 [n] (read | top_flag << 31); fills hits.read_id / loc / seed and active_out;
+    count int32 [1] on the device receives the number of slots written"""
+    dev = deques.device
+    hq = hits.c_struct()
+    _check(lib().nvbio_seed_hits_select(FMIndex._dev_index(dev), _ptr(active), ctypes.c_uint32(active.numel()), _ptr(trys),
+                                        ctypes.c_uint32(params.capacity()), _ptr(deques), _ptr(sizes), _ptr(active_out), ctypes.byref(hq),
+                                        _ptr(count), _stream_ptr(dev)))
+
+
+def seed_hits_loc(positions, hits):
+    hq = hits.c_struct()
+    _check(lib().nvbio_seed_hits_loc(FMIndex._dev_index(hits.device), _ptr(positions), ctypes.byref(hq), _stream_ptr(hits.device)))
+
+
+def score_reduce_effort(active, hits, read_len, n_ext, params, best, best_rc, trys, sizes):
+    """score_reduce_kernel with the best-approx effort rules (nvbio_score_reduce_effort): best int32 [R, 4] = (a1 score, a1 locus,
+    a2 score, a2 locus), best_rc uint8 [R], trys int32 [R], sizes int32 [R] (erased deques get 0)"""
+    hq = hits.c_struct()
+    _check(lib().nvbio_score_reduce_effort(FMIndex._dev_index(hits.device), _ptr(active), ctypes.byref(hq), ctypes.c_uint32(read_len),
+                                           ctypes.c_uint32(n_ext), ctypes.byref(params.c), _ptr(best), _ptr(best_rc), _ptr(trys), _ptr(sizes),
+                                           _stream_ptr(hits.device)))

@@ -1,0 +1,332 @@
+// seed_hits.hip -- nvBowtie's seed-hit bookkeeping around the seed-and-extend path, for gfx950:
+//   * the per-read deque of seed hits filled by the exact seed mapper, capped at max_hits, and the reseeding decision
+//         seed_mapper<EXACT_MAPPING>::enact + map_kernel            nvBowtie/bowtie2/cuda/mapping_inl.h:193-282,485-556
+//         SeedHit, hit_compare                                      nvBowtie/bowtie2/cuda/seed_hit.h:45-229
+//         priority_deque over an interval heap                      nvbio/basic/priority_deque.h, interval_heap.h
+//   * select_kernel: the next SA row of every active read's top hit                 select_inl.h:62-130
+//   * score_reduce_kernel with ReduceBestApproxContext: best / second best in arrival order, the effort counter, the stop
+//                                                                   reduce_inl.h:65-140, reduce.h:55-99
+// One lane owns one read, as in the reference: these are small state machines per read (a deque of at most 2 x seeds entries,
+// two alignments, a counter), streamed once per extension pass; what costs time in this mode is the number of passes, not
+// these kernels.  The deque is an interval heap: pairs (2k, 2k+1) hold the low and the high end of node k, "low" meaning
+// first under hit_compare (the LARGEST range), so that element 0 is what a full deque drops and element 1 (or 0 when alone) is
+// the smallest range, the one select takes rows from.  Hits of equal size are ordered by the heap's moves alone, so the
+// moves below are the reference container's, one for one (checked against it through the oracle: tests/test_gpu_seed_hits.py).
+#include "common.h"
+
+namespace nvbio_amd {
+
+struct HitHeap
+{
+    uint2*   a;          // word x = range_begin, word y = range_delta:20 | pos:10 | rc:1 | indexdir:1
+    uint32_t n;
+
+    __device__ __forceinline__ static uint32_t size_of(const uint2 h) { return h.y & 0xFFFFFu; }
+    // hit_compare: f goes before s iff f's range is larger
+    __device__ __forceinline__ bool before(const uint32_t i, const uint32_t j) const { return size_of( a[i] ) > size_of( a[j] ); }
+    __device__ __forceinline__ void exchange(const uint32_t i, const uint32_t j) { const uint2 t = a[i]; a[i] = a[j]; a[j] = t; }
+
+    // climb from element i along the low ends (towards element 0) or the high ends (towards element 1)
+    __device__ void climb(uint32_t i, const bool low)
+    {
+        while (i >= 2u)
+        {
+            const uint32_t up = ((i / 2u - 1u) | 1u) ^ (low ? 1u : 0u);
+            const bool move = low ? before( i, up ) : before( up, i );
+            if (!move) break;
+            exchange( i, up ); i = up;
+        }
+    }
+    // a leaf settles against the other end of its interval (or of its parent's, for a lone low end), then climbs
+    __device__ void settle_high(const uint32_t i)
+    {
+        const uint32_t other = (2u * i < n) ? 2u * i : (i ^ 1u);
+        if (before( i, other )) { exchange( i, other ); climb( other, true ); }
+        else climb( i, false );
+    }
+    __device__ void settle_low(const uint32_t i)
+    {
+        uint32_t other = i | 1u;
+        if (other >= n)
+        {
+            if (other == 1u) return;
+            other = (other / 2u - 1u) | 1u;
+        }
+        if (before( other, i )) { exchange( i, other ); climb( other, false ); }
+        else climb( i, true );
+    }
+    // the element at i sinks to a leaf -- along the first-ordered low children, or the last-ordered high ones -- and settles there
+    __device__ void sink(uint32_t i, const bool low)
+    {
+        const int32_t two_children_end = (int32_t)(n / 2u) - ((low && (n & 3u) == 0u) ? 2 : 1);
+        while ((int32_t)i < two_children_end)
+        {
+            uint32_t c = 2u * i + (low ? 2u : 1u);
+            if (low ? before( c + 2u, c ) : before( c, c + 2u )) c += 2u;
+            exchange( i, c ); i = c;
+        }
+        if ((int32_t)i <= two_children_end + (low ? 0 : 1))
+        {
+            uint32_t c = 2u * i + (low ? 2u : 1u);
+            if (c < n)
+            {
+                if (!low && c + 1u < n && before( c, c + 1u ))
+                {
+                    ++c; exchange( i, c );
+                    settle_low( c );
+                    return;
+                }
+                exchange( i, c ); i = c;
+            }
+        }
+        if (low) settle_low( i ); else settle_high( i );
+    }
+
+    __device__ void push(const uint2 h)
+    {
+        a[n] = h; ++n;
+        if ((n - 1u) & 1u) settle_high( n - 1u ); else settle_low( n - 1u );
+    }
+    __device__ void pop_bottom()                     // the largest range goes
+    {
+        --n;
+        exchange( 0u, n );
+        sink( 0u, true );
+    }
+    __device__ void pop_top()                        // the smallest range goes
+    {
+        if (n > 2u)
+        {
+            exchange( 1u, n - 1u );
+            --n;
+            sink( 1u, false );
+        }
+        else --n;
+    }
+    __device__ __forceinline__ uint32_t top() const { return n > 1u ? 1u : 0u; }
+};
+
+// ---- map: the deques of a batch of reads from the match ranges of their seeds ----
+// Read r (uniform length read_len) has seeds j = 0 .. spr-1 at stored offsets first_off + j * interval; fw / rc hold what
+// match_range returned for the forward scan of the stored read and for its reverse scan complemented (inclusive, empty iff x > y).
+__global__ void __launch_bounds__(256)
+seed_hits_map_kernel(const uint2* __restrict__ fw, const uint2* __restrict__ rc, const uint32_t* __restrict__ queue, const uint32_t n_reads, const uint32_t spr,
+                     const uint32_t first_off, const uint32_t interval, const uint32_t seed_len, const uint32_t read_len, const uint32_t max_hits,
+                     const uint32_t rep_seeds, const uint32_t cap, uint2* __restrict__ deques, uint32_t* __restrict__ sizes,
+                     uint8_t* __restrict__ reseed)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_reads; t += gridDim.x * blockDim.x)
+    {
+        const uint32_t r = queue ? queue[t] : t;
+        HitHeap heap; heap.a = deques + (uint64_t)r * cap; heap.n = 0;
+        uint32_t range_sum = 0, range_count = 0;
+        for (uint32_t j = 0; j < spr; ++j)
+        {
+            const uint32_t off = first_off + j * interval;
+            #pragma unroll
+            for (uint32_t strand = 0; strand < 2u; ++strand)
+            {
+                const uint2 g = strand ? rc[(uint64_t)t * spr + j] : fw[(uint64_t)t * spr + j];
+                if (g.x > g.y) continue;
+                const uint32_t pos = strand ? off : read_len - off - seed_len;       // SeedHit::build_flags (mapping_inl.h:241,275)
+                if (heap.n == max_hits) heap.pop_bottom();
+                heap.push( make_uint2( g.x, ((g.y + 1u - g.x) & 0xFFFFFu) | ((pos & 0x3FFu) << 20) | (strand << 30) ) );
+                range_sum += g.y - g.x + 1u; ++range_count;
+            }
+        }
+        sizes[r] = heap.n;
+        if (reseed) reseed[r] = (range_count == 0u || range_sum >= rep_seeds * range_count) ? 1 : 0;
+    }
+}
+
+// ---- select: one SA row per active read ----
+// active_in[t] = read id | top_flag << 31 (packed_read, defs.h).  A read that still has a hit takes a slot of the output queue:
+// active_out[slot], hit_read_id[slot], hit_loc[slot] = the SA row, hit_seed[slot] = packed_seed.  counts[0] = slots written.
+__global__ void __launch_bounds__(256)
+seed_hits_select_kernel(const uint32_t* __restrict__ active_in, const uint32_t n_active, const uint32_t* __restrict__ trys, const uint32_t cap,
+                        uint2* __restrict__ deques, uint32_t* __restrict__ sizes, uint32_t* __restrict__ active_out, uint32_t* __restrict__ hit_read_id,
+                        uint32_t* __restrict__ hit_loc, uint32_t* __restrict__ hit_seed, unsigned int* __restrict__ counts)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_active; base += gridDim.x * blockDim.x)
+    {
+        const uint32_t t = base + threadIdx.x;
+        bool     take = false;
+        uint32_t read = 0, top_flag = 0, row = 0, seed = 0;
+        if (t < n_active)
+        {
+            read = active_in[t] & 0x7FFFFFFFu; top_flag = active_in[t] >> 31;
+            if (!(trys && trys[read] == 0u))                             // context.stop( read_id )
+            {
+                HitHeap heap; heap.a = deques + (uint64_t)read * cap; heap.n = sizes[read];
+                if (heap.n)
+                {
+                    uint32_t k = heap.top();
+                    if (HitHeap::size_of( heap.a[k] ) == 0u)             // the top range is used up
+                    {
+                        heap.pop_top();
+                        top_flag = 0u;
+                        k = heap.top();
+                    }
+                    if (heap.n)
+                    {
+                        uint2 h = heap.a[k];
+                        row = h.x;                                       // SeedHit::pop_front
+                        h.x += 1u; h.y = (h.y & ~0xFFFFFu) | ((HitHeap::size_of( h ) - 1u) & 0xFFFFFu);
+                        heap.a[k] = h;
+                        seed = ((h.y >> 20) & 0x3FFu) | (((h.y >> 31) & 1u) << 12) | (((h.y >> 30) & 1u) << 13) | (top_flag << 14);
+                        take = true;
+                    }
+                    sizes[read] = heap.n;
+                }
+            }
+        }
+        const uint64_t m = __ballot( take );
+        if (m)
+        {
+            uint32_t slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd( &counts[0], (unsigned int)__popcll( m ) );
+            slot0 = (uint32_t)__shfl( (int)slot0, 0 );
+            if (take)
+            {
+                const uint32_t slot = slot0 + (uint32_t)__popcll( m & ((1ull << lane) - 1ull) );
+                active_out[slot] = read | (top_flag << 31); hit_read_id[slot] = read; hit_loc[slot] = row; hit_seed[slot] = seed;
+            }
+        }
+    }
+}
+
+// ---- locate helper: hit.loc = locate(row) - pos_in_read (locate_inl.h:127-136), uint32 arithmetic ----
+__global__ void __launch_bounds__(256)
+seed_hits_loc_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ hit_seed, const uint32_t n, uint32_t* __restrict__ hit_loc)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hit_loc[i] = pos[i] - (hit_seed[i] & 0xFFFu);
+}
+
+// ---- reduce: best / second best in arrival order, the effort counter ----
+// best[r] = { a1 score, a1 pos, a2 score, a2 pos } with the strands in bits 0 / 1 of best_rc[r]; positions 0xFFFFFFFF = unaligned.
+// Work item i is the hit in slot i of the scoring queue (one hit per active read and pass).
+__device__ __forceinline__ bool distinct_loci(const uint32_t pos1, const uint32_t rc1, const uint32_t pos2, const uint32_t rc2, const uint32_t dist)
+{
+    if (rc1 != rc2) return true;
+    return !(pos1 >= pos2 - (pos2 < dist ? pos2 : dist) && pos1 <= pos2 + dist);          // io::distinct_alignments, uint32 arithmetic
+}
+
+__global__ void __launch_bounds__(256)
+score_reduce_effort_kernel(const uint32_t* __restrict__ active, const uint32_t n, const int32_t* __restrict__ hit_score, const uint32_t* __restrict__ hit_loc,
+                           const uint32_t* __restrict__ hit_seed, const uint32_t read_len, const uint32_t ext, const uint32_t max_effort,
+                           const uint32_t min_ext, const uint32_t max_ext, int4* __restrict__ best, uint8_t* __restrict__ best_rc,
+                           uint32_t* __restrict__ trys, uint32_t* __restrict__ sizes)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t read = active[i] & 0x7FFFFFFFu;
+        const uint32_t rc = (hit_seed[i] >> 13) & 1u, top_flag = (hit_seed[i] >> 14) & 1u;
+        const int32_t  score = hit_score[i];
+        const uint32_t g = hit_loc[i];
+        int4 b = best[read];
+        uint32_t rcs = best_rc[read];
+        const uint32_t rc1 = rcs & 1u, rc2 = (rcs >> 1) & 1u;
+        if ((rc == rc1 && g == (uint32_t)b.y) || (rc == rc2 && g == (uint32_t)b.w)) continue;     // a locus already held: free
+        if (score > b.x)
+        {
+            trys[read] = max_effort;
+            b.z = b.x; b.w = b.y; b.x = score; b.y = (int32_t)g;
+            rcs = rc | (rc1 << 1);
+        }
+        else if (score > b.z && distinct_loci( (uint32_t)b.y, rc1, g, rc, read_len / 2u ))
+        {
+            trys[read] = max_effort;
+            b.z = score; b.w = (int32_t)g;
+            rcs = rc1 | (rc << 1);
+        }
+        else
+        {
+            uint32_t t = trys[read];
+            if (t > 0u)
+            {
+                bool stop = false;
+                if (ext >= min_ext && top_flag == 0u) { --t; trys[read] = t; stop = (t == 0u); }
+                if (stop || ext >= max_ext) sizes[read] = 0u;            // pipeline.hits.erase( read_id )
+            }
+        }
+        best[read] = b; best_rc[read] = (uint8_t)rcs;
+    }
+}
+
+} // namespace nvbio_amd
+
+using namespace nvbio_amd;
+
+extern "C" {
+
+nvbio_status nvbio_seed_hits_capacity(uint32_t seeds_per_read, uint32_t max_hits, uint32_t* capacity)
+{
+    NVB_REQUIRE( capacity != nullptr, "capacity is NULL" );
+    const uint64_t c = 2ull * seeds_per_read;
+    *capacity = (uint32_t)((c < max_hits ? c : max_hits) + 1u);
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_seed_hits_map(int device, const nvbio_uint2* fw_ranges_dev, const nvbio_uint2* rc_ranges_dev, const uint32_t* read_queue_dev,
+                                 uint32_t n_reads, const nvbio_seed_hits_params* p, nvbio_uint2* deques_dev, uint32_t* sizes_dev, uint8_t* reseed_dev,
+                                 void* stream)
+{
+    NVB_REQUIRE( p != nullptr, "params is NULL" );
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( fw_ranges_dev && rc_ranges_dev && deques_dev && sizes_dev, "NULL device pointer" );
+    NVB_REQUIRE( p->max_hits > 0 && p->seeds_per_read > 0, "max_hits and seeds_per_read must be positive" );
+    NVB_REQUIRE( (uint64_t)p->first_offset + (uint64_t)(p->seeds_per_read - 1u) * p->seed_interval + p->seed_len <= p->read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( p->read_len < 1024u, "SeedHit keeps the seed position in 10 bits (seed_hit.h:217)" );
+    uint32_t cap = 0; NVB_CHECK( nvbio_seed_hits_capacity( p->seeds_per_read, p->max_hits, &cap ) );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( seed_hits_map_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream, (const uint2*)fw_ranges_dev, (const uint2*)rc_ranges_dev,
+                        read_queue_dev, n_reads, p->seeds_per_read, p->first_offset, p->seed_interval, p->seed_len, p->read_len, p->max_hits, p->rep_seeds, cap,
+                        (uint2*)deques_dev, sizes_dev, reseed_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_seed_hits_select(int device, const uint32_t* active_in_dev, uint32_t n_active, const uint32_t* trys_dev, uint32_t capacity,
+                                    nvbio_uint2* deques_dev, uint32_t* sizes_dev, uint32_t* active_out_dev, const nvbio_hit_queues* hits,
+                                    uint32_t* count_dev, void* stream)
+{
+    NVB_REQUIRE( count_dev != nullptr && hits != nullptr, "NULL argument" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    NVB_HIP( hipMemsetAsync( count_dev, 0, sizeof(uint32_t), (hipStream_t)stream ) );
+    if (n_active == 0) return NVBIO_OK;
+    NVB_REQUIRE( active_in_dev && deques_dev && sizes_dev && active_out_dev && hits->hit_read_id_dev && hits->hit_loc_dev && hits->hit_seed_dev, "NULL device pointer" );
+    hipLaunchKernelGGL( seed_hits_select_kernel, dim3( grid_for( n_active ) ), dim3(256), 0, (hipStream_t)stream, active_in_dev, n_active, trys_dev, capacity,
+                        (uint2*)deques_dev, sizes_dev, active_out_dev, (uint32_t*)hits->hit_read_id_dev, (uint32_t*)hits->hit_loc_dev, (uint32_t*)hits->hit_seed_dev,
+                        (unsigned int*)count_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_seed_hits_loc(int device, const uint32_t* positions_dev, const nvbio_hit_queues* hits, void* stream)
+{
+    NVB_REQUIRE( hits != nullptr, "hits is NULL" );
+    if (hits->n == 0) return NVBIO_OK;
+    NVB_REQUIRE( positions_dev && hits->hit_seed_dev && hits->hit_loc_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( seed_hits_loc_kernel, dim3( grid_for( hits->n ) ), dim3(256), 0, (hipStream_t)stream, positions_dev, hits->hit_seed_dev, hits->n, (uint32_t*)hits->hit_loc_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_score_reduce_effort(int device, const uint32_t* active_dev, const nvbio_hit_queues* hits, uint32_t read_len, uint32_t n_ext,
+                                       const nvbio_seed_hits_params* p, int32_t* best_dev, uint8_t* best_rc_dev, uint32_t* trys_dev, uint32_t* sizes_dev,
+                                       void* stream)
+{
+    NVB_REQUIRE( hits != nullptr && p != nullptr, "NULL argument" );
+    if (hits->n == 0) return NVBIO_OK;
+    NVB_REQUIRE( active_dev && hits->hit_score_dev && hits->hit_loc_dev && hits->hit_seed_dev && best_dev && best_rc_dev && trys_dev && sizes_dev, "NULL device pointer" );
+    NVB_REQUIRE( ((uintptr_t)best_dev & 15u) == 0, "best_dev must be 16-byte aligned" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( score_reduce_effort_kernel, dim3( grid_for( hits->n ) ), dim3(256), 0, (hipStream_t)stream, active_dev, hits->n, hits->hit_score_dev,
+                        hits->hit_loc_dev, hits->hit_seed_dev, read_len, n_ext, p->max_effort, p->min_ext, p->max_ext, (int4*)best_dev, best_rc_dev, trys_dev, sizes_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+} // extern "C"

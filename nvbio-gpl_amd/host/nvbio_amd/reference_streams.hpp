@@ -63,7 +63,7 @@ void enact_best_score_stream(const stream_type& stream, nvbio_alignment_type typ
     nvbio_hit_queues hq;
     hq.idx_queue_dev   = p.idx_queue;
     hq.hit_read_id_dev = &p.scoring_queues.hits.read_id[0];
-    hq.hit_seed_dev    = (const uint32_t*)&p.scoring_queues.hits.seed[0];       // packed_seed is one 32-bit word (defs.h:162-172)
+    hq.hit_seed_dev    = (uint32_t*)&p.scoring_queues.hits.seed[0];             // packed_seed is one 32-bit word (defs.h:162-172)
     hq.hit_loc_dev     = &p.scoring_queues.hits.loc[0];
     hq.hit_score_dev   = (int32_t*)&p.scoring_queues.hits.score[0];
     hq.hit_sink_dev    = (uint32_t*)&p.scoring_queues.hits.sink[0];

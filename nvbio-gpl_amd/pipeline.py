@@ -446,3 +446,99 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
         if e is not None:
             e.record()
     return out
+
+
+
+class NvBowtieParams:
+    """the parameters of nvBowtie's best-approx pipeline that decide WHICH loci get extended (bowtie2_cuda_driver.cu:86-141 defaults)"""
+
+    def __init__(self, seed_len=22, seed_freq=None, max_hits=100, rep_seeds=1000, max_effort=15, max_effort_init=15, min_ext=30,
+                 max_ext=400, max_reseed=2, band=31, top_seed=0):
+        self.seed_len, self.seed_freq, self.max_hits, self.rep_seeds = seed_len, seed_freq, max_hits, rep_seeds
+        self.max_effort, self.max_effort_init, self.min_ext, self.max_ext = max_effort, max(max_effort_init, max_effort), min_ext, max(max_ext, max_effort)
+        self.max_reseed, self.band, self.top_seed = max_reseed, band, top_seed
+
+
+def nvbowtie_best_approx(fmi, genome2, genome_len, stored_reads, params, nvb=None, stats=None):
+    """nvBowtie's best-approx single-end loop with nvBowtie's own choices (Aligner::best_approx, aligner_best_approx.h:39-207,363-667):
+    for every seeding pass (reads that ask for reseeding go round again with their seeds shifted), map the exact seeds of both strands
+    into per-read hit deques capped at max_hits (the smallest SA ranges survive), then repeat: select the next SA row of every active
+    read's smallest range -> locate it -> band-DP its window (BestScoreStream) -> fold the score into the read's best / second best
+    in arrival order, counting failed extensions, until a read's hits or its effort run out.  One hit per read and pass (the
+    reference switches to several once fewer than half a batch of reads are active: an optimisation that changes no rule but
+    the order effort runs out in).  Every data-parallel step is a kernel behind the C ABI; this function is the host loop.
+    stored_reads: ReadBatch of reads stored REVERSED, as nvBowtie loads them (io::REVERSE, nvBowtie.cpp:322).
+    Returns dict(best_score, best_loc, best_rc, second_score, second_loc, second_rc) (loc = hit.loc, the diagonal's locus; -1 = none),
+    n_extensions, passes."""
+    import torch
+    from . import (FM_COMPLEMENT, FM_SCAN_FORWARD, AlignmentBatch, BatchedBandedAlignmentScore, GotohAligner, HitQueues, PackedStringSet,
+                   SeedHitsParams, score_reduce_effort, score_stream_flatten, score_stream_output, seed_hits_loc, seed_hits_map, seed_hits_select)
+    nvb = nvb or NvBowtieParams()
+    dev = fmi.device
+    R, M = stored_reads.n, stored_reads.read_len
+    L = min(nvb.seed_len, M)
+    S = nvb.seed_freq or params.interval_for(M)
+    retry_stride = S // (nvb.max_reseed + 1)
+    worst = params.min_score_for(M)                                   # init_alignments( reads, threshold_score, ... ) (aligner_best_approx.h:77)
+    best = torch.empty((R, 4), dtype=torch.int32, device=dev)
+    best[:, 0] = worst; best[:, 2] = worst; best[:, 1] = -1; best[:, 3] = -1
+    best_rc = torch.zeros(R, dtype=torch.uint8, device=dev)
+    trys = torch.empty(R, dtype=torch.int32, device=dev)
+    read_index = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    aligner = GotohAligner(params.aln_type, params.scheme)
+    queue = torch.arange(R, device=dev, dtype=torch.int32)           # seed_queues: the reads of this seeding pass
+    n_extensions = passes = 0
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    for seeding_pass in range(nvb.max_reseed + 1):
+        nq = queue.numel()
+        if nq == 0:
+            break
+        first = seeding_pass * retry_stride
+        spr = (M - L - first) // S + 1 if M >= L + first else 0
+        if spr <= 0:
+            break
+        sp = SeedHitsParams(spr, S, L, M, first_offset=first, max_hits=nvb.max_hits, rep_seeds=nvb.rep_seeds, max_effort=nvb.max_effort,
+                            min_ext=nvb.min_ext, max_ext=nvb.max_ext)
+        cap = sp.capacity()
+        # the two match_range calls of the exact mapper over the seeds of the queued reads
+        offs = (queue.to(torch.int64) * M + first).to(torch.int32).contiguous()
+        qs = PackedStringSet(stored_reads.reads4, 4, nq * spr, offsets=offs, fixed_len=L, stride=M, device=dev, seeds_per_string=spr, seed_interval=S)
+        fw = fmi.match(qs, FM_SCAN_FORWARD)
+        rc = fmi.match(qs, FM_COMPLEMENT)
+        deques = torch.zeros((R, cap, 2), dtype=torch.int32, device=dev)
+        sizes = torch.zeros(R, dtype=torch.int32, device=dev)
+        reseed = torch.zeros(R, dtype=torch.uint8, device=dev)
+        seed_hits_map(fw, rc, sp, nq, deques, sizes, reseed, read_queue=queue)
+        # the extension loop (best_approx_score)
+        trys.fill_(nvb.max_effort_init)                               # select_init
+        active = (queue | (nvb.top_seed << 31)).contiguous()
+        n_ext = 0
+        while active.numel() and n_ext < nvb.max_ext:
+            na = active.numel()
+            hits = HitQueues(torch.empty(na, dtype=torch.int32, device=dev), torch.empty(na, dtype=torch.int32, device=dev),
+                             torch.empty(na, dtype=torch.int32, device=dev), device=dev)
+            active_out = torch.empty(na, dtype=torch.int32, device=dev)
+            seed_hits_select(active, trys, sp, deques, sizes, hits, active_out, count)
+            nh = int(count.item())
+            if nh == 0:
+                break
+            active = active_out[:nh].contiguous()
+            hits.n = nh
+            pos = fmi.locate(hits.loc[:nh].contiguous())
+            seed_hits_loc(pos, hits)
+            rid, flags, wb, we = score_stream_flatten(hits, read_index, nvb.band, genome_len, reads_reversed=True)
+            batch = AlignmentBatch(stored_reads.reads4, 4, read_index, genome2, 2, wb, we, quals=stored_reads.quals, read_id=rid, flags=flags,
+                                   device=dev, max_read_len=M)
+            scores, sinks = BatchedBandedAlignmentScore(nvb.band, aligner).enact(batch)
+            score_stream_output(hits, scores, sinks, wb)
+            score_reduce_effort(active, hits, M, n_ext, sp, best, best_rc, trys, sizes)
+            n_ext += 1
+            n_extensions += nh
+            passes += 1
+        queue = queue[reseed[queue.to(torch.int64)] != 0].contiguous()       # the reads that asked for reseeding go round again
+    if stats is not None:
+        stats.update(n_extensions=n_extensions, passes=passes)
+    b = best.to(torch.int64)
+    loc = lambda c: torch.where(b[:, c] == -1, b[:, c], b[:, c] & 0xFFFFFFFF)
+    return dict(best_score=best[:, 0].clone(), best_loc=loc(1), best_rc=(best_rc & 1), second_score=best[:, 2].clone(), second_loc=loc(3),
+                second_rc=((best_rc >> 1) & 1), n_extensions=n_extensions, passes=passes)

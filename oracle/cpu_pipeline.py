@@ -344,6 +344,7 @@ def score_stream_flatten(idx_queue, hit_read_id, hit_seed, hit_loc, read_index, 
         read_len = int(read_index[read_id + 1]) - int(read_index[read_id])            # read_range.y - read_range.x            (:102)
         begin = g_pos - band_len // 2 if g_pos > band_len // 2 else 0                 # genome_begin                           (:103)
         end = min((begin + band_len + read_len) & 0xFFFFFFFF, genome_len)             # genome_end (uint32 arithmetic)         (:104)
+        end = max(end, begin)     # a wrapped locus (seed hanging over the genome start) would make the reference read out of bounds: empty window
         if reads_reversed:
             f = 2 if read_rc else 1                                                   # FORWARD + COMPLEMENT : REVERSE + STANDARD
         else:
@@ -360,3 +361,68 @@ def score_stream_output(idx_queue, n_hits, scores, sinks, genome_begin, worst_sc
         hit_score[idx] = max(int(scores[i]), worst_score)
         hit_sink[idx] = (int(genome_begin[i]) + int(sinks[i][0])) & 0xFFFFFFFF
     return hit_score, hit_sink
+
+
+def nvbowtie_best_approx_cpu(O, hidx, text, genome_len, reads, scheme, aln_type, min_score, seed_len=22, seed_freq=None, max_hits=100,
+                             rep_seeds=1000, max_effort=15, max_effort_init=15, min_ext=30, max_ext=400, max_reseed=2, band=31, top_seed=0):
+    """nvBowtie's best-approx single-end loop, one read at a time, on the oracle (Aligner::best_approx, aligner_best_approx.h:39-207,
+    363-667; map_kernel mapping_inl.h:485-556; select_kernel select_inl.h:62-130; locate locate_inl.h:113-138; BestScoreStream
+    score_inl.h:85-133; score_reduce_kernel reduce_inl.h:65-140).  reads: uint8 [R, M] in their ORIGINAL orientation; nvBowtie stores
+    them reversed and seeds the stored stream.  One hit per read and pass.  Test infrastructure; parity unpinned beyond the pieces
+    that are pinned on their own (match / locate / banded DP / the deque container)."""
+    R, M = reads.shape
+    L = min(seed_len, M)
+    S = seed_freq or int(1 + 1.15 * math.sqrt(M))
+    retry_stride = S // (max_reseed + 1)
+    max_effort_init = max(max_effort_init, max_effort); max_ext = max(max_ext, max_effort)
+    stored = reads[:, ::-1]
+    best = np.zeros((R, 6), dtype=np.int64)
+    best[:, 0] = min_score; best[:, 3] = min_score; best[:, 1] = 0xFFFFFFFF; best[:, 4] = 0xFFFFFFFF
+    n_extensions = 0
+    queue = list(range(R))
+    for seeding_pass in range(max_reseed + 1):
+        if not queue:
+            break
+        first = seeding_pass * retry_stride
+        if M < L + first:
+            break
+        spr = (M - L - first) // S + 1
+        seed_off = first + np.arange(spr) * S
+        nxt = []
+        for r in queue:
+            seeds = np.concatenate([stored[r, o:o + L] for o in seed_off]).astype(np.uint8)
+            offs = (np.arange(spr + 1) * L).astype(np.uint32)
+            fw = O.match_batch(hidx, seeds, offs, reverse=True)                         # forward scan of the stored seed
+            comp = np.where(seeds < 4, 3 - seeds, seeds).astype(np.uint8)
+            rc = O.match_batch(hidx, comp, offs)                                       # reverse scan, complemented
+            deque, reseed = O.map_exact_read(fw, rc, seed_off, M, L, max_hits, rep_seeds)
+            if reseed:
+                nxt.append(r)
+            trys, top, n_ext = max_effort_init, top_seed, 0
+            while n_ext < max_ext:
+                if trys == 0:
+                    break
+                ok, row, seed, top, deque = O.select_read(deque, top)
+                if not ok:
+                    break
+                pos = int(O.locate_batch(hidx, np.array([row], dtype=np.uint32))[0])
+                g_pos = (pos - (seed & 0xFFF)) & 0xFFFFFFFF                           # hit.loc (locate_inl.h:133)
+                read_rc = (seed >> 13) & 1
+                begin = g_pos - band // 2 if g_pos > band // 2 else 0
+                end = min((begin + band + M) & 0xFFFFFFFF, genome_len)
+                pat = (np.where(reads[r, ::-1] < 4, 3 - reads[r, ::-1], reads[r, ::-1]) if read_rc else reads[r]).astype(np.uint8)
+                if end > begin:
+                    _, score, _ = O.banded_gotoh(band, aln_type, scheme, pat, text[begin:end])
+                else:
+                    score = SCORE_MIN
+                score = max(score, -65536)                                            # hit.score = max( sink.score, worst_score )
+                b, trys, erase = O.score_reduce_effort(list(best[r]), trys, score, g_pos, read_rc, (seed >> 14) & 1, M, n_ext, max_effort, min_ext, max_ext)
+                best[r] = b
+                if erase:
+                    deque = deque[:0]
+                n_ext += 1; n_extensions += 1
+        queue = nxt
+    out = dict(best_score=best[:, 0].astype(np.int32), best_loc=np.where(best[:, 1] == 0xFFFFFFFF, -1, best[:, 1]), best_rc=best[:, 2].astype(np.uint8),
+               second_score=best[:, 3].astype(np.int32), second_loc=np.where(best[:, 4] == 0xFFFFFFFF, -1, best[:, 4]),
+               second_rc=best[:, 5].astype(np.uint8), n_extensions=n_extensions)
+    return out
