@@ -500,7 +500,9 @@ enum
     NVBIO_ALN_NO_THIRD_CHANCE       = 2,   /* three-mismatch jobs go to the DP                                                  */
     NVBIO_ALN_NO_PACKED_DP          = 4,   /* int32 kernels only                                                                */
     NVBIO_ALN_FORCE_PACKED_DP       = 8,   /* packed full-matrix kernel also for small batches                                  */
-    NVBIO_ALN_NO_UNGAPPED_TRACEBACK = 16   /* every traceback through the direction-vector DP                                   */
+    NVBIO_ALN_NO_UNGAPPED_TRACEBACK = 16,  /* every traceback through the direction-vector DP                                   */
+    NVBIO_ALN_PK_TWO_WAVES          = 32   /* packed band-31 kernel built for 2 waves per SIMD (256 VGPRs, no register spills) instead
+                                              of 3 (168 VGPRs; SEMI_GLOBAL / GLOBAL spill their prologue state)                  */
 };
 
 enum { NVBIO_READ_REVERSE = 1, NVBIO_READ_COMPLEMENT = 2 };

@@ -221,8 +221,12 @@ __device__ __forceinline__ uint32_t clamp_u32(const int64_t v, const uint32_t lo
 // issues the loads for the next chunk: one wave-uniform wait point per 8 rows with an 8-row
 // (~5,000 instruction) head start, and no per-row branches.  Reads are packed RBITS (2 or 4) per
 // symbol, the text 2 bits per symbol.
-template <int TYPE, int RBITS>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// MINW: the occupancy the register allocator must reach.  3 waves per SIMD leave 168 VGPRs: LOCAL fits; SEMI_GLOBAL / GLOBAL spill
+// 34 / 72 registers (140 / 276 bytes of scratch per lane) -- all of it prologue / epilogue state (the scratch accesses sit outside
+// the row loop).  2 waves leave 256: nothing spills.  Which is faster is measured, not assumed: NVBIO_ALN_PK_TWO_WAVES runs the
+// 2-wave build.
+template <int TYPE, int RBITS, int MINW = 3>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MINW, 3)))
 banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
                               const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
 {
@@ -856,15 +860,25 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         }
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
-            hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                                (const uint32_t*)job_list, (const uint32_t*)job_count );
+        {
+            if (b.algo & NVBIO_ALN_PK_TWO_WAVES)
+                hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,2>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                                    (const uint32_t*)job_list, (const uint32_t*)job_count );
+            else
+                hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,3>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                                    (const uint32_t*)job_list, (const uint32_t*)job_count );
+        }
         (void)hipFreeAsync( aux, s );
         if (e != hipSuccess) { set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
         NVB_HIP( hipGetLastError() );
         return NVBIO_OK;
     }
-    hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                        (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+    if (b.algo & NVBIO_ALN_PK_TWO_WAVES)
+        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,2>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+    else
+        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,3>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
+                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

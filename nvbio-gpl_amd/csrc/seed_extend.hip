@@ -280,12 +280,13 @@ score_stream_flatten_kernel(const uint32_t* __restrict__ idx_queue, const uint32
         read_id[i] = rid;
         flags[i]   = reads_reversed ? (rc ? (uint8_t)NVBIO_READ_COMPLEMENT : (uint8_t)NVBIO_READ_REVERSE)
                                     : (rc ? (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT) : (uint8_t)0);
-        wb[i] = b;
         // a locus that wrapped below zero (a seed hanging over the genome start: locate_inl.h:133 subtracts pos_in_read in uint32) gives the
-        // reference a window that begins past its end, which it then reads out of bounds; here such a job gets an empty window
-        // and reports nothing
+        // reference a window that begins past the genome's end, which it then reads out of bounds; here such a job gets the empty
+        // window [0, 0) -- no kernel ever forms an address from it -- and reports nothing
         const uint32_t end = e < genome_len ? e : genome_len;
-        we[i] = end < b ? b : end;
+        const bool     bad = b >= genome_len || end < b;
+        wb[i] = bad ? 0u : b;
+        we[i] = bad ? 0u : end;
     }
 }
 

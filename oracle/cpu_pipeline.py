@@ -344,7 +344,8 @@ def score_stream_flatten(idx_queue, hit_read_id, hit_seed, hit_loc, read_index, 
         read_len = int(read_index[read_id + 1]) - int(read_index[read_id])            # read_range.y - read_range.x            (:102)
         begin = g_pos - band_len // 2 if g_pos > band_len // 2 else 0                 # genome_begin                           (:103)
         end = min((begin + band_len + read_len) & 0xFFFFFFFF, genome_len)             # genome_end (uint32 arithmetic)         (:104)
-        end = max(end, begin)     # a wrapped locus (seed hanging over the genome start) would make the reference read out of bounds: empty window
+        if begin >= genome_len or end < begin:     # a wrapped locus (seed hanging over the genome start) makes the reference read out of bounds:
+            begin = end = 0                        # here the job gets the empty window [0, 0) and reports nothing
         if reads_reversed:
             f = 2 if read_rc else 1                                                   # FORWARD + COMPLEMENT : REVERSE + STANDARD
         else:

@@ -358,13 +358,14 @@ uint32_t orc_locate(const orc_fm_index* f, uint32_t i)
 void orc_match_batch(const orc_fm_index* f, const uint8_t* syms, const uint32_t* off, uint32_t n,
                      int reverse, uint32_t* ranges, uint32_t* blocks)
 {
-    #pragma omp parallel for schedule(static)
+    /* small batches stay on the calling thread: a 128-thread team costs far more than a handful of searches (per-read callers) */
+    #pragma omp parallel for schedule(static) if(n > 512)
     for (int64_t q = 0; q < (int64_t)n; ++q)
         orc_match( f, syms + off[q], off[q+1] - off[q], reverse, ranges + 2*q, blocks ? blocks + q : 0 );
 }
 void orc_locate_batch(const orc_fm_index* f, const uint32_t* rows, uint32_t n, uint32_t* pos)
 {
-    #pragma omp parallel for schedule(static)
+    #pragma omp parallel for schedule(static) if(n > 512)
     for (int64_t i = 0; i < (int64_t)n; ++i)
         pos[i] = orc_locate( f, rows[i] );
 }
