@@ -404,6 +404,17 @@ nvbio_status nvbio_seed_hits_map(int device, const nvbio_uint2* fw_ranges_dev, c
                                  uint32_t n_reads, const nvbio_seed_hits_params* params, nvbio_uint2* deques_dev, uint32_t* sizes_dev,
                                  uint8_t* reseed_dev, void* stream);
 
+/* nvBowtie's APPROXIMATE seed mapper, seed_mapper<APPROX_MAPPING> (mapping_inl.h:114-184,288-342): every seed of the stored (reversed) read is
+ * searched four times -- forwards in `index` and backwards in `reverse_index` (the FM-index of the REVERSED text, nvBowtie's rfmi), as it
+ * stands and complemented -- each search matching its first half exactly and allowing one substitution in the rest; the two searches that
+ * start from the seed's near end also report the exact match.  Every non-empty range is pushed to the read's deque under the max_hits
+ * rule, in the reference's order, with the reference's flags (position in the read, strand, index direction).  reads_dev: reads of
+ * params->read_len symbols back to back (read_bits 2 / 4 / 8).  Deques need nvbio_seed_hits_approx_capacity entries per read. */
+nvbio_status nvbio_seed_hits_approx_capacity(uint32_t seeds_per_read, uint32_t seed_len, uint32_t max_hits, uint32_t* capacity);
+nvbio_status nvbio_seed_hits_map_approx(nvbio_fm_index_t index, nvbio_fm_index_t reverse_index, const void* reads_dev, uint32_t read_bits,
+                                        const uint32_t* read_queue_dev, uint32_t n_reads, const nvbio_seed_hits_params* params,
+                                        nvbio_uint2* deques_dev, uint32_t* sizes_dev, uint8_t* reseed_dev, void* stream);
+
 /* select_kernel (select_inl.h:62-130): every active read (active_in_dev[t] = read id | top_flag << 31, the reference's packed_read) whose
  * search has not stopped (trys_dev[read] != 0; NULL = never) and which has a hit left takes a slot of the output queue: its next SA row
  * goes to hits->hit_loc_dev[slot], with hits->hit_read_id_dev[slot], hits->hit_seed_dev[slot] = packed_seed( pos_in_read, index_dir, rc,

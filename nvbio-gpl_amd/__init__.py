@@ -938,6 +938,20 @@ def seed_hits_map(fw_ranges, rc_ranges, params, n_reads, deques, sizes, reseed=N
                                      ctypes.byref(params.c), _ptr(deques), _ptr(sizes), _ptr(reseed), _stream_ptr(dev)))
 
 
+def seed_hits_approx_capacity(params):
+    cap = ctypes.c_uint32(0)
+    _check(lib().nvbio_seed_hits_approx_capacity(params.c.seeds_per_read, params.c.seed_len, params.c.max_hits, ctypes.byref(cap)))
+    return cap.value
+
+
+def seed_hits_map_approx(fmi, rfmi, reads, read_bits, params, n_reads, deques, sizes, reseed=None, read_queue=None):
+    """nvBowtie's approximate seed mapper (nvbio_seed_hits_map_approx): fmi = the forward index, rfmi = the index of the reversed text;
+    reads = the stored (reversed) reads of params.read_len symbols back to back; deques [R, seed_hits_approx_capacity, 2]"""
+    dev = deques.device
+    _check(lib().nvbio_seed_hits_map_approx(fmi._h, rfmi._h, _ptr(reads), ctypes.c_uint32(read_bits), _ptr(read_queue), ctypes.c_uint32(n_reads),
+                                            ctypes.byref(params.c), _ptr(deques), _ptr(sizes), _ptr(reseed), _stream_ptr(dev)))
+
+
 def seed_hits_select(active, trys, params, deques, sizes, hits, active_out, count):
     """select_kernel (nvbio_seed_hits_select): active int32 [n] (read | top_flag << 31); fills hits.read_id / loc / seed and active_out;
     count int32 [1] on the device receives the number of slots written"""

@@ -17,6 +17,7 @@
 // the reference's own early-exit values, so ranges are identical with and without it).
 #include "fm_device.h"
 #include "fm_seed_device.h"
+#include "seed_hits_device.h"
 #include <hipcub/hipcub.hpp>
 #include <new>
 #include <stdlib.h>
@@ -686,6 +687,81 @@ fm_hamming_backtrack_kernel(const DevIndex f, const StringSetDev q, const uint32
         }
         counts[i] = total;
         if (n_ranges) n_ranges[i] = nr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// nvBowtie's approximate seed mapper: seed_mapper<APPROX_MAPPING>::enact + map<find_exact> inside map_kernel's loop
+// (nvBowtie/bowtie2/cuda/mapping_inl.h:114-184,288-342,485-556).  Every seed is searched four times -- forwards in the forward index
+// and backwards in the index of the REVERSED text, as it stands and complemented -- each search matching its first half exactly and
+// allowing one substitution in the rest; every non-empty range goes to the read's hit deque under the max_hits rule, in the
+// reference's order.  One lane = one read, as in the reference (the deque is a per-read state machine).
+// ---------------------------------------------------------------------------------------------
+template <class Q>
+__device__ __forceinline__ void map_match_range(const DevIndex& f, uint32_t& x, uint32_t& y, Q& query, const uint32_t begin, const uint32_t end)
+{
+    uint32_t nb = 0;
+    for (uint32_t i = begin; i < end && x <= y; ++i)
+    {
+        const uint32_t c = query( i );
+        if (c > 3u) { x = 1u; y = 0u; return; }
+        search_step<false>( f, x, y, c, nb );
+    }
+}
+
+template <class Q>
+__device__ void map_one_mismatch(const DevIndex& f, Q& query, const uint32_t len1, const uint32_t len2, const bool find_exact, const uint32_t flags,
+                                 HitHeap& heap, const uint32_t max_hits, uint32_t& range_sum, uint32_t& range_count)
+{
+    uint32_t bx = 0u, by = f.length;
+    map_match_range( f, bx, by, query, 0u, len1 );
+    for (uint32_t i = len1; i < len2 && bx <= by; ++i)
+    {
+        const uint32_t c = query( i );
+        uint32_t lo[4], hi[4];
+        rank4_pair( f, bx - 1u, by, lo, hi );
+        for (uint32_t sub = 0; sub < 4u; ++sub)
+            if (sub != c && hi[sub] > lo[sub])
+            {
+                uint32_t x = L2_of( f, sub ) + lo[sub] + 1u, y = L2_of( f, sub ) + hi[sub];
+                map_match_range( f, x, y, query, i + 1u, len2 );
+                if (x <= y) push_seed_hit( heap, max_hits, x, y, flags, range_sum, range_count );
+            }
+        if (c < 4u) { bx = L2_of( f, c ) + lo[c] + 1u; by = L2_of( f, c ) + hi[c]; }
+        else        { bx = 1u; by = 0u; break; }
+    }
+    if (find_exact && bx <= by) push_seed_hit( heap, max_hits, bx, by, flags, range_sum, range_count );
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(128)
+fm_map_approx_kernel(const DevIndex f, const DevIndex rf, const void* __restrict__ symbols, const uint32_t* __restrict__ queue, const uint32_t n_reads,
+                     const uint32_t spr, const uint32_t first_off, const uint32_t interval, const uint32_t seed_len, const uint32_t read_len,
+                     const uint32_t max_hits, const uint32_t rep_seeds, const uint32_t cap, uint2* __restrict__ deques, uint32_t* __restrict__ sizes,
+                     uint8_t* __restrict__ reseed)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_reads; t += gridDim.x * blockDim.x)
+    {
+        const uint32_t r = queue ? queue[t] : t;
+        HitHeap heap; heap.a = deques + (uint64_t)r * cap; heap.n = 0;
+        uint32_t range_sum = 0, range_count = 0;
+        SymbolReader<BITS> rd( symbols );
+        const uint32_t base = r * read_len;                             // reads of one length, back to back
+        for (uint32_t j = 0; j < spr; ++j)
+        {
+            const uint32_t pos = first_off + j * interval;
+            auto fq  = [&](const uint32_t i) -> uint32_t { return rd.get( base + pos + i ); };
+            auto rq  = [&](const uint32_t i) -> uint32_t { return rd.get( base + pos + seed_len - 1u - i ); };
+            auto cfq = [&](const uint32_t i) -> uint32_t { const uint32_t c = fq( i ); return c < 4u ? 3u - c : c; };
+            auto crq = [&](const uint32_t i) -> uint32_t { const uint32_t c = rq( i ); return c < 4u ? 3u - c : c; };
+            // SeedHit::build_flags( readtype, indexdir, pos ): pos << 20 | rc << 30 | indexdir << 31
+            map_one_mismatch( f,  fq,  seed_len / 2u,        seed_len, true,  ((read_len - pos - seed_len) & 0x3FFu) << 20,                       heap, max_hits, range_sum, range_count );
+            map_one_mismatch( rf, rq,  (seed_len + 1u) / 2u, seed_len, false, (((read_len - pos - 1u) & 0x3FFu) << 20) | (1u << 31),              heap, max_hits, range_sum, range_count );
+            map_one_mismatch( rf, cfq, seed_len / 2u,        seed_len, true,  (((pos + seed_len - 1u) & 0x3FFu) << 20) | (1u << 30) | (1u << 31), heap, max_hits, range_sum, range_count );
+            map_one_mismatch( f,  crq, (seed_len + 1u) / 2u, seed_len, false, ((pos & 0x3FFu) << 20) | (1u << 30),                                heap, max_hits, range_sum, range_count );
+        }
+        sizes[r] = heap.n;
+        if (reseed) reseed[r] = (range_count == 0u || range_sum >= rep_seeds * range_count) ? 1 : 0;
     }
 }
 
@@ -1559,6 +1635,43 @@ nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbi
     hipLaunchKernelGGL( fm_filter_locate_kernel<true>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
                         idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)nullptr, direct_dev, ds, keys_dev );
     NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+
+nvbio_status nvbio_seed_hits_map_approx(nvbio_fm_index_t index, nvbio_fm_index_t reverse_index, const void* reads_dev, uint32_t read_bits,
+                                        const uint32_t* read_queue_dev, uint32_t n_reads, const nvbio_seed_hits_params* p, nvbio_uint2* deques_dev,
+                                        uint32_t* sizes_dev, uint8_t* reseed_dev, void* stream)
+{
+    NVB_REQUIRE( index && reverse_index && p, "NULL argument" );
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( reads_dev && deques_dev && sizes_dev, "NULL device pointer" );
+    NVB_REQUIRE( read_bits == 2 || read_bits == 4 || read_bits == 8, "read_bits must be 2, 4 or 8" );
+    NVB_REQUIRE( p->max_hits > 0 && p->seeds_per_read > 0 && p->seed_len > 0, "max_hits, seeds_per_read and seed_len must be positive" );
+    NVB_REQUIRE( (uint64_t)p->first_offset + (uint64_t)(p->seeds_per_read - 1u) * p->seed_interval + p->seed_len <= p->read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( p->read_len < 1024u, "SeedHit keeps the seed position in 10 bits (seed_hit.h:217)" );
+    FMIndexImpl *fi = (FMIndexImpl*)index, *ri = (FMIndexImpl*)reverse_index;
+    NVB_REQUIRE( fi->device == ri->device, "both indices must live on one device" );
+    // up to 3 (len2 - len1) + 1 ranges per search, four searches per seed
+    const uint64_t worst = 4ull * p->seeds_per_read * (3ull * ((p->seed_len + 1u) / 2u) + 1ull);
+    const uint32_t cap = (uint32_t)((worst < p->max_hits ? worst : p->max_hits) + 1u);
+    DeviceGuard g( fi->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    DevIndex f = fi->dev(), rf = ri->dev();
+    const dim3 grid( grid_for( n_reads, 128 ) ), block( 128 );
+#define NVB_LAUNCH_MA(BITS) hipLaunchKernelGGL( (fm_map_approx_kernel<BITS>), grid, block, 0, (hipStream_t)stream, f, rf, reads_dev, read_queue_dev, n_reads, \
+                                                p->seeds_per_read, p->first_offset, p->seed_interval, p->seed_len, p->read_len, p->max_hits, p->rep_seeds, cap,   \
+                                                (uint2*)deques_dev, sizes_dev, reseed_dev )
+    switch (read_bits) { case 2: NVB_LAUNCH_MA(2); break; case 4: NVB_LAUNCH_MA(4); break; default: NVB_LAUNCH_MA(8); break; }
+#undef NVB_LAUNCH_MA
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_seed_hits_approx_capacity(uint32_t seeds_per_read, uint32_t seed_len, uint32_t max_hits, uint32_t* capacity)
+{
+    NVB_REQUIRE( capacity != nullptr, "capacity is NULL" );
+    const uint64_t worst = 4ull * seeds_per_read * (3ull * ((seed_len + 1u) / 2u) + 1ull);
+    *capacity = (uint32_t)((worst < max_hits ? worst : max_hits) + 1u);
     return NVBIO_OK;
 }
 

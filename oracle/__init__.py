@@ -409,6 +409,18 @@ class Oracle:
                                              ctypes.c_uint32(rep_seeds), _p(deque, _u32p), ctypes.byref(size))
         return deque[:size.value].copy(), bool(reseed)
 
+    def map_approx_read(self, idx, ridx, stored, seed_off, seed_len, max_hits, rep_seeds):
+        """seed_mapper<APPROX_MAPPING> for one read (mapping_inl.h:114-184,288-342): idx / ridx = the forward index and the index of the
+        reversed text, stored = the read as nvBowtie stores it (reversed), one symbol per byte -> (deque [n, 2], reseed)"""
+        v, rv = idx.view(), ridx.view()
+        stored = _c8(stored); seed_off = _c32(seed_off)
+        cap = 4 * len(seed_off) * (3 * ((seed_len + 1) // 2) + 1) + 1
+        deque = np.zeros((cap, 2), dtype=np.uint32); size = ctypes.c_uint32(0)
+        reseed = self.lib.orc_map_approx_read(ctypes.byref(v), ctypes.byref(rv), _p(stored, _u8p), ctypes.c_uint32(len(stored)), _p(seed_off, _u32p),
+                                              ctypes.c_uint32(len(seed_off)), ctypes.c_uint32(seed_len), ctypes.c_uint32(max_hits),
+                                              ctypes.c_uint32(rep_seeds), _p(deque, _u32p), ctypes.byref(size))
+        return deque[:size.value].copy(), bool(reseed)
+
     def select_read(self, deque, top_flag):
         """select_kernel for one read (select_inl.h:62-130); deque [n, 2] is updated in place (returned with its new size)
         -> (selected, sa_pos, packed_seed, top_flag, deque)"""

@@ -1555,3 +1555,80 @@ void orc_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32
     for (uint32_t k = 0; k < n; ++k) { heap_out[2 * k] = a[k].begin; heap_out[2 * k + 1] = a[k].bits; }
     free( a );
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * nvBowtie's approximate seed mapper, seed_mapper<APPROX_MAPPING> (nvBowtie/bowtie2/cuda/mapping_inl.h:114-184,288-342): every seed is
+ * searched four times -- forwards in the forward index and backwards in the index of the REVERSED text, as it stands and
+ * complemented -- each search matching its first half exactly and allowing ONE substitution in the rest (`map`), the searches that
+ * start from the seed's far end leaving the exact match to the other one.  Device-only source: parity unpinned; rank / rank4 / the
+ * deque are pinned.
+ * ------------------------------------------------------------------------------------------------------------------- */
+/* match_range (mapping_inl.h:73-86): backward-search steps over query[begin, end) in that order */
+static void map_match_range(const orc_fm_index* f, uint32_t range[2], const uint8_t* q, uint32_t begin, uint32_t end)
+{
+    for (uint32_t i = begin; i < end && range[0] <= range[1]; ++i)
+    {
+        const uint8_t c = q[i];
+        if (c > 3) { range[0] = 1u; range[1] = 0u; return; }
+        uint32_t r[2];
+        orc_rank2( f, range[0] - 1u, range[1], c, r );
+        range[0] = f->L2[c] + r[0] + 1u; range[1] = f->L2[c] + r[1];
+    }
+}
+static void map_push(orc_seed_hit* deque, uint32_t* n, uint32_t max_hits, const uint32_t range[2], uint32_t flags, uint32_t* sum, uint32_t* count)
+{
+    orc_seed_hit h;
+    h.begin = range[0];
+    h.bits  = ((range[1] + 1u - range[0]) & 0xFFFFFu) | flags;
+    if (*n == max_hits) orc_hit_deque_pop_bottom( deque, n );
+    orc_hit_deque_push( deque, n, h );
+    *sum += range[1] - range[0] + 1u; ++*count;
+}
+/* map<find_exact> (:114-184) */
+static void map_one_mismatch(const orc_fm_index* f, const uint8_t* q, uint32_t len1, uint32_t len2, int find_exact, uint32_t flags,
+                             orc_seed_hit* deque, uint32_t* n, uint32_t max_hits, uint32_t* sum, uint32_t* count)
+{
+    uint32_t base[2] = { 0u, f->length };
+    map_match_range( f, base, q, 0u, len1 );
+    for (uint32_t i = len1; i < len2 && base[0] <= base[1]; ++i)
+    {
+        const uint8_t c = q[i];
+        uint32_t lo[4], hi[4];
+        orc_rank4( f, base[0] - 1u, lo ); orc_rank4( f, base[1], hi );
+        for (uint8_t sub = 0; sub < 4; ++sub)
+            if (sub != c && hi[sub] > lo[sub])
+            {
+                uint32_t range[2] = { f->L2[sub] + lo[sub] + 1u, f->L2[sub] + hi[sub] };
+                map_match_range( f, range, q, i + 1u, len2 );
+                if (range[0] <= range[1]) map_push( deque, n, max_hits, range, flags, sum, count );
+            }
+        if (c < 4) { base[0] = f->L2[c] + lo[c] + 1u; base[1] = f->L2[c] + hi[c]; }
+        else       { base[0] = 1u; base[1] = 0u; break; }
+    }
+    if (find_exact && base[0] <= base[1]) map_push( deque, n, max_hits, base, flags, sum, count );
+}
+/* map_kernel's loop over the seeds of ONE read with seed_mapper<APPROX_MAPPING>; stored = the read as nvBowtie stores it (reversed),
+ * one symbol per byte; f = forward index, rf = the index of the reversed text.  Returns the reseeding decision. */
+int orc_map_approx_read(const orc_fm_index* f, const orc_fm_index* rf, const uint8_t* stored, uint32_t read_len, const uint32_t* seed_off, uint32_t n_seeds,
+                        uint32_t seed_len, uint32_t max_hits, uint32_t rep_seeds, orc_seed_hit* deque, uint32_t* deque_size)
+{
+    uint32_t n = 0, sum = 0, count = 0;
+    uint8_t fq[64], rq[64], cfq[64], crq[64];
+    for (uint32_t j = 0; j < n_seeds; ++j)
+    {
+        const uint32_t pos = seed_off[j];                                  /* pos - read_range.x */
+        for (uint32_t k = 0; k < seed_len; ++k)
+        {
+            fq[k] = stored[pos + k]; rq[k] = stored[pos + seed_len - 1u - k];
+            cfq[k] = fq[k] < 4 ? 3 - fq[k] : fq[k]; crq[k] = rq[k] < 4 ? 3 - rq[k] : rq[k];
+        }
+        /* flags: pos:10 << 20 | rc << 30 | indexdir << 31 (SeedHit::build_flags( readtype, indexdir, pos )) */
+        map_one_mismatch( f,  fq,  seed_len / 2u,        seed_len, 1, (((read_len - pos - seed_len) & 0x3FFu) << 20),                         deque, &n, max_hits, &sum, &count );
+        map_one_mismatch( rf, rq,  (seed_len + 1u) / 2u, seed_len, 0, (((read_len - pos - 1u) & 0x3FFu) << 20) | (1u << 31),                  deque, &n, max_hits, &sum, &count );
+        map_one_mismatch( rf, cfq, seed_len / 2u,        seed_len, 1, (((pos + seed_len - 1u) & 0x3FFu) << 20) | (1u << 30) | (1u << 31),     deque, &n, max_hits, &sum, &count );
+        map_one_mismatch( f,  crq, (seed_len + 1u) / 2u, seed_len, 0, ((pos & 0x3FFu) << 20) | (1u << 30),                                    deque, &n, max_hits, &sum, &count );
+    }
+    *deque_size = n;
+    return (count == 0u || sum >= rep_seeds * count) ? 1 : 0;
+}

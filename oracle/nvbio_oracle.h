@@ -223,6 +223,8 @@ void     orc_hit_deque_pop_top(orc_seed_hit* a, uint32_t* n);
 uint32_t orc_hit_deque_top(uint32_t n);
 int      orc_map_exact_read(const uint32_t* fw, const uint32_t* rc, const uint32_t* seed_off, uint32_t n_seeds, uint32_t read_len, uint32_t seed_len,
                             uint32_t max_hits, uint32_t rep_seeds, orc_seed_hit* deque, uint32_t* deque_size);
+int      orc_map_approx_read(const orc_fm_index* f, const orc_fm_index* rf, const uint8_t* stored, uint32_t read_len, const uint32_t* seed_off, uint32_t n_seeds,
+                             uint32_t seed_len, uint32_t max_hits, uint32_t rep_seeds, orc_seed_hit* deque, uint32_t* deque_size);
 int      orc_select_read(orc_seed_hit* deque, uint32_t* size, uint32_t* top_flag, uint32_t* sa_pos, uint32_t* packed_seed);
 void     orc_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32_t* bits, uint32_t n_ops, uint32_t max_hits,
                            uint32_t* heap_out, uint32_t* size_out, uint32_t* out_rows);

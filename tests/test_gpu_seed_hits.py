@@ -105,3 +105,42 @@ def test_best_approx_loop_equals_the_oracle(amd, orc, mode):
     aligned = got["best_loc"].cpu().numpy() >= 0
     assert aligned[:-15].mean() > 0.97 and not aligned[-15:].any()
     fmi.close()
+
+
+@pytest.mark.parametrize("max_hits", [100, 7])
+def test_approximate_seed_mapper_equals_the_oracle(amd, orc, max_hits):
+    """seed_mapper<APPROX_MAPPING>: four one-mismatch searches per seed over the forward index and the index of the reversed text; the
+    deques (hit for hit, in heap order, with the reference's flags) and the reseeding decisions equal the oracle's restatement"""
+    import torch
+    rng = np.random.default_rng(55)
+    G = 120_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    text[3000:3400] = np.tile(text[3000:3010], 40)                 # a tandem repeat: many one-mismatch neighbours
+    hidx, ridx = orc.build_index(text), orc.build_index(text[::-1].copy())
+    fmi = amd.FMIndex.build(orc.pack2(text), G, kmer_len=0, sa_int=16)
+    rfmi = amd.FMIndex.build(orc.pack2(text[::-1].copy()), G, kmer_len=0, sa_int=16)
+    R, M, L, S = 600, 100, 20, 13
+    starts = rng.integers(0, G - M, R); starts[:40] = rng.integers(2990, 3300, 40)
+    reads = np.stack([text[s:s + M] for s in starts]).copy()
+    mut = rng.random(reads.shape) < 0.03
+    reads[mut] = (reads[mut] + 1 + rng.integers(0, 3, int(mut.sum()))) % 4
+    reads[rng.random(reads.shape) < 0.003] = 4
+    rcm = rng.random(R) < 0.5
+    reads[rcm] = np.where(reads[rcm][:, ::-1] < 4, 3 - reads[rcm][:, ::-1], 4)
+    stored = np.ascontiguousarray(reads[:, ::-1])
+    spr = (M - L) // S + 1
+    sp = amd.SeedHitsParams(spr, S, L, M, max_hits=max_hits, rep_seeds=50)
+    cap = amd.seed_hits_approx_capacity(sp)
+    deques = torch.zeros((R, cap, 2), dtype=torch.int32, device="cuda:0")
+    sizes = torch.zeros(R, dtype=torch.int32, device="cuda:0"); reseed = torch.zeros(R, dtype=torch.uint8, device="cuda:0")
+    for bits, packed in ((4, orc.pack4(stored.reshape(-1))), (8, stored.reshape(-1))):
+        dt = torch.from_numpy(packed.view(np.int32) if bits == 4 else packed).cuda()
+        amd.seed_hits_map_approx(fmi, rfmi, dt, bits, sp, R, deques, sizes, reseed)
+        d, n, rs = amd.u32(deques), sizes.cpu().numpy(), reseed.cpu().numpy()
+        total = 0
+        for r in range(R):
+            want, want_rs = orc.map_approx_read(hidx, ridx, stored[r], np.arange(spr) * S, L, max_hits, 50)
+            assert n[r] == len(want) and np.array_equal(d[r, :n[r]], want) and bool(rs[r]) == want_rs, (bits, r)
+            total += len(want)
+        assert total > 5 * R                                        # plenty of hits, and with max_hits = 7 the cap bites
+    fmi.close(); rfmi.close()
