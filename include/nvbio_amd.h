@@ -203,6 +203,31 @@ nvbio_status nvbio_fm_rank(nvbio_fm_index_t index, const uint32_t* rows_dev, con
 nvbio_status nvbio_fm_rank4(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,
                             uint32_t* out_dev, void* stream);
 
+/* The GENERIC rank dictionary of the reference (nvbio/fmindex/rank_dictionary.h; dispatch_rank over plain words,
+ * rank_dictionary_inl.h:206-336): 2-bit big-endian text in 32- or 64-bit words (PackedStream<const uint32*|const uint64*,uint8,2,true>),
+ * a separate occurrence table occ[4 k + c] = # c in text[0, k K) (build_occurrence_table<K>, :33-66), indices and counts of 32 or 64 bits
+ * -- the layouts of the reference's own rank test (nvbio-test/rank_test.cu:83-227: uint32 / K = 64; uint64 / K = 128 with 64-bit indices),
+ * and the one to use beyond 2^32 symbols.  (The production layout, 32-byte records of BWT + occ, is served by nvbio_fm_rank.)
+ *   nvbio_rank_dictionary_occ_entries : entries (of index_bits each) the occurrence table needs = 4 ceil(length / K)
+ *   nvbio_rank_dictionary_build       : fills occ_out_dev; counts[c] (host) = total occurrences of c; synchronizes
+ *   nvbio_rank_dictionary_rank        : out[q] = rank( dict, idx[q], sym[q] ) = occurrences of sym[q] in text[0, idx[q]] (inclusive);
+ *                                       idx = all ones (-1) gives 0 (:278-279); idx / out are index_bits wide
+ *   nvbio_rank_dictionary_rank4       : out[4 q + c] = rank( dict, idx[q], c ) for the four symbols (rank4, :294-309)            */
+typedef struct
+{
+    const void* text_dev;
+    uint32_t    word_bits;     /* 32 or 64 */
+    const void* occ_dev;       /* NULL for nvbio_rank_dictionary_build */
+    uint32_t    index_bits;    /* 32 or 64 */
+    uint32_t    K;             /* symbols per block: a power of two, a multiple of the symbols per word */
+    uint64_t    length;        /* symbols */
+} nvbio_rank_dictionary;
+nvbio_status nvbio_rank_dictionary_occ_entries(const nvbio_rank_dictionary* dict, uint64_t* entries);
+nvbio_status nvbio_rank_dictionary_build(int device, const nvbio_rank_dictionary* dict, void* occ_out_dev, uint64_t counts[4], void* stream);
+nvbio_status nvbio_rank_dictionary_rank(int device, const nvbio_rank_dictionary* dict, const void* idx_dev, const uint8_t* syms_dev, uint32_t n,
+                                        void* out_dev, void* stream);
+nvbio_status nvbio_rank_dictionary_rank4(int device, const nvbio_rank_dictionary* dict, const void* idx_dev, uint32_t n, void* out_dev, void* stream);
+
 /* out_dev[i] = basic_inv_psi(fmi, rows_dev[i]): one LF step, the row of the suffix one symbol to the
  * left (nvbio/fmindex/fmindex_inl.h:286-309); rows_dev == out_dev is allowed */
 nvbio_status nvbio_fm_basic_inv_psi(nvbio_fm_index_t index, const uint32_t* rows_dev, uint32_t n,

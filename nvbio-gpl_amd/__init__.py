@@ -95,6 +95,11 @@ class _SeedHitsParams(ctypes.Structure):
                                                 "rep_seeds", "max_effort", "min_ext", "max_ext")]
 
 
+class _RankDict(ctypes.Structure):
+    _fields_ = [("text_dev", ctypes.c_void_p), ("word_bits", ctypes.c_uint32), ("occ_dev", ctypes.c_void_p), ("index_bits", ctypes.c_uint32),
+                ("K", ctypes.c_uint32), ("length", ctypes.c_uint64)]
+
+
 _lib = None
 
 
@@ -974,3 +979,43 @@ def score_reduce_effort(active, hits, read_len, n_ext, params, best, best_rc, tr
     _check(lib().nvbio_score_reduce_effort(FMIndex._dev_index(hits.device), _ptr(active), ctypes.byref(hq), ctypes.c_uint32(read_len),
                                            ctypes.c_uint32(n_ext), ctypes.byref(params.c), _ptr(best), _ptr(best_rc), _ptr(trys), _ptr(sizes),
                                            _stream_ptr(hits.device)))
+
+
+# ---- the generic rank dictionary (nvbio_rank_dictionary_*) -------------------------------------------------------------------------
+class RankDictionary:
+    """nvbio::rank_dictionary<2, K, PackedStream<const uint32*|const uint64*, uint8, 2, true>, occ, count_table> over plain word storage
+    with a separate occurrence table and 32- or 64-bit indices (nvbio/fmindex/rank_dictionary_inl.h:206-336).  text: int32 tensor of
+    32-bit words or int64 tensor of 64-bit words (bit patterns), on the device."""
+
+    def __init__(self, text, length, K, index_bits):
+        torch = _torch()
+        self.text, self.length, self.K, self.index_bits = text, int(length), int(K), int(index_bits)
+        self.word_bits = 32 if text.dtype == torch.int32 else 64
+        self.device = text.device
+        d = self._c(None)
+        n = ctypes.c_uint64(0)
+        _check(lib().nvbio_rank_dictionary_occ_entries(ctypes.byref(d), ctypes.byref(n)))
+        self.occ = torch.zeros(max(n.value, 4), dtype=torch.int32 if index_bits == 32 else torch.int64, device=self.device)
+        counts = (ctypes.c_uint64 * 4)()
+        _check(lib().nvbio_rank_dictionary_build(FMIndex._dev_index(self.device), ctypes.byref(d), _ptr(self.occ), counts, _stream_ptr(self.device)))
+        self.counts = [int(c) for c in counts]
+
+    def _c(self, occ):
+        return _RankDict(_ptr(self.text), self.word_bits, _ptr(occ), self.index_bits, self.K, self.length)
+
+    def rank(self, idx, syms):
+        """idx: tensor of index_bits-wide indices; syms uint8 -> ranks (same dtype as idx)"""
+        torch = _torch()
+        out = torch.empty_like(idx)
+        d = self._c(self.occ)
+        _check(lib().nvbio_rank_dictionary_rank(FMIndex._dev_index(self.device), ctypes.byref(d), _ptr(idx), _ptr(syms), ctypes.c_uint32(idx.numel()),
+                                                _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def rank4(self, idx):
+        torch = _torch()
+        out = torch.empty((idx.numel(), 4), dtype=idx.dtype, device=idx.device)
+        d = self._c(self.occ)
+        _check(lib().nvbio_rank_dictionary_rank4(FMIndex._dev_index(self.device), ctypes.byref(d), _ptr(idx), ctypes.c_uint32(idx.numel()), _ptr(out),
+                                                 _stream_ptr(self.device)))
+        return out

@@ -438,6 +438,21 @@ class Oracle:
                                                  ctypes.c_uint32(max_effort), ctypes.c_uint32(min_ext), ctypes.c_uint32(max_ext))
         return [int(v) for v in b], t.value, bool(erase)
 
+    def rank_generic(self, text_words, word_bits, length, K, index_bits, idx, sym):
+        """the generic rank dictionary (rank_dictionary_inl.h:206-336): build_occurrence_table<K> + rank(dict, i, c) for every (idx, sym) pair
+        -> (occ [blocks, 4], counts [4], ranks)"""
+        tw = np.ascontiguousarray(text_words, dtype=np.uint32 if word_bits == 32 else np.uint64)
+        nb = (length + K - 1) // K
+        occ = np.zeros((max(nb, 1), 4), dtype=np.uint32 if index_bits == 32 else np.uint64)
+        cnt = np.zeros(4, dtype=np.uint64)
+        self.lib.orc_rank_generic.restype = ctypes.c_uint64
+        self.lib.orc_rank_generic_build(tw.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(word_bits), ctypes.c_uint64(length), ctypes.c_uint32(K),
+                                        ctypes.c_uint32(index_bits), occ.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p))
+        out = np.array([self.lib.orc_rank_generic(tw.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(word_bits), occ.ctypes.data_as(ctypes.c_void_p),
+                                                  ctypes.c_uint32(index_bits), ctypes.c_uint32(K), ctypes.c_uint64(int(i)), ctypes.c_uint32(int(c)))
+                        for i, c in zip(idx, sym)], dtype=np.uint64)
+        return occ, cnt, out
+
     def mapq(self, version, monotone, perfect_score, min_score, best_score, has_second, second_score):
         """BowtieMapq2 / BowtieMapq3, single-end (nvBowtie/bowtie2/cuda/mapq.h)"""
         return int(self.lib.orc_mapq(ctypes.c_int(version), ctypes.c_int(1 if monotone else 0), ctypes.c_int32(perfect_score),
@@ -507,6 +522,20 @@ class Reference:
         self.lib.ref_hit_deque_run(_p(ops, _u32p), _p(begins, _u32p), _p(bits, _u32p), ctypes.c_uint32(n), ctypes.c_uint32(max_hits),
                     _p(heap, _u32p), ctypes.byref(size), _p(rows, _u32p))
         return heap[:size.value].copy(), rows[:n].copy()
+
+    def rank_generic(self, text_words, word_bits, length, idx, sym):
+        """the reference's generic rank dictionary in its two test configurations (32-bit words / K 64 / uint32, 64-bit words / K 128 / uint64)
+        -> (occ [blocks, 4], counts [4], rank [n], rank4 [n, 4])"""
+        K = 64 if word_bits == 32 else 128
+        tw = np.ascontiguousarray(text_words, dtype=np.uint32 if word_bits == 32 else np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.uint64); sym = _c8(sym)
+        nb = (length + K - 1) // K
+        occ = np.zeros((max(nb, 1), 4), dtype=np.uint32 if word_bits == 32 else np.uint64)
+        cnt = np.zeros(4, dtype=np.uint64); r = np.zeros(len(idx), dtype=np.uint64); r4 = np.zeros((len(idx), 4), dtype=np.uint64)
+        self.lib.ref_rank_generic(ctypes.c_uint32(word_bits), tw.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(length), idx.ctypes.data_as(ctypes.c_void_p),
+                                  _p(sym, _u8p), ctypes.c_uint32(len(idx)), occ.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p),
+                                  r.ctypes.data_as(ctypes.c_void_p), r4.ctypes.data_as(ctypes.c_void_p))
+        return occ, cnt, r, r4
 
     def build_index(self, text):
         text = _c8(text)

@@ -1632,3 +1632,41 @@ int orc_map_approx_read(const orc_fm_index* f, const orc_fm_index* rf, const uin
     *deque_size = n;
     return (count == 0u || sum >= rep_seeds * count) ? 1 : 0;
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The GENERIC rank dictionary (nvbio/fmindex/rank_dictionary_inl.h:33-66 build_occurrence_table, :206-336 dispatch_rank over plain
+ * words, :482-539 rank / rank4): 2-bit big-endian text in 32- or 64-bit words (symbol i at bits [W-2-2(i mod W/2), +2) of word
+ * i / (W/2)), occ[4 k + c] = # c in text[0, k K), indices and counts of 32 or 64 bits.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static uint32_t gen_symbol(const void* text, uint32_t word_bits, uint64_t i)
+{
+    if (word_bits == 32) { const uint32_t w = ((const uint32_t*)text)[i >> 4]; return (w >> (30u - 2u * (uint32_t)(i & 15u))) & 3u; }
+    const uint64_t w = ((const uint64_t*)text)[i >> 5]; return (uint32_t)(w >> (62u - 2u * (uint32_t)(i & 31u))) & 3u;
+}
+/* build_occurrence_table<K>: occ entries as index_bits-wide words; cnt[c] = totals */
+void orc_rank_generic_build(const void* text, uint32_t word_bits, uint64_t length, uint32_t K, uint32_t index_bits, void* occ, uint64_t cnt[4])
+{
+    uint64_t counters[4] = { 0, 0, 0, 0 };
+    for (uint64_t i = 0; i < length; ++i)
+    {
+        if ((i & (K - 1u)) == 0u)
+            for (uint32_t c = 0; c < 4; ++c)
+            {
+                if (index_bits == 32) ((uint32_t*)occ)[(i / K) * 4u + c] = (uint32_t)counters[c];
+                else                  ((uint64_t*)occ)[(i / K) * 4u + c] = counters[c];
+            }
+        ++counters[gen_symbol( text, word_bits, i )];
+    }
+    for (uint32_t c = 0; c < 4; ++c) cnt[c] = counters[c];
+}
+/* rank( dict, i, c ) = occurrences of c in text[0, i] (:276-292); i = all ones -> 0 */
+uint64_t orc_rank_generic(const void* text, uint32_t word_bits, const void* occ, uint32_t index_bits, uint32_t K, uint64_t i, uint32_t c)
+{
+    const uint64_t minus1 = index_bits == 32 ? 0xFFFFFFFFull : ~0ull;
+    if (i == minus1) return 0;
+    const uint64_t k = i / K;
+    uint64_t r = index_bits == 32 ? ((const uint32_t*)occ)[k * 4u + c] : ((const uint64_t*)occ)[k * 4u + c];
+    for (uint64_t j = k * K; j <= i; ++j) r += gen_symbol( text, word_bits, j ) == c;      /* what the word-by-word popcounts add up to */
+    return index_bits == 32 ? (uint32_t)r : r;
+}

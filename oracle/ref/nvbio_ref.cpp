@@ -864,4 +864,48 @@ void ref_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const uint32
     for (uint32 k = 0; k < heap.size(); ++k) { heap_out[2*k] = storage[k].begin; heap_out[2*k+1] = storage[k].bits; }
 }
 
+
+// The GENERIC rank dictionary (nvbio/fmindex/rank_dictionary_inl.h:206-336: plain word storage, separate occurrence table, any K, 32- or
+// 64-bit indices), in the two configurations the reference's own test runs besides the production one (nvbio-test/rank_test.cu:83-227):
+//   word_bits 32: PackedStream<const uint32*,uint8,2,true>,        K = 64,  uint32 indices
+//   word_bits 64: PackedStream<const uint64*,uint8,2,true,uint64>, K = 128, uint64 indices
+// occ_out = build_occurrence_table<K> of the text (4 entries per block, as index-width words); rank_out[q] = rank( dict, idx[q], sym[q] ),
+// rank4_out[4 q ..] = rank4( dict, idx[q] ).  idx 0xFFFF...F is passed through to rank() (-> 0) and skipped for rank4 (undefined there).
+void ref_rank_generic(uint32_t word_bits, const void* text_words, uint64_t length, const uint64_t* idx, const uint8_t* sym, uint32_t n,
+                      void* occ_out, uint64_t* counts_out, uint64_t* rank_out, uint64_t* rank4_out)
+{
+    std::vector<uint32> count_table( 256 );
+    gen_bwt_count_table( &count_table[0] );
+    if (word_bits == 32)
+    {
+        typedef PackedStream<const uint32*,uint8,2,true> stream_type;
+        stream_type text( (const uint32*)text_words );
+        uint32* occ = (uint32*)occ_out; uint32 cnt[4];
+        build_occurrence_table<64>( text.begin(), text.begin() + uint32(length), occ, cnt );
+        for (int c = 0; c < 4; ++c) counts_out[c] = cnt[c];
+        typedef rank_dictionary<2u, 64, stream_type, const uint32*, const uint32*> dict_type;
+        dict_type dict( text, occ, &count_table[0] );
+        for (uint32 q = 0; q < n; ++q)
+        {
+            rank_out[q] = rank( dict, uint32( idx[q] ), uint32( sym[q] ) );
+            if (uint32( idx[q] ) != uint32(-1)) { const uint4 r = rank4( dict, uint32( idx[q] ) ); rank4_out[4*q] = r.x; rank4_out[4*q+1] = r.y; rank4_out[4*q+2] = r.z; rank4_out[4*q+3] = r.w; }
+        }
+    }
+    else
+    {
+        typedef PackedStream<const uint64*,uint8,2,true,uint64> stream_type;
+        stream_type text( (const uint64*)text_words );
+        uint64* occ = (uint64*)occ_out; uint64 cnt[4];
+        build_occurrence_table<128>( text.begin(), text.begin() + length, occ, cnt );
+        for (int c = 0; c < 4; ++c) counts_out[c] = cnt[c];
+        typedef rank_dictionary<2u, 128, stream_type, const uint64*, const uint32*> dict_type;
+        dict_type dict( text, occ, &count_table[0] );
+        for (uint32 q = 0; q < n; ++q)
+        {
+            rank_out[q] = rank( dict, uint64( idx[q] ), uint32( sym[q] ) );
+            if (idx[q] != uint64(-1)) { const uint64_4 r = rank4( dict, uint64( idx[q] ) ); rank4_out[4*q] = r.x; rank4_out[4*q+1] = r.y; rank4_out[4*q+2] = r.z; rank4_out[4*q+3] = r.w; }
+        }
+    }
+}
+
 } // extern "C"

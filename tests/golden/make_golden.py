@@ -439,6 +439,36 @@ def make_deque(R):
     print("deque_golden.npz: %d sequences, %d operations" % (len(cases), off[-1]))
 
 
+def pack_words(sym, word_bits):
+    """2-bit big-endian packing into 32- or 64-bit words (PackedStream<.., 2, true>)"""
+    spw = word_bits // 2
+    n = len(sym)
+    words = np.zeros((n + spw - 1) // spw + 4, dtype=np.uint64)
+    sh = (word_bits - 2 - 2 * (np.arange(n) % spw)).astype(np.uint64)
+    np.bitwise_or.at(words, np.arange(n) // spw, sym.astype(np.uint64) << sh)
+    return words.astype(np.uint32) if word_bits == 32 else words
+
+
+def make_rankdict(R):
+    """the reference's GENERIC rank dictionary (rank_dictionary_inl.h:206-336) in the two configurations of its own test
+    (rank_test.cu:83-227): occurrence table, rank of every (i, c) incl. i = -1, rank4 of every i"""
+    rng = np.random.default_rng(404)
+    n = 7001
+    sym = rng.integers(0, 4, n).astype(np.uint8)
+    sym[3000:3300] = 2
+    out = {"sym": sym}
+    for wb in (32, 64):
+        tw = pack_words(sym, wb)
+        minus1 = (1 << wb) - 1
+        idx = np.repeat(np.concatenate([np.arange(n, dtype=np.uint64), np.array([minus1], dtype=np.uint64)]), 4)
+        cs = np.tile(np.arange(4, dtype=np.uint8), n + 1)
+        occ, cnt, r, r4 = R.rank_generic(tw, wb, n, idx, cs)
+        out["occ%d" % wb] = occ.astype(np.uint64); out["cnt%d" % wb] = cnt
+        out["rank%d" % wb] = r.reshape(n + 1, 4); out["rank4_%d" % wb] = r4[:4 * n:4]
+    np.savez_compressed(os.path.join(HERE, "rankdict_golden.npz"), **out)
+    print("rankdict_golden.npz: %d symbols, 2 configurations" % n)
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -452,3 +482,4 @@ if __name__ == "__main__":
     make_best2(R)
     make_bt(R)
     make_deque(R)
+    make_rankdict(R)

@@ -499,3 +499,25 @@ def test_exact_mapper_select_and_effort_rules(orc):
     best, trys, erase = orc.score_reduce_effort(best, 2, -50, 5040, 0, 1, 150, 4, 3, 2, 400)        # top-seed hits never count
     assert trys == 2 and not erase
     assert orc.score_reduce_effort(best, 2, -50, 5040, 0, 1, 150, 400, 3, 2, 400)[2]               # max_ext reached: stop regardless
+
+
+def test_generic_rank_dictionary_golden(orc, rankdict_golden):
+    """the generic rank dictionary (plain 32- / 64-bit words, separate occurrence table, K = 64 / 128, 32- / 64-bit indices) against the
+    reference's own dispatch_rank in the two configurations its test runs (rank_test.cu:83-227): occ table, totals, rank of every
+    (i, c) including i = -1"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("mg", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = rankdict_golden
+    sym = g["sym"]; n = len(sym)
+    for wb, K in ((32, 64), (64, 128)):
+        tw = mg.pack_words(sym, wb)
+        minus1 = (1 << wb) - 1
+        idx = np.repeat(np.concatenate([np.arange(n, dtype=np.uint64), np.array([minus1], dtype=np.uint64)]), 4)
+        cs = np.tile(np.arange(4, dtype=np.uint8), n + 1)
+        occ, cnt, r = orc.rank_generic(tw, wb, n, K, wb, idx, cs)
+        assert np.array_equal(occ.astype(np.uint64), g["occ%d" % wb]) and np.array_equal(cnt, g["cnt%d" % wb])
+        assert np.array_equal(r.reshape(n + 1, 4), g["rank%d" % wb])
+        assert np.array_equal(g["rank4_%d" % wb], g["rank%d" % wb][:n])          # the reference's rank4 agrees with its rank
+        run = np.cumsum(sym[:, None] == np.arange(4)[None, :], axis=0)           # and both with running counts (rank_test.cu:46-79)
+        assert np.array_equal(g["rank%d" % wb][:n], run.astype(np.uint64))
