@@ -1670,3 +1670,12 @@ uint64_t orc_rank_generic(const void* text, uint32_t word_bits, const void* occ,
     for (uint64_t j = k * K; j <= i; ++j) r += gen_symbol( text, word_bits, j ) == c;      /* what the word-by-word popcounts add up to */
     return index_bits == 32 ? (uint32_t)r : r;
 }
+
+/* sw-benchmark's shape: every pattern against the whole of one text (sw-benchmark.cu:152,362-369), OpenMP over work items */
+void orc_full_gotoh_many_to_one(int type, int blocking, const orc_gotoh_scheme* s, const uint8_t* pats, const uint8_t* quals, const uint32_t* po,
+                                const uint8_t* text, uint32_t text_len, uint32_t n, int32_t min_score, int32_t* scores, uint32_t* sinks)
+{
+    #pragma omp parallel for schedule(dynamic,64)
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        orc_full_gotoh( type, blocking, s, pats + po[i], quals ? quals + po[i] : 0, po[i+1] - po[i], text, text_len, min_score, scores + i, sinks + 2*i );
+}

@@ -203,6 +203,9 @@ void orc_banded_gotoh_packed_batch(uint32_t band, int type, const orc_gotoh_sche
                                    const uint32_t* genome2, const uint32_t* win_begin, const uint32_t* win_end,
                                    uint32_t n, int32_t* scores, uint32_t* sinks);
 
+void orc_full_gotoh_many_to_one(int type, int blocking, const orc_gotoh_scheme* s, const uint8_t* pats, const uint8_t* quals, const uint32_t* po,
+                                const uint8_t* text, uint32_t text_len, uint32_t n, int32_t min_score, int32_t* scores, uint32_t* sinks);
+
 int orc_num_threads(void);
 
 /* hamming_backtrack (nvbio/fmindex/backtrack.h) with a counting delegate; see nvbio_oracle.c */

@@ -908,4 +908,17 @@ void ref_rank_generic(uint32_t word_bits, const void* text_words, uint64_t lengt
     }
 }
 
+
+// sw-benchmark's shape (sw-benchmark/sw-benchmark.cu:152,362-369): every pattern against the WHOLE of one text, the host scheduler's
+// OpenMP parallel-for over work items (batched_inl.h:283-306)
+void ref_full_gotoh_many_to_one(int type, int blocking, int match, int mm, int gap_open, int gap_ext,
+                                const uint8_t* pats, const uint32_t* pat_off, const uint8_t* text, uint32_t text_len, uint32_t n,
+                                int32_t min_score, int32_t* scores, uint32_t* sinks)
+{
+    #pragma omp parallel for schedule(dynamic,64)
+    for (int64 i = 0; i < int64(n); ++i)
+        ref_full_gotoh( type, blocking, match, mm, gap_open, gap_ext, pats + pat_off[i], pat_off[i+1] - pat_off[i], text, text_len,
+                        min_score, scores + i, sinks + 2*i );
+}
+
 } // extern "C"

@@ -34,7 +34,7 @@ def test_generic_rank_golden(amd, rankdict_golden):
         occ = rd.occ.cpu().numpy().view(np.uint32 if wb == 32 else np.uint64)[:4 * nb].reshape(nb, 4).astype(np.uint64)
         assert np.array_equal(occ, g["occ%d" % wb]) and rd.counts == [int(c) for c in g["cnt%d" % wb]]
         ity = np.uint32 if wb == 32 else np.uint64
-        idx = np.repeat(np.concatenate([np.arange(n), [(1 << wb) - 1]]).astype(ity), 4)
+        idx = np.repeat(np.concatenate([np.arange(n, dtype=np.uint64), np.array([(1 << wb) - 1], dtype=np.uint64)]).astype(ity), 4)
         cs = np.tile(np.arange(4, dtype=np.uint8), n + 1)
         r = rd.rank(_dev(idx), torch.from_numpy(cs).cuda()).cpu().numpy().view(ity).astype(np.uint64)
         assert np.array_equal(r.reshape(n + 1, 4), g["rank%d" % wb])
@@ -52,7 +52,7 @@ def test_generic_rank_other_shapes_equal_the_oracle(amd, orc, wb, K, ib):
     tw = _mg().pack_words(sym, wb)
     rd = amd.RankDictionary(_dev(tw), n, K, ib)
     ity = np.uint32 if ib == 32 else np.uint64
-    q = np.concatenate([rng.integers(0, n, 20000), [0, n - 1, K - 1, K, (1 << ib) - 1]]).astype(ity)
+    q = np.concatenate([rng.integers(0, n, 20000).astype(np.uint64), np.array([0, n - 1, K - 1, K, (1 << ib) - 1], dtype=np.uint64)]).astype(ity)
     cs = rng.integers(0, 4, len(q)).astype(np.uint8)
     got = rd.rank(_dev(q), torch.from_numpy(cs).cuda()).cpu().numpy().view(ity).astype(np.uint64)
     occ, cnt, want = orc.rank_generic(tw, wb, n, K, ib, q.astype(np.uint64), cs)
