@@ -521,3 +521,18 @@ def test_generic_rank_dictionary_golden(orc, rankdict_golden):
         assert np.array_equal(g["rank4_%d" % wb], g["rank%d" % wb][:n])          # the reference's rank4 agrees with its rank
         run = np.cumsum(sym[:, None] == np.arange(4)[None, :], axis=0)           # and both with running counts (rank_test.cu:46-79)
         assert np.array_equal(g["rank%d" % wb][:n], run.astype(np.uint64))
+
+
+def test_arrival_order_rule_differs_from_the_order_free_second_best_on_near_ties(orc):
+    """documented deviation: nvBowtie's score_reduce demotes the old best to second best WITHOUT a distinctness
+    test (reduce_inl.h:113-114), so its second alignment depends on the order hits arrive in; the default pipeline's order-free pass
+    (nvbio_second_candidate_reduce) keeps the best candidate that is distinct from the final best.  Two hits 10 bp apart on one strand:
+    arriving worse-first the reference keeps both (a2 = the worse, not distinct); arriving better-first it keeps only the best; the
+    order-free rule says "no second alignment" either way.  nvbio_score_reduce_effort / pipeline.nvbowtie_best_approx implement the
+    reference's rule."""
+    worst = -90
+    a = orc.score_reduce(np.array([-12, -6], dtype=np.int32), np.array([5000, 5010], dtype=np.uint32), np.array([0, 0], dtype=np.uint8), 150, worst)
+    b = orc.score_reduce(np.array([-6, -12], dtype=np.int32), np.array([5010, 5000], dtype=np.uint32), np.array([0, 0], dtype=np.uint8), 150, worst)
+    assert a[:4] == (1, -6, 5010, 0) and a[4:] == (1, -12, 5000, 0)        # worse first: the demoted old best stays as a2
+    assert b[:4] == (1, -6, 5010, 0) and b[4] == 0                          # better first: the near-by worse hit is not distinct -> no a2
+    # the order-free rule = the reference's loop over candidates in DESCENDING key order = case b, whatever the arrival order
