@@ -685,6 +685,16 @@ nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int t
                                     const int32_t* min_scores_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev,
                                     void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* The Myers bit-vector aligner: aln::banded_alignment_score<band>( aln::EditDistanceAligner<TYPE, aln::MyersTag<5> >, ... )
+ * (nvbio/alignment/myers/myers_banded_inl.h:172-315), the aligner examples/fmmap/fmmap.cu:346-359 instantiates (SEMI_GLOBAL, band 31).
+ * scores_dev[i] = MINUS the edit distance found inside the band that slides down the window's main diagonal, sinks_dev[i] = (text column
+ * where it ends, pattern length); NVBIO_SCORE_MIN / (-1,-1) when nothing is reported (text shorter than the pattern, or nothing reaches
+ * min_score).  As the reference's code behaves, min_score is truncated to an int16 (:258) -- Field_traits<int32>::min() becomes 0 and
+ * only distance-0 columns are reported; pass e.g. -32768 to see every distance.  band <= 32; GLOBAL and SEMI_GLOBAL only; text symbols
+ * must be < 4 (the reference's match-vector set leaves the N vector uninitialised). */
+nvbio_status nvbio_banded_myers_score(int device, uint32_t band, nvbio_alignment_type type, const nvbio_alignment_batch* batch, int32_t min_score,
+                                      int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
+
 /* Scoring into aln::Best2Sink<int32>( distinct_dist ) (nvbio/alignment/sink.h:96-116, sink_inl.h:55-83) instead of BestSink: the
  * best alignment in scores_dev / sinks_dev and a second one, ending more than distinct_dist text positions from the first, in
  * scores2_dev / sinks2_dev (NVBIO_SCORE_MIN / (-1,-1) when there is none).  The reference's sink does not demote the old best

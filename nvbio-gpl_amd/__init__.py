@@ -1019,3 +1019,15 @@ class RankDictionary:
         _check(lib().nvbio_rank_dictionary_rank4(FMIndex._dev_index(self.device), ctypes.byref(d), _ptr(idx), ctypes.c_uint32(idx.numel()), _ptr(out),
                                                  _stream_ptr(self.device)))
         return out
+
+
+def batch_banded_myers_score(band, aln_type, batch, min_score=SCORE_MIN):
+    """aln::batch_banded_alignment_score<BAND>( make_edit_distance_aligner<TYPE, MyersTag<5>>(), ... ) (nvbio_banded_myers_score): the aligner of
+    examples/fmmap -> (scores = -(edit distance), sinks)"""
+    torch = _torch()
+    scores = torch.empty(batch.n, dtype=torch.int32, device=batch.device)
+    sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
+    bs = batch.c_struct()
+    _check(lib().nvbio_banded_myers_score(FMIndex._dev_index(batch.device), ctypes.c_uint32(band), ctypes.c_int(aln_type), ctypes.byref(bs),
+                                          ctypes.c_int32(min_score), _ptr(scores), _ptr(sinks), _stream_ptr(batch.device)))
+    return scores, sinks

@@ -453,6 +453,15 @@ class Oracle:
                         for i, c in zip(idx, sym)], dtype=np.uint64)
         return occ, cnt, out
 
+    def banded_myers(self, band, typ, pat, txt, min_score=SCORE_MIN):
+        """aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE, MyersTag<5>>, ... ) (myers/myers_banded_inl.h:247-342)
+        -> (ok, score = -(edit distance), sink)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32(); sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_banded_myers(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                         ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
     def mapq(self, version, monotone, perfect_score, min_score, best_score, has_second, second_score):
         """BowtieMapq2 / BowtieMapq3, single-end (nvBowtie/bowtie2/cuda/mapq.h)"""
         return int(self.lib.orc_mapq(ctypes.c_int(version), ctypes.c_int(1 if monotone else 0), ctypes.c_int32(perfect_score),
@@ -536,6 +545,15 @@ class Reference:
                                   _p(sym, _u8p), ctypes.c_uint32(len(idx)), occ.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p),
                                   r.ctypes.data_as(ctypes.c_void_p), r4.ctypes.data_as(ctypes.c_void_p))
         return occ, cnt, r, r4
+
+    def banded_myers(self, band, typ, pat, txt, min_score=SCORE_MIN):
+        """aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE, MyersTag<5>>, ... ) (myers/myers_banded_inl.h:247-342)
+        -> (ok, score = -(edit distance), sink)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sc = ctypes.c_int32(); sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.ref_banded_myers(ctypes.c_uint32(band), ctypes.c_int(typ), _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                         ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
 
     def build_index(self, text):
         text = _c8(text)

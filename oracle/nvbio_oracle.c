@@ -1679,3 +1679,53 @@ void orc_full_gotoh_many_to_one(int type, int blocking, const orc_gotoh_scheme* 
     for (int64_t i = 0; i < (int64_t)n; ++i)
         orc_full_gotoh( type, blocking, s, pats + po[i], quals ? quals + po[i] : 0, po[i+1] - po[i], text, text_len, min_score, scores + i, sinks + 2*i );
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The Myers bit-vector aligner: aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE, MyersTag<5> >, ... ) =
+ * banded_myers<BAND, 0, TYPE, 5> (nvbio/alignment/myers/myers_banded_inl.h:247-342) -- the aligner examples/fmmap/fmmap.cu:346-359
+ * instantiates.  A band of BAND bits slides down the main diagonal: one diagonal step per text symbol while pattern symbols enter
+ * the band, then horizontal steps; the score is MINUS the edit distance.  As the code behaves: `min_score` is taken as an int16
+ * (:258: the caller's int32 is truncated -- Field_traits<int32>::min() becomes 0, so that only distance-0 cells get reported),
+ * SEMI_GLOBAL reports every column of the horizontal phase that reaches it (BestSink keeps the last best), GLOBAL the final one.
+ * Text symbols must be < 4 (the constructor of MyersBitVectors<5> leaves B[4] uninitialised, :139-144).
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int myers_column(uint32_t band, uint32_t eq, uint32_t* VP, uint32_t* VN, int horizontal, int s)
+{
+    uint32_t X = eq | *VN;
+    const uint32_t D0 = ((*VP + (X & *VP)) ^ *VP) | X;
+    const uint32_t HN = *VP & D0;
+    const uint32_t HP = *VN | ~(*VP | D0);
+    X = D0 >> 1;
+    *VN = X & HP;
+    *VP = HN | ~(X | HP);
+    if (!horizontal) return 1 - (int)((D0 >> (band - 1u)) & 1u);                  /* diagonal_column (:172-186) */
+    return (int)((HP >> s) & 1u) - (int)((HN >> s) & 1u);                         /* horizontal_column (:194-208) */
+}
+int orc_banded_myers(uint32_t band, int type, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score32,
+                     int32_t* score, uint32_t sink[2])
+{
+    *score = -(1 << 30); sink[0] = sink[1] = 0xFFFFFFFFu;                         /* BestSink<int32>() */
+    if (N < M) return 0;
+    const int16_t min_score = (int16_t)min_score32;                              /* `const int16 min_score` (:258) */
+    uint32_t B[5] = { 0, 0, 0, 0, 0 };
+    uint32_t VP = 0xFFFFFFFFu, VN = 0u;
+    int dist = 0;                                                                /* -C with C = 0 */
+    const uint32_t last = (N - 1u < M) ? N - 1u : M;
+    for (uint32_t i = 0; i < last; ++i)
+    {
+        for (int c = 0; c < 5; ++c) B[c] >>= 1;
+        if (pat[i] < 5) B[pat[i]] |= 1u << (band - 1u);
+        dist -= myers_column( band, B[txt[i]], &VP, &VN, 0, 0 );
+    }
+    int s = (int)band - 1 + (int)M - (int)last;
+    for (uint32_t i = last; i < N && s >= 0; ++i)
+    {
+        for (int c = 0; c < 5; ++c) B[c] >>= 1;
+        dist -= myers_column( band, B[txt[i]], &VP, &VN, 1, s );
+        if (type == ORC_SEMI_GLOBAL && dist >= min_score && *score <= dist) { *score = dist; sink[0] = i + 1u; sink[1] = M; }
+        --s;
+    }
+    if (type == ORC_GLOBAL && dist >= min_score && *score <= dist) { *score = dist; sink[0] = N; sink[1] = M; }
+    return 1;
+}

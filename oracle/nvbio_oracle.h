@@ -234,6 +234,9 @@ void     orc_hit_deque_run(const uint32_t* ops, const uint32_t* begins, const ui
 int      orc_score_reduce_effort(int64_t best[6], uint32_t* trys, int32_t score, uint32_t g_pos, uint32_t read_rc, uint32_t top_flag, uint32_t read_len,
                                  uint32_t ext, uint32_t max_effort, uint32_t min_ext, uint32_t max_ext);
 
+/* the Myers bit-vector aligner as banded_alignment_score<BAND> runs it (myers/myers_banded_inl.h:247-342); score = -(edit distance) */
+int      orc_banded_myers(uint32_t band, int type, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                          int32_t* score, uint32_t sink[2]);
 /* the generic rank dictionary (rank_dictionary_inl.h:33-66,206-336,482-539): plain 32- / 64-bit words, separate occ table, any K,
  * 32- or 64-bit indices */
 void     orc_rank_generic_build(const void* text, uint32_t word_bits, uint64_t length, uint32_t K, uint32_t index_bits, void* occ, uint64_t cnt[4]);

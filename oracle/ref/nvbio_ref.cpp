@@ -289,6 +289,24 @@ int banded_ed_type(int type, const uint8* pat, uint32 M, const uint8* txt, uint3
     return -1;
 }
 
+// the Myers bit-vector aligner, aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE, MyersTag<5> >, ... ) (nvbio/alignment/myers/
+// myers_banded_inl.h:247-342): the aligner examples/fmmap/fmmap.cu:346-359 actually instantiates (GLOBAL and SEMI_GLOBAL only)
+template <uint32 BAND, aln::AlignmentType TYPE>
+int banded_myers_run(const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score, int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::BestSink<int32> best;
+    const bool ok = aln::banded_alignment_score<BAND>(
+        aln::make_edit_distance_aligner<TYPE, aln::MyersTag<5u> >(),
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        min_score,
+        best );
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return ok ? 1 : 0;
+}
+
 // Best2Sink<int32> through the same dispatches (banded and full matrix)
 template <uint32 BAND, aln::AlignmentType TYPE>
 int banded_best2_run(const QualRampScheme& scheme, const uint8* pat, const uint8* quals, uint32 M, const uint8* txt, uint32 N, uint32 dist, int64* out)
@@ -919,6 +937,21 @@ void ref_full_gotoh_many_to_one(int type, int blocking, int match, int mm, int g
     for (int64 i = 0; i < int64(n); ++i)
         ref_full_gotoh( type, blocking, match, mm, gap_open, gap_ext, pats + pat_off[i], pat_off[i+1] - pat_off[i], text, text_len,
                         min_score, scores + i, sinks + 2*i );
+}
+
+
+int ref_banded_myers(uint32_t band, int type, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score, int32_t* score, uint32_t* sink)
+{
+#define REF_MY(B) (type == 0 ? banded_myers_run<B,aln::GLOBAL>( pat, M, txt, N, min_score, score, sink ) : banded_myers_run<B,aln::SEMI_GLOBAL>( pat, M, txt, N, min_score, score, sink ))
+    switch (band)
+    {
+    case 3:  return REF_MY( 3 );
+    case 7:  return REF_MY( 7 );
+    case 15: return REF_MY( 15 );
+    case 31: return REF_MY( 31 );
+    }
+#undef REF_MY
+    return -1;
 }
 
 } // extern "C"

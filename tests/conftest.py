@@ -72,6 +72,11 @@ def best2_golden():
 
 
 @pytest.fixture(scope="session")
+def myers_golden():
+    return np.load(os.path.join(GOLDEN, "myers_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def rankdict_golden():
     return np.load(os.path.join(GOLDEN, "rankdict_golden.npz"), allow_pickle=False)
 

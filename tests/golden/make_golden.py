@@ -469,6 +469,41 @@ def make_rankdict(R):
     print("rankdict_golden.npz: %d symbols, 2 configurations" % n)
 
 
+def myers_cases(seed=31):
+    """(band, type, min_score, pattern, text) cases for the Myers aligner: near-matches at every offset of the window, indels, N's in the
+    pattern, windows shorter / barely longer than the pattern, min_score values on both sides of the int16 truncation"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(1500):
+        band = int(rng.choice([3, 7, 15, 31])); typ = int(rng.choice([0, 2]))
+        M = int(rng.integers(1, 170)); N = max(M + int(rng.integers(-2, 45)), 1)
+        txt = rng.integers(0, 4, N).astype(np.uint8)
+        if rng.random() < 0.85 and N >= M:
+            off = int(rng.integers(0, N - M + 1)); pat = txt[off:off + M].copy()
+            for _ in range(int(rng.integers(0, 5))):
+                pat[rng.integers(0, M)] = rng.integers(0, 5)
+            if rng.random() < 0.3 and M > 10:
+                p = int(rng.integers(2, M - 2)); pat = np.concatenate([pat[:p], pat[p + 1:], rng.integers(0, 4, 1).astype(np.uint8)])
+        else:
+            pat = rng.integers(0, 5, M).astype(np.uint8)
+        ms = int(rng.choice([-(1 << 30), -32768, -3, -12, -100, 0, -40000, -65536 - 7]))
+        cases.append((band, typ, ms, pat, txt))
+    return cases
+
+
+def make_myers(R):
+    cases = myers_cases()
+    po = np.zeros(len(cases) + 1, dtype=np.uint32); to = np.zeros(len(cases) + 1, dtype=np.uint32)
+    out = np.zeros((len(cases), 4), dtype=np.int64)
+    for k, (band, typ, ms, pat, txt) in enumerate(cases):
+        ok, sc, sk = R.banded_myers(band, typ, pat, txt, ms)
+        out[k] = (ok, sc, sk[0], sk[1]); po[k + 1] = po[k] + len(pat); to[k + 1] = to[k] + len(txt)
+    np.savez_compressed(os.path.join(HERE, "myers_golden.npz"), band=np.array([c[0] for c in cases], dtype=np.uint32),
+                        typ=np.array([c[1] for c in cases], dtype=np.int32), min_score=np.array([c[2] for c in cases], dtype=np.int64),
+                        pats=np.concatenate([c[3] for c in cases]), txts=np.concatenate([c[4] for c in cases]), pat_off=po, txt_off=to, out=out)
+    print("myers_golden.npz: %d cases, %d report a score" % (len(cases), int((out[:, 1] > -(1 << 30)).sum())))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -483,3 +518,4 @@ if __name__ == "__main__":
     make_bt(R)
     make_deque(R)
     make_rankdict(R)
+    make_myers(R)

@@ -536,3 +536,13 @@ def test_arrival_order_rule_differs_from_the_order_free_second_best_on_near_ties
     assert a[:4] == (1, -6, 5010, 0) and a[4:] == (1, -12, 5000, 0)        # worse first: the demoted old best stays as a2
     assert b[:4] == (1, -6, 5010, 0) and b[4] == 0                          # better first: the near-by worse hit is not distinct -> no a2
     # the order-free rule = the reference's loop over candidates in DESCENDING key order = case b, whatever the arrival order
+
+
+def test_myers_golden(orc, myers_golden):
+    """the Myers bit-vector aligner (myers_banded_inl.h:172-315, fmmap's aligner) against the reference's own outputs: 1,500 cases over
+    bands 3 / 7 / 15 / 31, GLOBAL and SEMI_GLOBAL, min_score on both sides of the reference's int16 truncation"""
+    g = myers_golden
+    for k in range(len(g["band"])):
+        pat = g["pats"][g["pat_off"][k]:g["pat_off"][k + 1]]; txt = g["txts"][g["txt_off"][k]:g["txt_off"][k + 1]]
+        ok, sc, sk = orc.banded_myers(int(g["band"][k]), int(g["typ"][k]), pat, txt, int(g["min_score"][k]))
+        assert (ok, sc, sk[0], sk[1]) == tuple(int(v) for v in g["out"][k]), k
