@@ -266,6 +266,17 @@ class Oracle:
                                        ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
 
+    def banded_gotoh_staged(self, band, typ, scheme, pat, txt, min_score, quals=None):
+        """the staged scheduler's windowed scoring -> (ran_to_end, score, sink)"""
+        pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        ok = self.lib.orc_banded_gotoh_staged(ctypes.c_uint32(band), ctypes.c_int(typ), ctypes.byref(scheme), _p(pat, _u8p),
+                                              _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                              ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc),
+                                              _p(sk, _u32p))
+        return ok, sc.value, (int(sk[0]), int(sk[1]))
+
     def banded_gotoh_traceback(self, band, typ, scheme, pat, txt, quals=None, cap=4096):
         """-> (traced, score, source, sink, cigar uint16[], ops uint8[]) in backtracking order"""
         pat, txt, quals = _c8(pat), _c8(txt), _c8(quals)
@@ -649,6 +660,23 @@ class Reference:
                                               ctypes.c_uint32(len(txt)), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc),
                                               _p(sk, _u32p))
         return ok, sc.value, (int(sk[0]), int(sk[1]))
+
+    def banded_gotoh_staged(self, band, typ, scheme, pat, txt, min_score, quals=None):
+        """StagedAlignmentUnitBase::run over BandedScoreUnit (batched_stream.h:117-285) -> (ran_to_end, score, sink, windows).
+        The windowed overload reloads its text cache from text[window_begin + j], j < BAND-1, unconditionally
+        (gotoh_banded_inl.h:432-433): the text is handed over with BAND sentinel bytes (255) behind it so that the read is
+        defined -- the value the continuous loop puts there (:569-570)."""
+        pat, quals = _c8(pat), _c8(quals)
+        n = len(txt)
+        txt = np.concatenate([np.asarray(txt, dtype=np.uint8), np.full(band + 1, 255, np.uint8)])
+        sc = ctypes.c_int32()
+        sk = np.zeros(2, dtype=np.uint32)
+        arr = scheme.as_array()
+        r = self.lib.ref_banded_gotoh_staged_ex(ctypes.c_uint32(band), ctypes.c_int(typ), _p(arr, _i32p), _p(pat, _u8p),
+                                                _p(quals, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                                ctypes.c_uint32(n), ctypes.c_int32(min_score), ctypes.byref(sc),
+                                                _p(sk, _u32p))
+        return r & 1, sc.value, (int(sk[0]), int(sk[1])), r >> 1
 
     def banded_ed(self, band, typ, pat, txt):
         """aln::banded_alignment_score<BAND>( EditDistanceAligner<TYPE> ) (ed/ed_banded_inl.h:37-69)"""

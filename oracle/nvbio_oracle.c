@@ -437,9 +437,10 @@ static inline void sink_report(best_sink* s, int32_t score, uint32_t x, uint32_t
 
 /* the banded DP; dirs (optional, M*B bytes) receives every cell's direction vector
  * hdir | edir | fdir as GotohSubmatrixContext::new_cell stores it (gotoh_banded_inl.h:316-330) */
-static int banded_core(uint32_t B, int type, const orc_gotoh_scheme* sc,
-                       const uint8_t* pat, const uint8_t* quals, uint32_t M,
-                       const uint8_t* txt, uint32_t N, best_sink* sink_p, uint8_t* dirs)
+static int banded_core_w(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                         const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                         const uint8_t* txt, uint32_t N, best_sink* sink_p, uint8_t* dirs,
+                         uint32_t window, int32_t min_score)
 {
     best_sink sink = *sink_p;
     /* Reference_cache<BAND> (alignment_base_inl.h:66-90): bands 3,5,7,15 cache whole uint32
@@ -470,6 +471,23 @@ static int banded_core(uint32_t B, int type, const orc_gotoh_scheme* sc,
 
     for (uint32_t i = 0; i < M; ++i)
     {
+        /* the windowed form (:703-727), as the staged scheduler drives it (batched_stream.h:145-180): at the end of every
+         * window short of the pattern's end, stop -- returning false, with whatever LOCAL cells were reported so far -- if no
+         * band cell can still reach min_score (:610-622); otherwise the band goes through a short2 checkpoint clamped from
+         * below at int16_min + 32 (GotohCheckpointedScoringContext::last_row / init, :166-176, :139-147).  The text cache the
+         * next window reloads (:432-433) holds the same symbols the continuous loop carries. */
+        if (window && i && (i % window) == 0)
+        {
+            int32_t mx = H[0];
+            for (uint32_t j = 1; j < B; ++j) mx = imax( mx, H[j] );
+            const int32_t thr = (int32_t)((uint32_t)min_score + (uint32_t)(M - i) * (uint32_t)sc->match);
+            if (mx < thr) { *sink_p = sink; return 0; }
+            for (uint32_t j = 0; j < B; ++j)
+            {
+                H[j] = (int16_t)imax( H[j], -32768 + 32 );
+                F[j] = (int16_t)imax( F[j], -32768 + 32 );
+            }
+        }
         const uint8_t  q  = pat[i];
         const uint8_t  qq = quals ? quals[i] : 0;
         const int32_t  V  = sc->match;
@@ -536,6 +554,30 @@ static int banded_core(uint32_t B, int type, const orc_gotoh_scheme* sc,
     }
     *sink_p = sink;
     return 1;
+}
+
+static int banded_core(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                       const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                       const uint8_t* txt, uint32_t N, best_sink* sink_p, uint8_t* dirs)
+{
+    return banded_core_w( B, type, sc, pat, quals, M, txt, N, sink_p, dirs, 0u, 0 );
+}
+
+/* BatchedBandedAlignmentScore<BAND, stream, DeviceStagedThreadScheduler> for one job (batched_banded_inl.h:165-236,
+ * batched_stream.h:117-285): the score through 32-row windows with the min_score early exit.  Returns 1 if every window
+ * returned true, 0 if one stopped early (or text shorter than the pattern). */
+int orc_banded_gotoh_staged(uint32_t B, int type, const orc_gotoh_scheme* sc,
+                            const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                            const uint8_t* txt, uint32_t N, int32_t min_score,
+                            int32_t* score, uint32_t sink_out[2])
+{
+    best_sink sink; sink_init( &sink );
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    if (B < 2 || B > ORC_MAX_BAND) return -1;
+    if (N < M) return 0;
+    const int r = banded_core_w( B, type, sc, pat, quals, M, txt, N, &sink, 0, 32u, min_score );
+    *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
+    return r;
 }
 
 int orc_banded_gotoh(uint32_t B, int type, const orc_gotoh_scheme* sc,

@@ -126,6 +126,12 @@ int orc_banded_gotoh(uint32_t band, int type, const orc_gotoh_scheme* s,
                      const uint8_t* txt, uint32_t N,
                      int32_t* score, uint32_t sink[2]);
 
+/* the staged scheduler's windowed scoring (32-row windows, min_score early exit); 1 = ran to the end, 0 = stopped early */
+int orc_banded_gotoh_staged(uint32_t band, int type, const orc_gotoh_scheme* s,
+                            const uint8_t* pat, const uint8_t* quals, uint32_t M,
+                            const uint8_t* txt, uint32_t N, int32_t min_score,
+                            int32_t* score, uint32_t sink[2]);
+
 /* banded Gotoh traceback: aln::banded_alignment_traceback (nvbio/alignment/banded_inl.h:354-417,
  * gotoh/gotoh_banded_inl.h:872-948) delivered to nvBowtie's run-length Backtracker
  * (nvBowtie/bowtie2/cuda/alignment_utils.h:115-157).  cigar: io::Cigar elements (type bits 0-1:

@@ -162,6 +162,67 @@ int banded_band(uint32 band, int type, const scheme_type& scheme,
     return -1;
 }
 
+// The staged scheduler's scoring of one job: StagedAlignmentUnitBase::run (nvbio/alignment/batched_stream.h:145-180)
+// calls BandedScoreUnit::execute (:259-284) = the windowed aln::banded_alignment_score<BAND> (banded_inl.h:179-208)
+// over 32-row windows (WINDOW_SIZE, batched_stream.h:119) through one band of short2 checkpoints
+// (batched_banded_inl.h:176-183), until a window returns false or the pattern is consumed.
+template <uint32 BAND, aln::AlignmentType TYPE, typename scheme_type, typename qual_type>
+int banded_staged_run(const scheme_type& scheme,
+                      const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                      int32* score, uint32* sink)
+{
+    typedef vector_view<const uint8*> string_type;
+    aln::BestSink<int32> best;
+    short2 column[BAND];
+    bool valid = true; uint32 windows = 0;
+    for (uint32 window_begin = 0; valid; )
+    {
+        const uint32 window_end = nvbio::min( window_begin + 32u, M );
+        valid = aln::banded_alignment_score<BAND>(
+            aln::make_gotoh_aligner<TYPE>( scheme ),
+            string_type( M, pat ),
+            quals,
+            string_type( N, txt ),
+            min_score,
+            window_begin,
+            window_end,
+            best,
+            &column[0] );
+        ++windows;
+        if (window_end >= M) break;
+        window_begin = window_end;
+    }
+    *score = best.score; sink[0] = best.sink.x; sink[1] = best.sink.y;
+    return (int)windows * 2 + (valid ? 1 : 0);
+}
+template <uint32 BAND, typename scheme_type, typename qual_type>
+int banded_staged_type(int type, const scheme_type& scheme,
+                       const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                       int32* score, uint32* sink)
+{
+    switch (type)
+    {
+    case 0: return banded_staged_run<BAND,aln::GLOBAL>     ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 1: return banded_staged_run<BAND,aln::LOCAL>      ( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 2: return banded_staged_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, quals, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+template <typename scheme_type, typename qual_type>
+int banded_staged_band(uint32 band, int type, const scheme_type& scheme,
+                       const uint8* pat, const qual_type quals, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                       int32* score, uint32* sink)
+{
+    switch (band)
+    {
+    case 3:  return banded_staged_type<3> ( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 7:  return banded_staged_type<7> ( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 15: return banded_staged_type<15>( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    case 31: return banded_staged_type<31>( type, scheme, pat, quals, M, txt, N, min_score, score, sink );
+    }
+    return -1;
+}
+
 // A Backtracer model (concept: nvbio/alignment/alignment.h:130-140) that records exactly what the
 // reference's traceback hands it: the ops in backtracking order and the two clip() calls.
 struct RecordingBacktracer
@@ -657,6 +718,19 @@ int ref_banded_gotoh_ex(uint32_t band, int type, const int32_t* sc,
     return quals ?
         banded_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
         banded_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
+}
+
+// the same through the staged scheduler's 32-row windows (see banded_staged_run); returns 2*windows run + (1 if the last
+// window returned true)
+int ref_banded_gotoh_staged_ex(uint32_t band, int type, const int32_t* sc,
+                               const uint8_t* pat, const uint8_t* quals, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                               int32_t* score, uint32_t* sink)
+{
+    QualRampScheme scheme; scheme.m_match = sc[0]; scheme.m_mm_min = sc[1]; scheme.m_mm_max = sc[2];
+    scheme.m_pat_go = sc[3]; scheme.m_pat_ge = sc[4]; scheme.m_txt_go = sc[5]; scheme.m_txt_ge = sc[6];
+    return quals ?
+        banded_staged_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, sink ) :
+        banded_staged_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, sink );
 }
 
 int ref_banded_ed(uint32_t band, int type, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t* score, uint32_t* sink)
