@@ -608,6 +608,18 @@ nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbio_alignment
                                       const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
                                       int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
 
+/* The same through the reference's staged scheduler: BatchedBandedAlignmentScore<band, stream, DeviceStagedThreadScheduler>
+ * (nvbio/alignment/batched_banded_inl.h:165-236; work unit StagedAlignmentUnitBase / BandedScoreUnit, batched_stream.h:117-285),
+ * i.e. the windowed banded_alignment_score (banded_inl.h:179-208, gotoh/gotoh_banded_inl.h:703-727) over 32-row windows.  What
+ * differs from nvbio_banded_gotoh_score in the RESULT: a job stops at a window's end when max(band) < min_score + rows left x match
+ * (:610-622, the sign as the reference has it: exact for a zero match bonus, stricter than "cannot reach min_score" otherwise) -- LOCAL keeps what it reported so far, GLOBAL / SEMI_GLOBAL report nothing (NVBIO_SCORE_MIN, sink (-1,-1)) -- and the
+ * band passes through int16 checkpoints clamped at -32736 between windows.  min_score of job i = min_scores_dev[i] (the stream's
+ * context->min_score), or min_score for every job when min_scores_dev is NULL.  Instantiated for read_bits/text_bits 4/2, 2/2, 8/8. */
+nvbio_status nvbio_banded_gotoh_score_staged(int device, uint32_t band, nvbio_alignment_type type,
+                                             const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                             const int32_t* min_scores_dev, int32_t min_score,
+                                             int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
+
 /* Banded Gotoh traceback: aln::banded_alignment_traceback<band,CHECKPOINTS> / BatchedBandedAlignmentTraceback
  * (nvbio/alignment/banded_inl.h:354-483, gotoh/gotoh_banded_inl.h:730-950; nvBowtie banded_traceback_best,
  * traceback_inl.h:191-247) with nvBowtie's run-length Backtracker as the backtracer

@@ -589,20 +589,29 @@ class AlignmentBatch:
                       self.n, self.max_read_len, self.algo_flags)
 
 
+DEVICE_THREAD_SCHEDULER = "DeviceThreadScheduler"
+DEVICE_STAGED_THREAD_SCHEDULER = "DeviceStagedThreadScheduler"     # nvbio/alignment/batched.h: the 32-row-window work queue
+
+
 class BatchedBandedAlignmentScore:
     """aln::BatchedBandedAlignmentScore<BAND_LEN, stream, scheduler> (nvbio/alignment/batched.h:298,
-    batched_banded_inl.h:90-157): enact() scores every job of the stream."""
+    batched_banded_inl.h:90-157): enact() scores every job of the stream.  scheduler =
+    DEVICE_STAGED_THREAD_SCHEDULER gives the results of the staged specialization (batched_banded_inl.h:165-236): 32-row windows
+    with the min_score exit; min_scores (int32 per job, or one int) is then the stream's context->min_score."""
 
-    def __init__(self, band_len, aligner):
-        self.band_len, self.aligner = int(band_len), aligner
+    def __init__(self, band_len, aligner, scheduler=DEVICE_THREAD_SCHEDULER):
+        self.band_len, self.aligner, self.scheduler = int(band_len), aligner, scheduler
+        if scheduler not in (DEVICE_THREAD_SCHEDULER, DEVICE_STAGED_THREAD_SCHEDULER):
+            raise NvbioError(1, "unknown scheduler %r" % (scheduler,))
 
-    @staticmethod
-    def min_temp_storage(max_pattern_len, max_text_len, stream_size):
-        return 0        # as the reference's Host/Device thread schedulers (batched_banded_inl.h:100-104)
+    def min_temp_storage(self, max_pattern_len, max_text_len, stream_size):
+        # as the reference's Host/Device thread schedulers (batched_banded_inl.h:100-104); its staged scheduler asks for one band of
+        # short2 checkpoints per queue slot (:176-191) -- this library keeps the band in registers and needs none
+        return 0
 
     max_temp_storage = min_temp_storage
 
-    def enact(self, batch, scores=None, sinks=None):
+    def enact(self, batch, scores=None, sinks=None, min_scores=None):
         torch = _torch()
         if scores is None:
             scores = torch.empty(batch.n, dtype=torch.int32, device=batch.device)
@@ -610,6 +619,18 @@ class BatchedBandedAlignmentScore:
             sinks = torch.empty((batch.n, 2), dtype=torch.int32, device=batch.device)
         bs = batch.c_struct()
         sw = getattr(self.aligner, "sw", None)
+        if self.scheduler == DEVICE_STAGED_THREAD_SCHEDULER:
+            if sw is not None:
+                raise NvbioError(4, "the staged scheduler is instantiated for Gotoh aligners")
+            per_job = min_scores is not None and not isinstance(min_scores, int)
+            if per_job and (min_scores.dtype != torch.int32 or min_scores.numel() != batch.n):
+                raise NvbioError(1, "min_scores: int32 per job")
+            _check(lib().nvbio_banded_gotoh_score_staged(
+                FMIndex._dev_index(batch.device), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
+                ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs), _ptr(min_scores) if per_job else None,
+                ctypes.c_int32(SCORE_MIN if min_scores is None else (0 if per_job else int(min_scores))),
+                _ptr(scores), _ptr(sinks), _stream_ptr(batch.device)))
+            return scores, sinks
         fn = lib().nvbio_banded_sw_score if sw is not None else lib().nvbio_banded_gotoh_score
         _check(fn(FMIndex._dev_index(batch.device), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
                   ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c),

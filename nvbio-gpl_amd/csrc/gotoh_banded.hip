@@ -27,10 +27,17 @@ namespace nvbio_amd {
 // BEST2: the cells are reported one by one, in the reference's order, into a Best2Sink<int32>( distinct_dist )
 // (sink.h:96-116, sink_inl.h:55-83): best in scores / sinks, the second -- more than distinct_dist text positions away --
 // in scores2 / sinks2.  A new best does not demote the old one, so the result depends on the order of the reports.
-template <int BAND, int TYPE, int RBITS, int TBITS, bool BEST2 = false>
+// STAGED: the result of the staged scheduler (BatchedBandedAlignmentScore<BAND,stream,DeviceStagedThreadScheduler>,
+// batched_banded_inl.h:165-236): the windowed banded_alignment_score (gotoh_banded_inl.h:703-727) over 32-row windows
+// (batched_stream.h:119,145-180).  The reference re-queues a job after every window to re-compact divergent waves; what that changes
+// in the RESULT is (a) the exit at a window's end when no band cell can reach min_score any more (:610-622; LOCAL cells reported so far
+// stand, GLOBAL / SEMI_GLOBAL report nothing) and (b) the band passing through int16 checkpoints clamped at int16_min + 32
+// (:139-147,166-176).  Here a lane keeps its job for all rows -- lanes that exit idle until the wave ends -- and applies (a) and (b).
+template <int BAND, int TYPE, int RBITS, int TBITS, bool BEST2 = false, bool STAGED = false>
 __global__ void __launch_bounds__(128)
 banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
-                    const uint32_t distinct_dist = 0, int32_t* __restrict__ scores2 = nullptr, uint2* __restrict__ sinks2 = nullptr)
+                    const uint32_t distinct_dist = 0, int32_t* __restrict__ scores2 = nullptr, uint2* __restrict__ sinks2 = nullptr,
+                    const int32_t* __restrict__ min_scores = nullptr, const int32_t min_score_all = 0)
 {
     // mismatch score per quality value, computed once per workgroup
     __shared__ int32_t s_mm[64];
@@ -96,8 +103,24 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
     #pragma unroll
     for (int j = 0; j < BAND; ++j) F[j] = infimum;
 
+    bool stopped = false;                                        // STAGED: a window returned false
+    const int32_t min_score = STAGED ? (min_scores ? min_scores[job] : min_score_all) : 0;
     for (uint32_t i = 0; i < M; ++i)
     {
+        if (STAGED && i && (i & 31u) == 0u)
+        {
+            int32_t mx = H[0];
+            #pragma unroll
+            for (int j = 1; j < BAND; ++j) mx = max2( mx, H[j] );
+            const int32_t thr = (int32_t)((uint32_t)min_score + (M - i) * (uint32_t)V);
+            if (mx < thr) { stopped = true; break; }
+            #pragma unroll
+            for (int j = 0; j < BAND; ++j)
+            {
+                H[j] = (int32_t)(int16_t)max2( H[j], -32768 + 32 );
+                F[j] = (int32_t)(int16_t)max2( F[j], -32768 + 32 );
+            }
+        }
         const uint32_t pidx = rev ? first + M - 1u - i : first + i;
         uint32_t q = prd.get( pidx );
         if (comp && q < 4u) q = 3u - q;
@@ -164,7 +187,8 @@ banded_gotoh_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ 
         }
     }
 
-    if (TYPE == NVBIO_GLOBAL)                                    // :629-630
+    if (STAGED && stopped) { /* nothing more is reported */ }
+    else if (TYPE == NVBIO_GLOBAL)                               // :629-630
     {
         if (BEST2) report2( H[BAND - 1], M + BAND - 1, M );
         else if (best <= H[BAND - 1]) { best = H[BAND - 1]; best_x = M + BAND - 1; best_y = M; }
@@ -911,6 +935,35 @@ static nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t
     return NVBIO_OK;
 }
 
+template <int BAND, int TYPE>
+static nvbio_status launch_staged_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
+                                       const int32_t* min_scores, int32_t min_score, int32_t* scores, uint2* sinks, hipStream_t s)
+{
+    const dim3 grid( (b.n + 127u) / 128u ), block( 128 );
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_kernel<BAND,TYPE,RB,TB,false,true>), grid, block, 0, s, b, sc, scores, sinks, \
+                                           0u, (int32_t*)nullptr, (uint2*)nullptr, min_scores, min_score )
+    if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
+    else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
+    else if (rbits == 8 && tbits == 8) NVB_GO(8, 8);
+    else { set_error( "staged scoring: read_bits/text_bits %u/%u not instantiated (4/2, 2/2, 8/8)", rbits, tbits ); return NVBIO_ERR_UNSUPPORTED; }
+#undef NVB_GO
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+template <int BAND>
+static nvbio_status launch_staged_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
+                                       const int32_t* min_scores, int32_t min_score, int32_t* scores, uint2* sinks, hipStream_t s)
+{
+    switch (type)
+    {
+    case NVBIO_GLOBAL:      return launch_staged_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, min_scores, min_score, scores, sinks, s );
+    case NVBIO_LOCAL:       return launch_staged_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, min_scores, min_score, scores, sinks, s );
+    case NVBIO_SEMI_GLOBAL: return launch_staged_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, min_scores, min_score, scores, sinks, s );
+    }
+    set_error( "invalid alignment type %d", type );
+    return NVBIO_ERR_INVALID;
+}
+
 template <int BAND>
 static nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits,
                                 int32_t* scores, uint2* sinks, hipStream_t s)
@@ -1028,6 +1081,32 @@ extern "C" nvbio_status nvbio_banded_gotoh_score(int device, uint32_t band, nvbi
     if (b.n == 0) return NVBIO_OK;
     NVB_REQUIRE( scores_dev && sinks_dev, "NULL output pointer" );
     return banded_score( device, band, type, scheme_dev( scheme ), b, batch, scores_dev, sinks_dev, stream );
+}
+
+extern "C" nvbio_status nvbio_banded_gotoh_score_staged(int device, uint32_t band, nvbio_alignment_type type,
+                                                        const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                                        const int32_t* min_scores_dev, int32_t min_score,
+                                                        int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
+    if (band != 3 && band != 7 && band != 15 && band != 31)
+    {
+        set_error( "band %u is not instantiated (3, 7, 15, 31)", band );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    if (b.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( scores_dev && sinks_dev, "NULL output pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const SchemeDev sc = scheme_dev( scheme );
+    switch (band)
+    {
+    case 3:  return launch_staged_type<3> ( type, b, sc, batch->read_bits, batch->text_bits, min_scores_dev, min_score, scores_dev, (uint2*)sinks_dev, s );
+    case 7:  return launch_staged_type<7> ( type, b, sc, batch->read_bits, batch->text_bits, min_scores_dev, min_score, scores_dev, (uint2*)sinks_dev, s );
+    case 15: return launch_staged_type<15>( type, b, sc, batch->read_bits, batch->text_bits, min_scores_dev, min_score, scores_dev, (uint2*)sinks_dev, s );
+    default: return launch_staged_type<31>( type, b, sc, batch->read_bits, batch->text_bits, min_scores_dev, min_score, scores_dev, (uint2*)sinks_dev, s );
+    }
 }
 
 extern "C" nvbio_status nvbio_banded_sw_score(int device, uint32_t band, nvbio_alignment_type type,

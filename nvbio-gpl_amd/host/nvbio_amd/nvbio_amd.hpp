@@ -375,6 +375,35 @@ struct BatchedBandedAlignmentScore
     }
 };
 
+// the reference's staged scheduler tag (nvbio/alignment/batched.h): 32-row windows with the min_score exit.  The stream must also
+// offer min_scores() (int32 per job, device; nullptr = min_score() for all) -- the context->min_score of the reference's stream.
+struct DeviceStagedThreadScheduler {};
+template <typename aligner_t>
+struct FlatStagedAlignmentStream : FlatAlignmentStream<aligner_t>
+{
+    FlatStagedAlignmentStream(const aligner_t& a, const nvbio_alignment_batch& b, const int32_t* min_scores_dev, int32_t min_score_all,
+                              int32_t* scores_dev, nvbio_uint2* sinks_dev, uint32_t max_pattern_len, uint32_t max_text_len)
+        : FlatAlignmentStream<aligner_t>( a, b, scores_dev, sinks_dev, max_pattern_len, max_text_len ), m_min_scores( min_scores_dev ), m_min_score( min_score_all ) {}
+    const int32_t* min_scores() const { return m_min_scores; }
+    int32_t        min_score()  const { return m_min_score; }
+    const int32_t* m_min_scores; int32_t m_min_score;
+};
+template <uint32_t BAND_LEN, typename stream_type>
+struct BatchedBandedAlignmentScore<BAND_LEN,stream_type,DeviceStagedThreadScheduler>
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    // the reference asks for one band of short2 checkpoints per queue slot (batched_banded_inl.h:176-198); the band stays in registers here
+    static uint64_t min_temp_storage(uint32_t, uint32_t, uint32_t) { return 0u; }
+    static uint64_t max_temp_storage(uint32_t, uint32_t, uint32_t) { return 0u; }
+    void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0)
+    {
+        (void)temp_size; (void)temp;
+        const nvbio_gotoh_scheme f = stream.aligner().scheme.flat();
+        check( nvbio_banded_gotoh_score_staged( device, BAND_LEN, (nvbio_alignment_type)aligner_type::TYPE, &f, &stream.batch(),
+                                                stream.min_scores(), stream.min_score(), stream.scores(), stream.sinks(), s ) );
+    }
+};
+
 template <typename stream_type, typename scheduler = AmdDeviceScheduler>
 struct BatchedAlignmentScore
 {

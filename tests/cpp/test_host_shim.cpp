@@ -122,6 +122,24 @@ int main()
             REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
         }
     }
+    // the staged scheduler's specialization (32-row windows, min_score exit): LOCAL with a limit most pairs reach and some do not
+    {
+        typedef aln::GotohAligner<aln::LOCAL,aln::SimpleGotohScheme> aligner_t;
+        typedef aln::FlatStagedAlignmentStream<aligner_t> stream_t;
+        aln::BatchedBandedAlignmentScore<31,stream_t,aln::DeviceStagedThreadScheduler> staged;
+        const int32_t limit = -80;     // stops a job with 3+ mismatches in its first window (see the sign of the test, gotoh_banded_inl.h:619-621)
+        staged.enact( stream_t( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, nullptr, limit, d_scores.data(), d_sinks.data(), M, M + 31 ) );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<int32_t> sc = d_scores.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host();
+        uint32_t stopped = 0;
+        for (uint32_t j = 0; j < J; ++j)
+        {
+            int32_t ws; uint32_t wk[2];
+            stopped += orc_banded_gotoh_staged( 31, 1, &os, &pats[j*M], nullptr, M, &text[wb[j]], we[j] - wb[j], limit, &ws, wk ) == 0;
+            REQUIRE( sc[j] == ws && sk[j].x == wk[0] && sk[j].y == wk[1] );
+        }
+        REQUIRE( stopped > 0 && stopped < J );
+    }
     // the linear-gap Smith-Waterman aligner (unequal deletion / insertion) and the edit-distance aligner through the same class
     {
         const aln::SimpleSmithWatermanScheme sws( 2, -3, -5, -2 );

@@ -504,6 +504,51 @@ def make_myers(R):
     print("myers_golden.npz: %d cases, %d report a score" % (len(cases), int((out[:, 1] > -(1 << 30)).sum())))
 
 
+STAGED_SCHEMES = [(2, 2, 6, -8, -3, -8, -3), (0, 2, 6, -8, -3, -8, -3), (1, 3, 3, -5, -2, -6, -3), (0, 250, 250, -300, -150, -280, -170)]
+
+
+def staged_cases(seed=77):
+    """(band, type, scheme index, min_score, pattern, quals or None, text) for the staged scheduler's windowed scoring: patterns of
+    1..300 rows (0..9 windows), near-matches and far-off pairs, min_score on both sides of what the pair reaches, N's, qualities, a
+    scheme whose scores fall below the int16 checkpoint clamp, texts shorter than pattern + band"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(3000):
+        band = int(rng.choice([3, 7, 15, 31])); typ = int(rng.integers(0, 3))
+        M = int(rng.integers(1, 300)); N = max(M + int(rng.integers(-1, band + 4)), 1)
+        txt = rng.integers(0, 4, N).astype(np.uint8)
+        d = int(rng.integers(0, band))
+        pat = np.resize(txt[min(d, N - 1):], M).copy()
+        mut = rng.random(M) < (0.02 if rng.random() < 0.5 else 0.3)
+        pat[mut] = rng.integers(0, 4, int(mut.sum()))
+        if rng.random() < 0.3 and M > 40:                          # the second half does not match at all
+            pat[M // 2:] = rng.integers(0, 4, M - M // 2)
+        if rng.random() < 0.1:
+            pat[rng.integers(0, M)] = 4
+        si = 0 if typ == 1 else int(rng.choice([1, 1, 1, 2, 3]))
+        quals = rng.integers(0, 50, M).astype(np.uint8) if rng.random() < 0.5 else None
+        ms = int(rng.choice([-(1 << 30), -400, -200, -60, -20, 0, 40, 100, 250]))
+        cases.append((band, typ, si, ms, pat, quals, txt))
+    return cases
+
+
+def make_staged(R):
+    cases = staged_cases()
+    po = np.zeros(len(cases) + 1, dtype=np.uint32); to = np.zeros(len(cases) + 1, dtype=np.uint32)
+    out = np.zeros((len(cases), 5), dtype=np.int64)
+    quals = []
+    for k, (band, typ, si, ms, pat, q, txt) in enumerate(cases):
+        ok, sc, sk, windows = R.banded_gotoh_staged(band, typ, oracle.Scheme(*STAGED_SCHEMES[si]), pat, txt, ms, q)
+        out[k] = (ok, sc, sk[0], sk[1], windows); po[k + 1] = po[k] + len(pat); to[k + 1] = to[k] + len(txt)
+        quals.append(q if q is not None else np.full(len(pat), 255, np.uint8))          # 255 = "no quality string" for this case
+    np.savez_compressed(os.path.join(HERE, "staged_golden.npz"), band=np.array([c[0] for c in cases], dtype=np.uint32),
+                        typ=np.array([c[1] for c in cases], dtype=np.int32), scheme=np.array([c[2] for c in cases], dtype=np.int32),
+                        schemes=np.array(STAGED_SCHEMES, dtype=np.int32), min_score=np.array([c[3] for c in cases], dtype=np.int64),
+                        pats=np.concatenate([c[4] for c in cases]), quals=np.concatenate(quals),
+                        txts=np.concatenate([c[6] for c in cases]), pat_off=po, txt_off=to, out=out)
+    print("staged_golden.npz: %d cases, %d stop early" % (len(cases), int((out[:, 0] == 0).sum())))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -519,3 +564,4 @@ if __name__ == "__main__":
     make_deque(R)
     make_rankdict(R)
     make_myers(R)
+    make_staged(R)

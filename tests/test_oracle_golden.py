@@ -546,3 +546,20 @@ def test_myers_golden(orc, myers_golden):
         pat = g["pats"][g["pat_off"][k]:g["pat_off"][k + 1]]; txt = g["txts"][g["txt_off"][k]:g["txt_off"][k + 1]]
         ok, sc, sk = orc.banded_myers(int(g["band"][k]), int(g["typ"][k]), pat, txt, int(g["min_score"][k]))
         assert (ok, sc, sk[0], sk[1]) == tuple(int(v) for v in g["out"][k]), k
+
+
+def test_staged_banded_golden(orc, staged_golden):
+    """the staged scheduler's windowed banded scoring (batched_stream.h:117-285 over gotoh_banded_inl.h:703-727) against the
+    reference's own outputs: 3,000 cases, 0..9 windows of 32 rows, all three alignment types, min_score on both sides of what the
+    pair can reach, a scheme that drives scores below the int16 checkpoint clamp"""
+    g = staged_golden
+    early = 0
+    for k in range(len(g["band"])):
+        pat = g["pats"][g["pat_off"][k]:g["pat_off"][k + 1]]; txt = g["txts"][g["txt_off"][k]:g["txt_off"][k + 1]]
+        q = g["quals"][g["pat_off"][k]:g["pat_off"][k + 1]]
+        q = None if (len(q) and q[0] == 255) else q
+        ok, sc, sk = orc.banded_gotoh_staged(int(g["band"][k]), int(g["typ"][k]), oracle.Scheme(*[int(v) for v in g["schemes"][g["scheme"][k]]]),
+                                             pat, txt, int(g["min_score"][k]), q)
+        assert (ok, sc, sk[0], sk[1]) == tuple(int(v) for v in g["out"][k][:4]), k
+        early += ok == 0
+    assert early > 500
