@@ -32,7 +32,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
 TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
-SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"
+SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"            # the per-strand pass (--no-canonical)
+SEED_BOTH_KERNEL_TAG = "fm_seed_both_kernel<4, false>"   # the two-strand pass over the canonical table (default)
 
 
 def log(msg):
@@ -146,6 +147,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-direct", action="store_true", help="plain match() + locate() instead of the fused direct-position seed pass")
     ap.add_argument("--no-fused-seeds", action="store_true", help="match_direct + scan + locate_diagonals + dedupe as separate operators instead of the one-kernel seed pass")
+    ap.add_argument("--no-canonical", action="store_true", help="the 128 GiB direct table and one seed pass per strand instead of the 64 GiB canonical "
+                    "table and one pass for both strands")
     ap.add_argument("--no-plain-ab", action="store_true", help="skip the (untimed) run through the plain operators without the two exact shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -202,8 +205,11 @@ def main():
         tmp.close(); del tmp
         torch.cuda.empty_cache()
         t1 = time.time()
+    canonical = (not args.no_canonical and args.sa_int == 1 and args.kmer >= 3 and args.kmer % 2 == 1 and not args.no_direct
+                 and not args.no_fused_seeds)
     try:
-        fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify))
+        fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify),
+                                table_flags=amd.FM_TABLE_CANONICAL if canonical else 0)
     except amd.NvbioError as e:
         if args.kmer <= 16 or "memory" not in str(e):
             raise
@@ -310,13 +316,23 @@ def main():
     strands = ((0, 0), (1, amd.FM_SCAN_FORWARD | amd.FM_COMPLEMENT))
     use_direct = bool(params.direct and fmi.supports_direct())
     use_fused = bool(use_direct and params.fused_seed_pass)
+    use_both = bool(use_fused and fmi.canonical)                 # one launch serves both strands
+    launches = 1 if use_both else 2
+    seed_tag = SEED_BOTH_KERNEL_TAG if use_both else SEED_KERNEL_TAG
     # (1) bytes the TIMED launch has to move, at the 64-byte sector granularity of the fabric (outside the timed region, by the
     #     kernel's accounting instantiation, NVBIO_FM_COUNT_SECTORS): every gather of a search -- direct-table entry, group of a
     #     2..7-occurrence k-mer, bwt_occ records of the rank steps that are left, SA word, text words -- counted as one sector
     #     per distinct 64 bytes, plus what the launch streams: the packed reads once, the tiles' keys and counts written, then
     #     read and written again by the compaction, the residual list.
     launch_bytes = sectors = None
-    if use_fused:
+    if use_both:
+        bufs = fmi.match_seed_diagonals_both(qs, M, flags=amd.FM_COUNT_SECTORS)
+        c = bufs["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        n_tiles = -(-R // (64 // spr))
+        sectors = float(int(c[4] | (c[5] << 32)))
+        launch_bytes = sectors * SECTOR + float(R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * 2 * n_tiles + 12 * int(c[1] + c[2]))
+        del bufs
+    elif use_fused:
         acc = []
         for strand, flags in strands:
             bufs = fmi.match_seed_diagonals(qs, flags | amd.FM_COUNT_SECTORS, M, strand)
@@ -336,7 +352,7 @@ def main():
         _, blk = fmi.match(qs, flags | amd.FM_NO_KMER_TABLE, want_blocks=True)
         blocks += int((blk.to(torch.int64) & 0xFFFFFFFF).sum())
         del blk
-    alg_bytes_per_launch = (blocks * 32 + 2 * n_seeds * (11 + 8)) / 2.0
+    alg_bytes_per_launch = (blocks * 32 + 2 * n_seeds * (11 + 8)) / float(launches)
     nt = []
     for _, flags in strands:
         a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -345,7 +361,7 @@ def main():
         b_ev.record()
         torch.cuda.synchronize()
         nt.append(a_ev.elapsed_time(b_ev))
-    no_table_ms = float(np.mean(nt))
+    no_table_ms = float(np.sum(nt)) / launches                # per launch of the timed pass (both strands when it serves both)
 
     # ---- the same step through the plain operators (outside the timed region): match() + locate() without the fused
     #      direct-position seed pass, and the banded DP for every candidate without the ungapped shortcut.  Results are
@@ -368,7 +384,7 @@ def main():
                  "extend_gcups": float(pnc) * params.band * M / ((pst.get("extend_fw", 0.0) + pst.get("extend_rc", 0.0) + pst.get("extend", 0.0)) * 1e-3) / 1e9,
                  "kmer_table": (args.kmer - 1) if (fmi.supports_direct() and args.kmer >= 2) else args.kmer,   # the handle's plain table
                  "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
-    match_ms = 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
+    match_ms = stage_ms.get("match_both", 0.0) if use_both else 0.5 * (stage_ms.get("match_fw", 0.0) + stage_ms.get("match_rc", 0.0))
     if launch_bytes is None:                    # the separate operators: what their match kernel moves is not accounted; use the reference's bytes
         launch_bytes = alg_bytes_per_launch
     achieved = launch_bytes / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
@@ -379,13 +395,14 @@ def main():
             tj = json.load(open(tpath))
             if (tj.get("ref_len") == n and tj.get("reads") == R and tj.get("kmer") == args.kmer and tj.get("sa_int", 16) == args.sa_int
                     and bool(tj.get("direct", False)) == use_direct and bool(tj.get("fused", False)) == use_fused
-                    and tj.get("kernel_tag") == SEED_KERNEL_TAG):
+                    and tj.get("kernel_tag") == seed_tag):
                 traffic = tj.get("match_hbm_bytes_per_launch")
                 traffic_src = ("profiles/traffic.json (tag %s): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this configuration, "
                                "not measured in this run" % tj.get("tag"))
         except Exception:
             traffic = None
-    # the measured ceiling for this access pattern: a chain of two dependent random 8-byte gathers over 128 GiB
+    # the measured ceiling for this access pattern: a chain of two dependent random 8-byte gathers over the table's footprint (128 GiB
+    # direct table, 64 GiB canonical table)
     # (scripts/ubench/gather_rate.hip, profiles/r02_gather_rate.jsonl)
     ceiling = None
     gpath = os.path.join(ROOT, "profiles", "r02_gather_rate.jsonl")
@@ -395,10 +412,10 @@ def main():
                 gj = json.loads(line)
             except Exception:
                 continue
-            if gj.get("footprint_bytes") == 128 << 30 and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
+            if gj.get("footprint_bytes") == ((64 << 30) if use_both else (128 << 30)) and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
                 ceiling = gj.get("G_gathers_per_s")
     cells = float(nc) * params.band * M
-    extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0) + stage_ms.get("extend", 0.0)
+    extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0) + stage_ms.get("extend", 0.0) + stage_ms.get("extend_res", 0.0)
     step_ms = elapsed / args.steps * 1e3
     build = {"index_and_tables_s": build_s}
     if index_only_s is not None:
@@ -418,7 +435,7 @@ def main():
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
                    "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
-                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
+                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "canonical_table": use_both, "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world,
                    "traceback_in_step": bool(args.with_traceback), "repeat_family_copies": args.repeat_family,
                    "max_seed_hits": params.max_seed_hits},
@@ -427,7 +444,10 @@ def main():
                                  "build": build},
         "aligned_fraction": frac_aligned, "correct_locus_fraction": frac_correct,
         "stage_ms": stage_ms,
-        "roofline": {"kernel": (("seed pass launch of one strand, %d seeds: %s (match + locate + diagonal key + adjacent dedupe of every seed, one wave per "
+        "roofline": {"kernel": (("seed pass launch of BOTH strands, %d seed windows = %d searches: %s (match + locate + diagonal key + adjacent dedupe of every seed "
+                                 "and of its reverse complement from one canonical-table gather per window, one wave per tile of whole reads) followed by the "
+                                 "tile-count scan and fm_seed_compact_kernel (a few %% of the launch)" % (n_seeds, 2 * n_seeds, seed_tag)) if use_both else
+                                ("seed pass launch of one strand, %d seeds: %s (match + locate + diagonal key + adjacent dedupe of every seed, one wave per "
                                  "tile of whole reads) followed by the tile-count scan and fm_seed_compact_kernel (a few %% of the launch)" % (n_seeds, SEED_KERNEL_TAG)) if use_fused else
                                 ("fm_match_kernel<4,false,true,%s> (seed pass, one strand of %d seeds per launch%s)"
                                  % ("true" if use_direct else "false", n_seeds,
@@ -440,7 +460,8 @@ def main():
                      "sectors_per_seed": (sectors / n_seeds) if sectors else None,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,
-                     "queries_per_s": n_seeds / (match_ms * 1e-3) if match_ms > 0 else 0.0,
+                     "launches_per_step": launches,
+                     "queries_per_s": n_seeds * (2 if use_both else 1) / (match_ms * 1e-3) if match_ms > 0 else 0.0,
                      "gather_rate_G_per_s": (sectors / (match_ms * 1e-3) / 1e9) if (sectors and match_ms > 0) else None,
                      "gather_ceiling_G_per_s": ceiling,
                      "frac_of_gather_ceiling": (sectors / (match_ms * 1e-3) / 1e9 / ceiling) if (sectors and ceiling and match_ms > 0) else None,

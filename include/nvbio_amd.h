@@ -124,7 +124,10 @@ enum
     NVBIO_FM_TABLE_NO_DIRECT  = 1,  /* keep the plain SA-range table only, even if the handle holds the full SA and the text      */
     NVBIO_FM_TABLE_NO_CONTEXT = 2,  /* direct table, format 1: one-row entries hold the position only (the rest of a seed is then
                                        verified with a gather from the text)                                                      */
-    NVBIO_FM_TABLE_NO_GROUPS  = 4   /* no groups for k-mers with 2..7 occurrences (they keep their SA range and take rank steps)  */
+    NVBIO_FM_TABLE_NO_GROUPS  = 4,  /* no groups for k-mers with 2..7 occurrences (they keep their SA range and take rank steps)  */
+    NVBIO_FM_TABLE_CANONICAL  = 8   /* instead of the direct table: ONE table for a k-mer and its reverse complement (kmer_len odd; 64 GiB at
+                                       k = 17 where the direct table takes 128), serving nvbio_fm_match_seed_diagonals_both; the plain table of
+                                       (kmer_len - 1)-mers is kept for match().  Needs sa_int = 1.                                */
 };
 
 nvbio_status nvbio_fm_index_build(const uint32_t* text2_dev, uint32_t length, int device,
@@ -260,7 +263,8 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
  * diagonal key (read << 34 | strand << 33 | diagonal + 1024) instead of the (position, query) pair; direct_dev may
  * be NULL (plain ranges).  keys_dev[h - begin] equals nvbio_hits_to_diagonals of the hit nvbio_fm_filter_locate writes.
  * query_ids_dev (optional): the seed id of query i when the ranges are a compacted subset of a seed set (the residual
- * list of nvbio_fm_match_seed_diagonals); NULL = query i is seed i. */
+ * list of nvbio_fm_match_seed_diagonals); NULL = query i is seed i.  Bit 31 of a query id flips `strand` for that query (seed ids are
+ * below 2^31), so that the two residual lists of nvbio_fm_match_seed_diagonals_both can go through one call. */
 nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
                                               const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
                                               uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
@@ -306,6 +310,31 @@ nvbio_status nvbio_fm_match_seed_diagonals_temp_bytes(const nvbio_string_set* se
 nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                            uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
                                            uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes, void* stream);
+
+/* Both strands of every seed in ONE pass (handles built with NVBIO_FM_TABLE_CANONICAL): the outputs of
+ *   nvbio_fm_match_seed_diagonals( flags = 0, strand = 0 )  and
+ *   nvbio_fm_match_seed_diagonals( flags = NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT, strand = 1 )
+ * i.e. match() of every seed and of its reverse complement (nvBowtie maps both, mapping_inl.h:288-414) + locate() of the searches that end
+ * on one row + hit_to_diagonal + the adjacent-duplicate removal, from one table gather per seed window: a k-mer and its reverse
+ * complement share an entry that lists the occurrences of both orientations with the text on either side of each.
+ *   keys_dev[0 .. counts_dev[0])        diagonal keys of both strands (read << 34 | strand << 33 | diagonal + 1024), grouped by tile of
+ *                                       reads: a tile's forward keys in seed order, then its reverse-strand keys in seed order
+ *   residual_*_dev[0 .. counts_dev[1])                              forward-strand searches that ended on several rows (range, seed id)
+ *   residual_*_dev[residual_capacity .. + counts_dev[2])            the same for the reverse strand
+ * keys_dev: 2 * seeds->n entries; residual arrays: 2 * residual_capacity entries, residual_capacity >= seeds->n.  counts_dev: 4 uint32
+ * (6, 8-byte aligned, with NVBIO_FM_COUNT_SECTORS: the distinct 64-byte sectors gathered from the index as a uint64 at counts_dev + 4).
+ * Seeds: packed 2 or 4 bits, fixed length in [kmer_len, kmer_len + 7], at most 64 per read.  flags: NVBIO_FM_COUNT_SECTORS, the grid
+ * knob (bits 16..31) of nvbio_fm_match_seed_diagonals, and NVBIO_FM_INLINE_HITS(h), h in 2..4: a search that ends on up to h rows leaves
+ * ALL their diagonal keys in keys_dev (behind its tile's one-row keys, no duplicate removal) instead of a residual entry -- what
+ * FMIndexFilter's scan + locate would add for it, without the trip; only larger ranges reach the residual lists. */
+#define NVBIO_FM_INLINE_HITS(h) (((uint32_t)(h) & 15u) << 8)
+nvbio_status nvbio_fm_match_seed_diagonals_both_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes);
+nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
+                                                uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
+                                                uint32_t residual_capacity, uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes,
+                                                void* stream);
+/* 1 if the handle holds the canonical two-strand table (built with NVBIO_FM_TABLE_CANONICAL), else 0 */
+int nvbio_fm_index_is_canonical(nvbio_fm_index_t index);
 
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):
  * jt_dev[i] = locate_ssa_iterator(rows[i]) = (sampled row, steps)  (fmindex_inl.h:404-437)

@@ -28,7 +28,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
 FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS, FM_NO_PIPELINE = 1, 2, 4, 8, 16, 32
-FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS = 1, 2, 4      # nvbio_fm_build_options::table_flags
+FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS, FM_TABLE_CANONICAL = 1, 2, 4, 8      # nvbio_fm_build_options::table_flags
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
 # nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)
@@ -374,6 +374,40 @@ class FMIndex:
                                                    _ptr(buffers["ranges"]), _ptr(buffers["ids"]), _ptr(buffers["counts"]),
                                                    _ptr(buffers["temp"]), ctypes.c_uint64(buffers["temp"].numel()),
                                                    _stream_ptr(self.device)))
+        return buffers
+
+    @property
+    def canonical(self):
+        """True if the handle holds the canonical two-strand table (built with FM_TABLE_CANONICAL)"""
+        fn = lib().nvbio_fm_index_is_canonical
+        fn.restype = ctypes.c_int
+        return bool(fn(self._h))
+
+    def match_seed_diagonals_both(self, seeds, read_len, buffers=None, flags=0, grid_blocks=0, inline_hits=0):
+        """the seed pass of BOTH strands in one launch over the canonical table (nvbio_fm_match_seed_diagonals_both) -> the buffers dict:
+        "keys" int64 (the first counts[0]: both strands, tile by tile), "ranges" int32 [2 n, 2] / "ids" int32 [2 n]: residual seeds on
+        several rows, forward strand in [0, counts[1]), reverse strand in [n, n + counts[2]); "counts" int32 [6] on the device.
+        inline_hits (2..4): a search that ends on up to that many rows leaves all their keys in "keys" instead of a residual entry."""
+        torch = _torch()
+        n = seeds.n
+        if buffers is None:
+            buffers = {}
+        qs = seeds.c_struct()
+        if buffers.get("n") != n or buffers.get("spr") != seeds.seeds_per_string:
+            buffers["n"], buffers["spr"] = n, seeds.seeds_per_string
+            buffers["keys"] = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+            buffers["ranges"] = torch.empty((2 * n, 2), dtype=torch.int32, device=self.device)
+            buffers["ids"] = torch.empty(2 * n, dtype=torch.int32, device=self.device)
+            buffers["counts"] = torch.empty(6, dtype=torch.int32, device=self.device)     # [4:6]: FM_COUNT_SECTORS' uint64
+            nb = ctypes.c_uint64(0)
+            _check(lib().nvbio_fm_match_seed_diagonals_both_temp_bytes(ctypes.byref(qs), ctypes.byref(nb)))
+            buffers["temp"] = torch.empty(nb.value, dtype=torch.uint8, device=self.device)
+        assert grid_blocks % 64 == 0 and grid_blocks < (1 << 22)
+        _check(lib().nvbio_fm_match_seed_diagonals_both(
+            self._h, ctypes.byref(qs), ctypes.c_uint32(flags | ((int(inline_hits) & 15) << 8) | ((grid_blocks // 64) << 16)),
+            ctypes.c_uint32(read_len),
+            _ptr(buffers["keys"]), _ptr(buffers["ranges"]), _ptr(buffers["ids"]), ctypes.c_uint32(n), _ptr(buffers["counts"]),
+            _ptr(buffers["temp"]), ctypes.c_uint64(buffers["temp"].numel()), _stream_ptr(self.device)))
         return buffers
 
     def rank(self, rows, syms):

@@ -1,0 +1,389 @@
+// ---------------------------------------------------------------------------------------------
+// fm_canon_inl.h -- the two-strand seed pass over a CANONICAL k-mer table (included by fm_index.hip, inside namespace nvbio_amd).
+//
+// What is computed: for every seed window S of a read, match() of S (the forward strand) AND match() of its reverse complement
+// (nvBowtie searches both, mapping_inl.h:288-414; the fmmap-shaped pipeline runs the seed pass once per strand with
+// NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT), each followed by locate() of a search that ends on one row -- the outputs of two
+// launches of the per-strand pass (fm_seed_pipe_kernel), from ONE table gather per window instead of one per window and strand.
+//
+// How.  Let k = ckmer (odd), r = len - k, W = the last k symbols of S and A = its first r symbols (S = A W).  An occurrence of W in the
+// text at p is a forward hit at p - r iff text[p-r, p) = A; an occurrence of rc(W) at p is a reverse-strand hit at p iff
+// text[p+k, p+k+r) = rc(A) (rc(S) = rc(W) rc(A)).  W and rc(W) share ONE table entry -- the entry of whichever of the two has its
+// middle symbol in {A, C} (k is odd: the middle symbols of W and rc(W) are complements, so exactly one qualifies; dropping that
+// symbol's high bit gives a dense index of 2^(2k-1) entries: 64 GiB at k = 17 where the per-strand table takes 128) -- and that
+// entry lists the occurrences of BOTH orientations, each with the 7 text symbols before and the 7 after it, taken in the
+// orientation of the canonical k-mer C:
+//   entry (lo, hi):  hi <  MARK, lo >  hi : no occurrence of either orientation
+//                    hi <  MARK, lo <= hi : more than 8 occurrences: the search falls back to rank steps (per strand)
+//                    hi >= MARK, lo <  MARK : ONE occurrence: lo = text position p of the k-mer,
+//                                             hi - MARK = o << 28 | before << 14 | after, where o = 0 if text[p, p+k) = C and 1 if it is
+//                                             rc(C); before[t] (bits 2(6-t) of the field) = the symbol t+1 places before C in C's
+//                                             orientation: text[p-1-t] (o = 0) or 3 - text[p+k+t] (o = 1); after[t] likewise the symbol
+//                                             t+1 places after C: text[p+k+t] (o = 0) or 3 - text[p-1-t] (o = 1); symbols outside the
+//                                             text read as 0 and are never trusted (the position checks below exclude them)
+//                    hi >= MARK, lo >= MARK : m = hi - MARK in 2..8 occurrences, rows (position, MARK | payload) at cside + 4 (lo - MARK):
+//                                             2..4 rows in 32 bytes, 5..8 in 64 (aligned): the occurrences of C in SA order, then those of rc(C)
+// A window whose last k symbols are W looks up C = W (qo = 0) or C = rc(W) (qo = 1).  Row (p, o): it is an occurrence of W if o = qo and of
+// rc(W) otherwise; qo = 0 compares `before` with A reversed (the seed's remaining symbols in scan order), qo = 1 compares `after` with their
+// complement (rc(A) follows C = rc(W)).  A forward hit needs p >= r, a reverse one p + len <= length.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t CTAB_FLANK    = 7u;            // symbols stored on each side of an occurrence: seeds of up to k + 7 symbols
+constexpr uint32_t CTAB_ROWS_MAX = 8u;
+constexpr uint32_t CTAB_INLINE   = 4u;            // a seed with up to this many hits on a strand can leave them all as keys (inline_max)
+
+__device__ __forceinline__ uint64_t canon_revcomp(const uint64_t key, const uint32_t k)
+{
+    return reverse_symbols( key, k ) ^ ((1ull << (2u * k)) - 1ull);
+}
+__device__ __forceinline__ uint64_t canon_index(const uint64_t ckey, const uint32_t k)      // ckey: bit k (middle symbol's high bit) is 0
+{
+    return ((ckey >> (k + 1u)) << k) | (ckey & ((1ull << k) - 1ull));
+}
+__device__ __forceinline__ uint64_t canon_key(const uint64_t idx, const uint32_t k)
+{
+    return ((idx >> k) << (k + 1u)) | (idx & ((1ull << k) - 1ull));
+}
+__device__ __forceinline__ uint32_t text_symbol(const uint32_t* __restrict__ text, const uint32_t i)
+{
+    return (text[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
+}
+
+// the SA range of the k-mer `key` (scan order) from the table of (k-1)-mers: one search step, as fm_ktab_level_kernel
+__device__ __forceinline__ uint2 canon_range(const DevIndex& f, const uint64_t key)
+{
+    const uint2 r = f.ktab[key >> 2];
+    uint32_t x = r.x, y = r.y, nb = 0;
+    if (x <= y) search_step<false>( f, x, y, (uint32_t)(key & 3u), nb );
+    return make_uint2( x, y );
+}
+__device__ __forceinline__ uint32_t range_rows(const uint2 r) { return r.x <= r.y ? r.y - r.x + 1u : 0u; }
+
+// 0: empty / heavy   1: one occurrence   2: 2..4 (4 slots)   3: 5..8 (8 slots)
+__device__ __forceinline__ uint32_t canon_class(const uint32_t m)
+{
+    return m == 1u ? 1u : (m >= 2u && m <= 4u ? 2u : (m >= 5u && m <= CTAB_ROWS_MAX ? 3u : 0u));
+}
+
+// the row of an occurrence: o = 0: text[p, p+k) is the canonical k-mer; o = 1: its reverse complement
+__device__ __forceinline__ uint2 canon_row(const uint32_t* __restrict__ text, const uint32_t length, const uint32_t k, const uint32_t p, const uint32_t o)
+{
+    uint32_t before = 0, after = 0;
+    #pragma unroll
+    for (uint32_t t = 0; t < CTAB_FLANK; ++t)
+    {
+        const bool has_l = p >= t + 1u, has_r = (uint64_t)p + k + t < length;
+        const uint32_t l = has_l ? text_symbol( text, p - 1u - t ) : 0u;
+        const uint32_t g = has_r ? text_symbol( text, p + k + t ) : 0u;
+        const uint32_t b = o ? (has_r ? 3u - g : 0u) : l;
+        const uint32_t a = o ? (has_l ? 3u - l : 0u) : g;
+        before |= b << (2u * (CTAB_FLANK - 1u - t));
+        after  |= a << (2u * (CTAB_FLANK - 1u - t));
+    }
+    return make_uint2( p, DTAB_MARK | (o << 28) | (before << 14) | after );
+}
+
+// pass 1: tab[idx] = SA range of the reverse complement of canonical k-mer idx (kept for pass 2); per-tile group counts
+__global__ void __launch_bounds__(256)
+fm_ctab_count_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
+                     uint32_t* __restrict__ cnt_small, uint32_t* __restrict__ cnt_large)
+{
+    __shared__ uint32_t s_a[4], s_b[4];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        const uint64_t e0 = (uint64_t)tile * DT_TILE + threadIdx.x * 4u;
+        uint32_t a = 0, b = 0;
+        #pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            if (e0 + j < n)
+            {
+                const uint64_t key = canon_key( e0 + j, k );
+                const uint2 r1 = canon_range( f, key ), r2 = canon_range( f, canon_revcomp( key, k ) );
+                tab[e0 + j] = r2;
+                const uint32_t c = canon_class( range_rows( r1 ) + range_rows( r2 ) );
+                a += (c == 2u); b += (c == 3u);
+            }
+        a = wave_inclusive_sum( a ); b = wave_inclusive_sum( b );
+        if ((threadIdx.x & 63u) == 63u) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) { cnt_small[tile] = s_a[0] + s_a[1] + s_a[2] + s_a[3]; cnt_large[tile] = s_b[0] + s_b[1] + s_b[2] + s_b[3]; }
+        __syncthreads();
+    }
+}
+
+// pass 2: the entries and the groups; large groups occupy side slots [0, 8 tot_large), small ones follow
+__global__ void __launch_bounds__(256)
+fm_ctab_fill_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
+                    const uint32_t* __restrict__ off_small, const uint32_t* __restrict__ off_large, const uint32_t tot_large, uint2* __restrict__ side)
+{
+    __shared__ uint32_t s_a[4], s_b[4];
+    auto position = [&](const uint32_t row) -> uint32_t { const uint32_t sv = f.ssa[row]; return sv == 0xFFFFFFFFu ? f.length : sv; };
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        const uint64_t e0 = (uint64_t)tile * DT_TILE + threadIdx.x * 4u;
+        uint2 r1[4], r2[4]; uint32_t c[4];
+        uint32_t a = 0, b = 0;
+        #pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+        {
+            c[j] = 0u; r1[j] = r2[j] = make_uint2( 1u, 0u );
+            if (e0 + j < n)
+            {
+                r1[j] = canon_range( f, canon_key( e0 + j, k ) ); r2[j] = tab[e0 + j];
+                c[j] = canon_class( range_rows( r1[j] ) + range_rows( r2[j] ) );
+                a += (c[j] == 2u); b += (c[j] == 3u);
+            }
+        }
+        const uint32_t ia = wave_inclusive_sum( a ), ib = wave_inclusive_sum( b );
+        if ((threadIdx.x & 63u) == 63u) { s_a[threadIdx.x >> 6] = ia; s_b[threadIdx.x >> 6] = ib; }
+        __syncthreads();
+        uint32_t ga = ia - a, gb = ib - b;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { ga += s_a[w]; gb += s_b[w]; }
+        ga += off_small[tile]; gb += off_large[tile];
+        __syncthreads();
+        #pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+        {
+            if (e0 + j >= n) continue;
+            const uint32_t n1 = range_rows( r1[j] ), n2 = range_rows( r2[j] ), m = n1 + n2;
+            if (c[j] == 1u)
+                tab[e0 + j] = n1 ? canon_row( f.text, f.length, k, position( r1[j].x ), 0u ) : canon_row( f.text, f.length, k, position( r2[j].x ), 1u );
+            else if (c[j] >= 2u)
+            {
+                const uint32_t slots = c[j] == 2u ? 4u : 8u;
+                const uint32_t idx4  = c[j] == 2u ? 2u * tot_large + ga++ : 2u * gb++;
+                uint2* g = side + 4ull * idx4;
+                for (uint32_t s = 0; s < slots; ++s)
+                {
+                    uint2 v = make_uint2( 0u, DTAB_MARK );
+                    if (s < n1)     v = canon_row( f.text, f.length, k, position( r1[j].x + s ), 0u );
+                    else if (s < m) v = canon_row( f.text, f.length, k, position( r2[j].x + (s - n1) ), 1u );
+                    g[s] = v;
+                }
+                tab[e0 + j] = make_uint2( DTAB_MARK | idx4, DTAB_MARK | m );
+            }
+            else tab[e0 + j] = m ? make_uint2( 0u, 1u ) : make_uint2( 1u, 0u );          // heavy : empty
+        }
+    }
+}
+
+// the canonical table of k-mers from the plain table of (k-1)-mers the handle keeps (idx->ktab)
+static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hipStream_t stream)
+{
+    const uint32_t length = idx->view.length;
+    if ((uint64_t)length + 2u > DTAB_MARK) { set_error( "canonical table: the text is too long for the position marker" ); return NVBIO_ERR_UNSUPPORTED; }
+    const uint64_t entries = 1ull << (2u * k - 1u);
+    const uint32_t n_tiles = (uint32_t)((entries + DT_TILE - 1u) / DT_TILE);
+    const dim3 grid( n_tiles < 256u * 64u ? n_tiles : 256u * 64u ), block( 256 );
+    uint2* tab = nullptr; uint32_t* cnt = nullptr; void* temp = nullptr; uint2* side = nullptr;
+    size_t temp_bytes = 0;
+    if (hipMalloc( (void**)&tab, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (hipMalloc( (void**)&cnt, 4ull * n_tiles * sizeof(uint32_t) ) != hipSuccess) { (void)hipGetLastError(); (void)hipFree( tab ); set_error( "canonical table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    uint32_t *cs = cnt, *cl = cnt + n_tiles, *os = cnt + 2ull * n_tiles, *ol = cnt + 3ull * n_tiles;
+    const DevIndex f = idx->dev();
+    hipLaunchKernelGGL( fm_ctab_count_kernel, grid, block, 0, stream, f, k, tab, entries, n_tiles, cs, cl );
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( nullptr, temp_bytes, cs, os, (int)n_tiles, stream );
+    if (e == hipSuccess) e = hipMalloc( &temp, temp_bytes ? temp_bytes : 16 );
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( temp, temp_bytes, cs, os, (int)n_tiles, stream );
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( temp, temp_bytes, cl, ol, (int)n_tiles, stream );
+    uint32_t last[4] = { 0, 0, 0, 0 };
+    if (e == hipSuccess) e = hipMemcpyAsync( &last[0], cs + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+    if (e == hipSuccess) e = hipMemcpyAsync( &last[1], os + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+    if (e == hipSuccess) e = hipMemcpyAsync( &last[2], cl + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+    if (e == hipSuccess) e = hipMemcpyAsync( &last[3], ol + n_tiles - 1u, 4, hipMemcpyDeviceToHost, stream );
+    if (e == hipSuccess) e = hipStreamSynchronize( stream );
+    nvbio_status st = NVBIO_OK;
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: counting pass failed: %s", hipGetErrorString( e ) ); st = NVBIO_ERR_HIP; }
+    const uint32_t tot_small = last[0] + last[1], tot_large = last[2] + last[3];
+    const uint64_t units = 2ull * tot_large + tot_small;                      // groups in units of 4 slots (32 bytes)
+    if (st == NVBIO_OK && units >= (1ull << 30)) { set_error( "canonical table: too many groups" ); st = NVBIO_ERR_UNSUPPORTED; }
+    if (st == NVBIO_OK && hipMalloc( (void**)&side, (units ? units : 1u) * 32ull ) != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: out of device memory" ); st = NVBIO_ERR_NOMEM; }
+    if (st == NVBIO_OK)
+    {
+        hipLaunchKernelGGL( fm_ctab_fill_kernel, grid, block, 0, stream, f, k, tab, entries, n_tiles, (const uint32_t*)os, (const uint32_t*)ol, tot_large, side );
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess) { set_error( "canonical table: fill pass failed" ); st = NVBIO_ERR_HIP; }
+    }
+    (void)hipFree( cnt );
+    if (temp) (void)hipFree( temp );
+    if (st != NVBIO_OK) { (void)hipFree( tab ); if (side) (void)hipFree( side ); return st; }
+    idx->ctab = tab; idx->cside = side; idx->ckmer = k;
+    idx->owned_bytes += entries * sizeof(uint2) + (units ? units : 1u) * 32ull;
+    return NVBIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the seed pass of both strands: one wave per tile of whole reads, software-pipelined over the tiles a wave owns as
+// fm_seed_pipe_kernel (words of tile t+2 | table entry of tile t+1 | resolution of tile t).  Keys of the forward strand go to
+// the tile's slots [0, 64), of the reverse strand to [64, 128); tile_counts[2 tile + strand].  Seeds whose k-mer has more than
+// 8 occurrences, or with several hits on a strand (a repeat longer than the seed), take the ordinary search of that strand
+// (plain table + rank steps + finish on the text) inside the kernel; what ends on several rows goes to that strand's residual
+// list: ranges / ids [0, cap) forward, [cap, 2 cap) reverse; counts[1], counts[2].
+// ---------------------------------------------------------------------------------------------
+template <int BITS, bool COUNT>
+__global__ void __launch_bounds__(256)
+fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, const uint32_t read_len, const uint32_t inline_max,
+                    uint64_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_counts, uint2* __restrict__ res_ranges,
+                    uint32_t* __restrict__ res_ids, const uint32_t res_cap, unsigned int* __restrict__ counts, unsigned long long* __restrict__ sectors_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t k = f.ckmer, len = q.fixed_len, r = len - k;
+    const uint32_t lr = lane / q.spr, j = lane - lr * q.spr;
+    const bool lane_ok = lr < tl.rpt;
+    const uint32_t rmask = (1u << (2u * r)) - 1u;                            // r <= 7
+    const uint32_t fshift = 2u * (CTAB_FLANK - r);
+    DevIndex fplain = f; fplain.dtab = nullptr; fplain.dkmer = 0;            // the fallback searches use the plain table only
+
+    auto seed_begin = [&](const uint32_t rid) -> uint32_t { return (q.offsets ? q.offsets[rid] : rid * q.stride) + j * q.interval; };
+    auto entry_of = [&](const uint64_t V, uint32_t& qo) -> uint2 {
+        const uint64_t key = V >> (2u * r);
+        qo = (uint32_t)(key >> k) & 1u;
+        return load_table_entry( f.ctab, canon_index( qo ? canon_revcomp( key, k ) : key, k ), true );
+    };
+
+    uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= tl.n_tiles) return;
+    SeedWords W = { 0, 0, 0, 0, 0 }; uint32_t w_begin = 0; bool w_valid = false;
+    uint64_t V = 0; uint2 e = make_uint2( 1u, 0u ); bool e_valid = false; uint32_t qo = 0;
+    {
+        const uint32_t rid = tile * tl.rpt + lr;
+        if (lane_ok && rid < tl.reads)
+        {
+            const uint32_t b0 = seed_begin( rid );
+            const SeedWords W0 = load_seed_words<BITS>( q.symbols, b0, len );
+            e_valid = seed_bits_from_words<BITS>( W0, b0, len, false, false, V );
+            if (e_valid) e = entry_of( V, qo );
+        }
+        const uint32_t t1 = tile + n_waves, rid1 = t1 * tl.rpt + lr;
+        if (t1 < tl.n_tiles && lane_ok && rid1 < tl.reads) { w_begin = seed_begin( rid1 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); w_valid = true; }
+    }
+    for (; tile < tl.n_tiles; tile += n_waves)
+    {
+        const uint32_t rid = tile * tl.rpt + lr;
+        const bool valid = lane_ok && rid < tl.reads;
+        // ---- stage 3a: the kind of entry; the group of a k-mer with 2..8 occurrences is requested ----
+        const bool is_one   = e_valid && e.y >= DTAB_MARK && e.x < DTAB_MARK;
+        const bool is_group = e_valid && e.y >= DTAB_MARK && e.x >= DTAB_MARK;
+        const bool is_heavy = e_valid && e.y < DTAB_MARK && e.x <= e.y;
+        uint4 q0 = make_uint4( 0, 0, 0, 0 ), q1 = q0, q2 = q0, q3 = q0;
+        const uint32_t m = e.y - DTAB_MARK;
+        if (is_group)
+        {
+            const uint4* g4 = (const uint4*)(f.cside + 4ull * (e.x - DTAB_MARK));
+            q0 = g4[0]; q1 = g4[1];
+            if (m > 4u) { q2 = g4[2]; q3 = g4[3]; }
+        }
+        // ---- stage 2 for the next tile ----
+        uint64_t Vn = 0; uint2 en = make_uint2( 1u, 0u ); bool en_valid = false; uint32_t qon = 0;
+        if (w_valid)
+        {
+            en_valid = seed_bits_from_words<BITS>( W, w_begin, len, false, false, Vn );
+            if (en_valid) en = entry_of( Vn, qon );
+        }
+        // ---- stage 1 for the tile after next ----
+        {
+            const uint32_t t2 = tile + 2u * n_waves, rid2 = t2 * tl.rpt + lr;
+            w_valid = t2 < tl.n_tiles && lane_ok && rid2 < tl.reads;
+            if (w_valid) { w_begin = seed_begin( rid2 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); }
+        }
+        // ---- stage 3b: resolve the current tile ----
+        const uint32_t rest = (uint32_t)V & rmask;                           // the seed's first r symbols, reversed (scan order)
+        const uint32_t want = qo ? (~rest & rmask) : rest;
+        // per strand: the hits found among the entry's rows (the first CTAB_INLINE positions are kept)
+        uint32_t hits[2] = { 0, 0 }, pos[2][CTAB_INLINE] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+        auto row = [&](const uint32_t P, const uint32_t C) {
+            const uint32_t pay = C - DTAB_MARK;
+            const uint32_t o = (pay >> 28) & 1u;
+            const uint32_t flank = qo ? (pay & 0x3FFFu) : ((pay >> 14) & 0x3FFFu);
+            if ((flank >> fshift) != want) return;
+            const bool rev = (o ^ qo) != 0u;
+            if (rev ? ((uint64_t)P + len > f.length) : (P < r)) return;
+            const uint32_t v = rev ? P : P - r;
+            #pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if ((s == 1) == rev)
+                {
+                    #pragma unroll
+                    for (uint32_t t = 0; t < CTAB_INLINE; ++t) pos[s][t] = (hits[s] == t) ? v : pos[s][t];
+                    ++hits[s];
+                }
+        };
+        if (is_one) row( e.x, e.y );
+        else if (is_group)
+        {
+#define NVB_CROW(jj, P, C) if ((jj) < m) row( (P), (C) );
+            NVB_CROW( 0u, q0.x, q0.y ) NVB_CROW( 1u, q0.z, q0.w ) NVB_CROW( 2u, q1.x, q1.y ) NVB_CROW( 3u, q1.z, q1.w )
+            NVB_CROW( 4u, q2.x, q2.y ) NVB_CROW( 5u, q2.z, q2.w ) NVB_CROW( 6u, q3.x, q3.y ) NVB_CROW( 7u, q3.z, q3.w )
+#undef NVB_CROW
+        }
+        uint32_t sectors = e_valid ? (is_group ? 2u : 1u) : 0u;
+        const uint32_t i = rid * q.spr + j;
+        #pragma unroll
+        for (int s = 0; s < 2; ++s)
+        {
+            // what this strand leaves: cnt keys (positions pos[s][0 .. cnt)), or the range (rx, ry) of several rows for the residual list
+            uint32_t cnt = (valid && !is_heavy && hits[s] <= inline_max) ? hits[s] : 0u;
+            uint32_t rx = 1u, ry = 0u;
+            bool searched = false;
+            const uint32_t sflags = s ? (NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT) : 0u;
+            auto plain_search = [&]() -> bool {                              // the ordinary search of this strand: range (rx, ry) or a position
+                uint32_t nblk, sec = 0; bool single = false;
+                match_one<BITS,false,true,true>( fplain, q, sflags, f.ktab != nullptr, false, i, rx, ry, nblk, single, &sec );
+                sectors += sec; searched = true;
+                return single;
+            };
+            if (valid && (is_heavy || hits[s] > inline_max))
+            {
+                cnt = 0u;
+                if (plain_search()) { pos[s][0] = rx; cnt = 1u; }
+                else if (rx <= ry && ry - rx < inline_max)                   // 1 .. inline_max rows: their positions from the suffix array
+                {
+                    cnt = ry - rx + 1u;
+                    #pragma unroll
+                    for (uint32_t t = 0; t < CTAB_INLINE; ++t)
+                        if (t < cnt) { const uint32_t sv = f.ssa[rx + t]; pos[s][t] = (sv == 0xFFFFFFFFu) ? f.length : sv; }
+                    sectors += cnt;
+                }
+            }
+            // a tile's keys of one strand must fit its 64 slots: if the seeds with several keys would overflow them, those seeds go to the
+            // residual list instead (a wave-uniform decision; the range of a seed resolved from its entry's rows is searched for then)
+            uint32_t total = (uint32_t)__popcll( __ballot( cnt == 1u ) );
+            #pragma unroll
+            for (uint32_t t = 0; t < CTAB_INLINE; ++t) total += (uint32_t)__popcll( __ballot( cnt >= 2u && t < cnt ) );
+            if (total > 64u && cnt >= 2u)
+            {
+                if (!searched) (void)plain_search();
+                cnt = 0u;
+            }
+            uint64_t* slots = tile_keys + (uint64_t)tile * 128u + 64u * s;
+            uint32_t n_out = 0; uint64_t last = ~0ull;
+            const uint32_t x1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? rx : 1u), y1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? ry : 0u);
+            emit_seed_results( q, len, read_len, (uint32_t)s, lane, valid, cnt == 1u, x1, y1, rid, j, i, slots, n_out, last,
+                               res_ranges + (s ? res_cap : 0u), res_ids + (s ? res_cap : 0u), counts + s );
+            // seeds with 2 .. inline_max hits on this strand: their keys behind the tile's one-hit keys, no duplicate removal
+            if (__ballot( cnt >= 2u ))
+            {
+                uint32_t pq = j * q.interval;
+                if (s) pq = read_len - pq - len;
+                #pragma unroll
+                for (uint32_t t = 0; t < CTAB_INLINE; ++t)
+                {
+                    const bool on = cnt >= 2u && t < cnt;
+                    const uint64_t mk = __ballot( on );
+                    if (on) slots[n_out + (uint32_t)__popcll( mk & ((1ull << lane) - 1ull) )] =
+                                ((uint64_t)rid << 34) | ((uint64_t)s << 33) | ((uint64_t)pos[s][t] + 1024u - pq);
+                    n_out += (uint32_t)__popcll( mk );
+                }
+            }
+            if (lane == 0) tile_counts[2u * tile + s] = n_out;
+        }
+        if (COUNT)
+        {
+            uint32_t tot = valid ? sectors : 0u;
+            #pragma unroll
+            for (int d = 32; d > 0; d >>= 1) tot += (uint32_t)__shfl_xor( (int)tot, d );
+            if (lane == 0 && tot) atomicAdd( sectors_out, (unsigned long long)tot );
+        }
+        V = Vn; e = en; e_valid = en_valid; qo = qon;
+    }
+}

@@ -34,6 +34,9 @@ struct DevIndex
     uint32_t        dctx;     // text symbols to the left of the occurrence that such an entry carries (15 or 0)
     const uint32_t* isa;      // optional (with a full SA): isa[p] = row of suffix p, isa[length] = 0
     const uint32_t* text;     // optional: the 2-bit packed text the index was built from
+    const uint2*    ctab;     // optional (instead of dtab): the canonical two-strand table of ckmer-mers (fm_canon_inl.h)
+    const uint2*    cside;    // its groups
+    uint32_t        ckmer;    // odd
 };
 
 __device__ __forceinline__ uint32_t pick4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t i)

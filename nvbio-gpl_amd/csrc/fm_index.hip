@@ -37,6 +37,9 @@ struct FMIndexImpl
     uint32_t             dkmer;
     uint2*               side;        // owned, optional: its groups for k-mers with 2..7 occurrences
     uint32_t             dmark, dctx;
+    uint2*               ctab;        // owned, optional (NVBIO_FM_TABLE_CANONICAL, instead of dtab): the two-strand table (fm_canon_inl.h)
+    uint2*               cside;       // owned: its groups
+    uint32_t             ckmer;
     uint32_t             table_flags; // NVBIO_FM_TABLE_* of the build
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
@@ -54,6 +57,7 @@ struct FMIndexImpl
         d.ktab = ktab; d.kmer = kmer; d.dtab = dtab; d.dkmer = dkmer;
         d.side = side; d.dmark = dmark; d.dctx = dctx;
         d.isa = isa; d.text = text;
+        d.ctab = ctab; d.cside = cside; d.ckmer = ckmer;
         return d;
     }
 };
@@ -926,11 +930,14 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
                     const uint32_t pos = is_pos ? j : f.ssa[j >> f.sa_log] + t;
                     if (KEYS)
                     {
-                        const uint32_t sid = ds.qid ? ds.qid[slot] : slot;
+                        // bit 31 of a query id flips the strand: the two residual lists of the two-strand seed pass go through one call
+                        const uint32_t qv  = ds.qid ? ds.qid[slot] : slot;
+                        const uint32_t sid = ds.qid ? (qv & 0x7FFFFFFFu) : qv;
+                        const uint32_t str = (ds.strand ^ (ds.qid ? qv >> 31 : 0u)) & 1u;
                         const uint32_t rid = sid / ds.spr;
                         uint32_t       p   = (sid - rid * ds.spr) * ds.interval;
-                        if (ds.strand) p = ds.read_len - p - ds.seed_len;
-                        keys[h - begin] = ((uint64_t)rid << 34) | ((uint64_t)(ds.strand & 1u) << 33) | ((uint64_t)pos + 1024u - p);
+                        if (str) p = ds.read_len - p - ds.seed_len;
+                        keys[h - begin] = ((uint64_t)rid << 34) | ((uint64_t)str << 33) | ((uint64_t)pos + 1024u - p);
                     }
                     else hits[h - begin] = make_uint2( pos, slot );
                     h += 256u; have = h < t_end;
@@ -1133,11 +1140,52 @@ static nvbio_status build_direct_table(FMIndexImpl* idx, uint2* tab, const uint6
 // plain table of match() (SA ranges), level k becomes the table of the direct seed pass, the entries of k-mers with few
 // occurrences rewritten in place to text positions (fm_seed_device.h).  Other handles keep level k as the plain table.
 // (k = 17: 32 + 128 GiB; k = 16: 8 + 32 GiB.)
+#include "fm_canon_inl.h"
+
+// NVBIO_FM_TABLE_CANONICAL: the plain table of (k-1)-mers (match()) + the canonical two-strand table of k-mers built from it
+// (k = 17: 32 + 64 GiB, and nothing larger while building)
+static nvbio_status build_canonical_tables(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
+{
+    const uint32_t kk = k - 1u;
+    const uint64_t entries = 1ull << (2 * kk);
+    uint2 *a = nullptr, *b = nullptr;
+    if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (hipMalloc( (void**)&b, (entries / 4) * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); (void)hipFree( a ); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    uint2* cur = (kk % 2 == 0) ? a : b;
+    uint2* oth = (kk % 2 == 0) ? b : a;
+    DevIndex f = idx->dev(); f.ktab = nullptr; f.kmer = 0; f.dtab = nullptr; f.dkmer = 0;
+    hipLaunchKernelGGL( fm_ktab_root_kernel, dim3(1), dim3(1), 0, stream, cur, idx->view.length );
+    for (uint32_t j = 1; j <= kk; ++j)
+    {
+        const uint64_t n_next = 1ull << (2 * j);
+        hipLaunchKernelGGL( fm_ktab_level_kernel, dim3( grid_for( n_next ) ), dim3(256), 0, stream, f, (const uint2*)cur, oth, n_next );
+        uint2* t = cur; cur = oth; oth = t;
+    }
+    const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize( stream ) == hipSuccess;
+    (void)hipFree( b );                                          // level kk - 1
+    if (!ok) { (void)hipFree( a ); set_error( "k-mer table build failed" ); return NVBIO_ERR_HIP; }
+    idx->ktab = a; idx->kmer = kk;
+    idx->owned_bytes += entries * sizeof(uint2);
+    const nvbio_status st = build_canonical_table( idx, k, stream );
+    if (st != NVBIO_OK) { (void)hipFree( a ); idx->ktab = nullptr; idx->kmer = 0; }
+    return st;
+}
+
 static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
 {
     idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0;
+    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0;
     if (k == 0) return NVBIO_OK;
     const bool direct = idx->text && idx->view.ssa_dev && idx->view.sa_int == 1 && k >= 2 && !(idx->table_flags & NVBIO_FM_TABLE_NO_DIRECT);
+    if (idx->table_flags & NVBIO_FM_TABLE_CANONICAL)
+    {
+        if (!direct || (k & 1u) == 0u || k < 3u)
+        {
+            set_error( "NVBIO_FM_TABLE_CANONICAL needs the full suffix array, the text (sa_int = 1) and an odd kmer_len >= 3" );
+            return NVBIO_ERR_UNSUPPORTED;
+        }
+        return build_canonical_tables( idx, k, stream );
+    }
     const uint64_t entries = 1ull << (2 * k);
     uint2 *a = nullptr, *b = nullptr;
     if (hipMalloc( (void**)&a, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "k-mer table: out of device memory" ); return NVBIO_ERR_NOMEM; }
@@ -1184,6 +1232,7 @@ nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
     idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->isa = nullptr; idx->text = nullptr;
     idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0; idx->table_flags = table_flags;
+    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     idx->isa = isa; idx->text = text;
@@ -1233,6 +1282,8 @@ nvbio_status nvbio_fm_index_destroy(nvbio_fm_index_t index)
     if (idx->ktab) (void)hipFree( idx->ktab );
     if (idx->dtab) (void)hipFree( idx->dtab );
     if (idx->side) (void)hipFree( idx->side );
+    if (idx->ctab)  (void)hipFree( idx->ctab );
+    if (idx->cside) (void)hipFree( idx->cside );
     if (idx->isa)  (void)hipFree( idx->isa );
     if (idx->text) (void)hipFree( idx->text );
     if (idx->owns_arrays) { (void)hipFree( (void*)idx->view.bwt_occ_dev ); (void)hipFree( (void*)idx->view.ssa_dev ); }
@@ -1595,6 +1646,104 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     {
         hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, L.slots, keys_dev, (unsigned int*)counts_dev );
+        e = hipGetLastError();
+    }
+    if (own_temp) (void)hipFreeAsync( temp, s );
+    if (e != hipSuccess) { set_error( "seed pass failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    return NVBIO_OK;
+}
+
+int nvbio_fm_index_is_canonical(nvbio_fm_index_t index)
+{
+    return index != nullptr && ((FMIndexImpl*)index)->ctab != nullptr ? 1 : 0;
+}
+
+// scratch of the two-strand pass: 128 key slots and 2 counts per tile
+static nvbio_status seed_both_layout(const nvbio_string_set* seeds, SeedScratch* L)
+{
+    NVB_CHECK( seed_scratch_layout( seeds, L ) );
+    NVB_REQUIRE( seeds->seeds_per_string <= 64u, "the two-strand seed pass takes at most 64 seeds per read" );
+    L->slots        = 128u;
+    L->keys_bytes   = ((uint64_t)L->tl.n_tiles * 128u * sizeof(uint64_t) + 255u) & ~255ull;
+    L->counts_bytes = ((uint64_t)(2u * L->tl.n_tiles + 1u) * sizeof(uint32_t) + 255u) & ~255ull;
+    size_t scan = 0;
+    if (L->tl.n_tiles)
+        NVB_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(2u * L->tl.n_tiles), (hipStream_t)0 ) );
+    L->scan_bytes = ((uint64_t)scan + 255u) & ~255ull;
+    L->total = L->keys_bytes + 2u * L->counts_bytes + L->scan_bytes + 256u;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_match_seed_diagonals_both_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes)
+{
+    NVB_REQUIRE( bytes != nullptr, "bytes is NULL" );
+    SeedScratch L; NVB_CHECK( seed_both_layout( seeds, &L ) );
+    *bytes = L.total;
+    return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
+                                                uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
+                                                uint32_t residual_capacity, uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes,
+                                                void* stream)
+{
+    NVB_REQUIRE( index != nullptr, "index is NULL" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    StringSetDev q; NVB_CHECK( make_set( seeds, &q ) );
+    NVB_REQUIRE( counts_dev != nullptr, "counts_dev is NULL" );
+    if (idx->ctab == nullptr)
+    {
+        set_error( "nvbio_fm_match_seed_diagonals_both needs the canonical table: build the index with NVBIO_FM_TABLE_CANONICAL" );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    NVB_REQUIRE( q.spr > 0 && q.spr <= 64u, "the string set must enumerate 1..64 seeds per read (seeds_per_string)" );
+    NVB_REQUIRE( seeds->symbol_bits == 2 || seeds->symbol_bits == 4, "packed seeds (2 or 4 bits per symbol)" );
+    NVB_REQUIRE( q.fixed_len >= idx->ckmer && q.fixed_len - idx->ckmer <= CTAB_FLANK, "seed length outside [kmer_len, kmer_len + 7]" );
+    NVB_REQUIRE( (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( residual_capacity >= q.n, "residual_capacity must be at least the number of seeds" );
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const bool count = (flags & NVBIO_FM_COUNT_SECTORS) != 0;
+    NVB_REQUIRE( !count || ((uintptr_t)counts_dev & 7u) == 0, "counts_dev must be 8-byte aligned with NVBIO_FM_COUNT_SECTORS" );
+    NVB_HIP( hipMemsetAsync( counts_dev, 0, (count ? 6 : 4) * sizeof(uint32_t), s ) );
+    if (q.n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && residual_ranges_dev && residual_ids_dev, "NULL device pointer" );
+    SeedScratch L; NVB_CHECK( seed_both_layout( seeds, &L ) );
+    uint8_t* temp = (uint8_t*)temp_dev;
+    bool own_temp = false;
+    if (temp == nullptr)
+    {
+        if (hipMallocAsync( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
+        own_temp = true;
+    }
+    else NVB_REQUIRE( temp_bytes >= L.total, "temp_bytes too small (nvbio_fm_match_seed_diagonals_both_temp_bytes)" );
+    uint8_t* base = (uint8_t*)(((uintptr_t)temp + 255u) & ~(uintptr_t)255u);
+    uint64_t* tile_keys    = (uint64_t*)base;
+    uint32_t* tile_counts  = (uint32_t*)(base + L.keys_bytes);
+    uint32_t* tile_offsets = (uint32_t*)(base + L.keys_bytes + L.counts_bytes);
+    void*     scan_temp    = base + L.keys_bytes + 2u * L.counts_bytes;
+    const DevIndex f = idx->dev();
+    unsigned blocks = (L.tl.n_tiles + 3u) / 4u;
+    const unsigned cap = (flags >> 16) ? (flags >> 16) * 64u : 256u * 64u;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid( blocks ), block( 256 );
+    // flags bits 8..11: a seed with up to that many hits on a strand leaves them all as keys (0/1: only one-hit seeds do)
+    uint32_t inline_max = (flags >> 8) & 15u;
+    inline_max = inline_max < 1u ? 1u : (inline_max > CTAB_INLINE ? CTAB_INLINE : inline_max);
+#define NVB_LAUNCH_SB(BITS, CNT) hipLaunchKernelGGL( (fm_seed_both_kernel<BITS,CNT>), grid, block, 0, s, f, q, L.tl, read_len, inline_max, tile_keys, tile_counts, \
+                                    (uint2*)residual_ranges_dev, residual_ids_dev, residual_capacity, (unsigned int*)counts_dev,                         \
+                                    CNT ? (unsigned long long*)(counts_dev + 4) : (unsigned long long*)nullptr )
+    if (seeds->symbol_bits == 2) { if (count) NVB_LAUNCH_SB( 2, true ); else NVB_LAUNCH_SB( 2, false ); }
+    else                         { if (count) NVB_LAUNCH_SB( 4, true ); else NVB_LAUNCH_SB( 4, false ); }
+#undef NVB_LAUNCH_SB
+    hipError_t e = hipGetLastError();
+    size_t scan_bytes = L.scan_bytes;
+    const uint32_t n2 = 2u * L.tl.n_tiles;
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)n2, s );
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( n2 ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+                            (const uint32_t*)tile_offsets, n2, 64u, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }
     if (own_temp) (void)hipFreeAsync( temp, s );

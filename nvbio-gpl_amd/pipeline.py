@@ -145,7 +145,53 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     use_direct = params.direct and fmi.supports_direct()
     results, n_cand, scored = [], 0, []
     fused = use_direct and params.fused_seed_pass
-    if fused:
+
+    def residual_keys(ranges, ids, strand):
+        """seeds that ended on several SA rows (repeats): the ordinary scan + locate path -> their diagonal keys"""
+        if params.max_seed_hits is not None:
+            x = ranges[:, 0].to(torch.int64) & 0xFFFFFFFF
+            y = ranges[:, 1].to(torch.int64) & 0xFFFFFFFF
+            ycap = torch.minimum(y, x + (params.max_seed_hits - 1))
+            ranges = torch.stack([ranges[:, 0], torch.where(ycap >= 2 ** 31, ycap - 2 ** 32, ycap).to(torch.int32)], dim=1).contiguous()
+        flt = FMIndexFilter()
+        n_hits = flt.rank_ranges(fmi, ranges.contiguous(), None)
+        rkeys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, query_ids=ids.contiguous())
+        rkeys = torch.unique_consecutive(rkeys)
+        if rkeys.numel() > 2 * R:
+            rkeys = torch.unique(rkeys)
+        return rkeys
+
+    both = fused and fmi.canonical and getattr(params, "two_strand_pass", True)
+    if both:
+        # 2.-4. for BOTH strands in one kernel over the canonical table (a k-mer and its reverse complement share an entry): one table
+        #    gather per seed window instead of one per window and strand
+        b = getattr(fmi, "_seed_bufs2", None)
+        if b is None:
+            b = fmi._seed_bufs2 = {}
+        e = tick("match_both")
+        # seeds that end on 2..4 rows (short repeats) leave all their keys at once: on unique-ish genomes the residual lists stay
+        # empty and the scan + locate path with its host round trips is not entered at all
+        fmi.match_seed_diagonals_both(qs, M, b, inline_hits=min(4, params.max_seed_hits or 4))
+        tock(e)
+        if "host" not in b:
+            b["host"] = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        b["host"].copy_(b["counts"][:4], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+        n_keys, n_rf, n_rr = int(b["host"][0]), int(b["host"][1]), int(b["host"][2])
+        parts = [b["keys"][:n_keys]]
+        if n_rf or n_rr:
+            # both strands' residual seeds through ONE scan + locate (bit 31 of a seed id flips the strand)
+            e = tick("locate")
+            parts.append(residual_keys(torch.cat([b["ranges"][:n_rf], b["ranges"][qs.n:qs.n + n_rr]]),
+                                       torch.cat([b["ids"][:n_rf], b["ids"][qs.n:qs.n + n_rr] | -2 ** 31]), 0))
+            tock(e)
+        keys = parts[0] if len(parts) == 1 else torch.cat(parts)
+        n_cand += keys.numel()
+        if keys.numel():
+            results.append(extend(keys, ""))
+    elif fused:
         # 2.-4. in one kernel per strand: every seed that ends on one SA row leaves it as a deduplicated diagonal key; the few
         #    that end on several rows (repeats) come back as a residual list and take the scan + locate path.  Both strands'
         #    seed passes are enqueued first; each one's two counts travel to pinned host memory behind it, so that the host
@@ -172,19 +218,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             keys = b["keys"][:n_keys]
             if n_res:
                 e = tick("locate")
-                ranges = b["ranges"][:n_res]
-                if params.max_seed_hits is not None:
-                    x = ranges[:, 0].to(torch.int64) & 0xFFFFFFFF
-                    y = ranges[:, 1].to(torch.int64) & 0xFFFFFFFF
-                    ycap = torch.minimum(y, x + (params.max_seed_hits - 1))
-                    ranges = torch.stack([ranges[:, 0], torch.where(ycap >= 2 ** 31, ycap - 2 ** 32, ycap).to(torch.int32)], dim=1).contiguous()
-                flt = FMIndexFilter()
-                n_hits = flt.rank_ranges(fmi, ranges, None)
-                rkeys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, query_ids=b["ids"][:n_res])
-                rkeys = torch.unique_consecutive(rkeys)
-                if rkeys.numel() > 2 * R:
-                    rkeys = torch.unique(rkeys)
-                keys = torch.cat([keys, rkeys])
+                keys = torch.cat([keys, residual_keys(b["ranges"][:n_res], b["ids"][:n_res], strand)])
                 tock(e)
             if keys.numel() == 0:
                 continue

@@ -40,6 +40,19 @@ def _expected(orc, hidx, reads, M, L, S, strand):
     return ks[keep], {int(s): (int(a), int(b)) for s, a, b in zip(sid[multi], x[multi], y[multi])}
 
 
+def _single_ids(orc, hidx, reads, M, L, S, strand):
+    """ids of the seeds whose search ends on exactly one row"""
+    R = reads.shape[0]
+    spr = (M - L) // S + 1
+    flat = np.stack([reads[:, j * S:j * S + L] for j in range(spr)], axis=1).reshape(-1)
+    offs = (np.arange(R * spr + 1) * L).astype(np.uint32)
+    if strand == 0:
+        ranges = orc.match_batch(hidx, flat, offs).astype(np.int64)
+    else:
+        ranges = orc.match_batch(hidx, np.where(flat < 4, 3 - flat, flat).astype(np.uint8), offs, reverse=True).astype(np.int64)
+    return np.nonzero(ranges[:, 0] == ranges[:, 1])[0]
+
+
 def _run(amd, fmi, packed, bits, R, M, L, S, strand, grid_blocks=0, extra_flags=0):
     spr = (M - L) // S + 1
     qs = amd.PackedStringSet(packed, bits, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
@@ -155,3 +168,112 @@ def test_seed_pass_needs_a_direct_capable_index(amd, orc):
     with pytest.raises(amd.NvbioError):
         fmi.match_seed_diagonals(qs, 0, 150, 0)
     fmi.close()
+
+
+def _run_both(amd, fmi, packed, bits, R, M, L, S, grid_blocks=0, flags=0, inline_hits=0):
+    spr = (M - L) // S + 1
+    qs = amd.PackedStringSet(packed, bits, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
+    b = fmi.match_seed_diagonals_both(qs, M, flags=flags, grid_blocks=grid_blocks, inline_hits=inline_hits)
+    c = [int(v) for v in b["counts"][:4].cpu().numpy()]
+    keys = b["keys"][:c[0]].cpu().numpy()
+    n = R * spr
+    res = []
+    for lo, cnt in ((0, c[1]), (n, c[2])):
+        rr = amd.u32(b["ranges"][lo:lo + cnt]); ids = b["ids"][lo:lo + cnt].cpu().numpy()
+        res.append({int(i): (int(a), int(d)) for i, (a, d) in zip(ids, rr)})
+    sectors = int(b["counts"][4:6].cpu().numpy().view(np.uint64)[0]) if flags & amd.FM_COUNT_SECTORS else None
+    return keys, res[0], res[1], sectors
+
+
+def _tile_major(keys_f, keys_r, spr):
+    """the order of the two-strand pass: tile by tile (64 // spr whole reads), a tile's forward keys, then its reverse-strand keys"""
+    rpt = 64 // spr
+    tf, tr = (keys_f >> 34) // rpt, (keys_r >> 34) // rpt
+    out = []
+    for t in np.union1d(tf, tr):
+        out.append(keys_f[tf == t]); out.append(keys_r[tr == t])
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+@pytest.mark.parametrize("k", [5, 9, 11, 15])
+def test_two_strand_pass_equals_the_per_strand_operators(amd, orc, k):
+    """nvbio_fm_match_seed_diagonals_both over the canonical table (a k-mer and its reverse complement share an entry) against match() of
+    every seed and of its reverse complement by the oracle: single-occurrence entries of either orientation, groups that mix both, k-mers
+    with more than 8 occurrences (k = 5: every one) and repeats longer than the seed (the per-strand fallback inside the kernel, residual
+    lists), occurrences at the first and last positions of the text, N's, seed lengths from k to k + 7"""
+    rng = np.random.default_rng(900 + k)
+    n = 300007
+    text = _text(rng, n)
+    # reverse-complement copies: k-mers whose two orientations BOTH occur (a group with o = 0 and o = 1 rows; a forward and a reverse hit
+    # of the same seed)
+    text[160000:160300] = 3 - text[5000:5300][::-1]
+    text[170000:170200] = 3 - text[100000:100200][::-1]
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL)
+    assert fmi.canonical
+    R, M = 3000, 150
+    reads = _reads(rng, text, R, M)
+    reads[440:500] = np.stack([text[s:s + M] for s in 5000 + rng.integers(0, 150, 60)])       # reads from the region that also occurs reversed
+    flat = reads.reshape(-1)
+    n_multi = n_both = 0
+    for L, S in ((k, 13), (k + 3, 15), (k + 7, 20), (k + 5, 128 // 8)):
+        spr = (M - L) // S + 1
+        want_f, res_f = _expected(orc, hidx, reads, M, L, S, 0)
+        want_r, res_r = _expected(orc, hidx, reads, M, L, S, 1)
+        want = _tile_major(want_f, want_r, spr)
+        for bits, packed in ((4, orc.pack4(flat)),) + (((2, orc.pack2(np.where(flat < 4, flat, 0).astype(np.uint8))),) if L == k + 3 else ()):
+            if bits == 2:          # no N in a 2-bit stream: expectations for the N-free reads
+                clean = np.where(reads < 4, reads, 0).astype(np.uint8)
+                wf, rf = _expected(orc, hidx, clean, M, L, S, 0); wr, rr = _expected(orc, hidx, clean, M, L, S, 1)
+                w2 = _tile_major(wf, wr, spr)
+            else:
+                w2, rf, rr = want, res_f, res_r
+            for flags, gb in ((0, 0), (amd.FM_COUNT_SECTORS, 0), (0, 64)):
+                keys, gf, gr, sectors = _run_both(amd, fmi, packed, bits, R, M, L, S, grid_blocks=gb, flags=flags)
+                assert np.array_equal(keys, w2), (k, L, S, bits, flags, gb)
+                assert gf == rf and gr == rr, (k, L, S, bits, flags, gb)
+                if sectors is not None:
+                    assert R * spr * 0.5 < sectors < R * spr * 60
+        # inline_hits = h: a seed on 2..h rows leaves all its keys (any order inside its tile and strand), larger ranges stay residual
+        for h in (2, 4):
+            keys, gf, gr, _ = _run_both(amd, fmi, orc.pack4(flat), 4, R, M, L, S, inline_hits=h)
+            exp = [want_f, want_r]
+            rpt = 64 // spr
+            for strand, res, got in ((0, res_f, gf), (1, res_r, gr)):
+                # a tile's keys of one strand must fit 64 slots: where the one-row seeds plus all rows of the 2..h-row seeds would not,
+                # the latter stay residual (the kernel's wave-uniform rule)
+                n_single = np.bincount((_single_ids(orc, hidx, reads, M, L, S, strand) // spr) // rpt, minlength=R // rpt + 1)
+                small = {sid: xy for sid, xy in res.items() if xy[1] - xy[0] + 1 <= h}
+                load = n_single.copy()
+                for sid, (x, y) in small.items():
+                    load[(sid // spr) // rpt] += y - x + 1
+                inl = {sid: xy for sid, xy in small.items() if load[(sid // spr) // rpt] <= 64}
+                assert got == {sid: xy for sid, xy in res.items() if sid not in inl}, (k, L, S, h, strand)
+                for sid, (x, y) in inl.items():
+                    rid, j = sid // spr, sid % spr
+                    p = (M - j * S - L) if strand else j * S
+                    exp.append((np.int64(rid) << 34) | (strand << 33) | (hidx.sa[x:y + 1].astype(np.int64) + 1024 - p))
+            assert np.array_equal(np.sort(keys), np.sort(np.concatenate(exp))), (k, L, S, h)
+            # ... and the keys are still grouped tile by tile, forward strand first
+            order = ((keys >> 34) // rpt) * 2 + ((keys >> 33) & 1)
+            assert (np.diff(order) >= 0).all()
+        n_multi += len(res_f) + len(res_r)
+        n_both += len(np.intersect1d(want_f >> 34, want_r >> 34))
+    assert n_multi > 200 and n_both > 20
+    # the per-strand pass of the same handle (no direct table: plain table + rank steps + finish on the text) still answers
+    want_keys, want_res = _expected(orc, hidx, reads, M, k + 5, 15, 1)
+    keys, res = _run(amd, fmi, orc.pack4(flat), 4, R, M, k + 5, 15, 1)
+    assert np.array_equal(keys, want_keys) and res == want_res
+    # requests outside what the table serves are refused
+    qs = amd.PackedStringSet(orc.pack4(flat), 4, R * 2, fixed_len=k + 8, stride=M, seeds_per_string=2, seed_interval=20)
+    with pytest.raises(amd.NvbioError):
+        fmi.match_seed_diagonals_both(qs, M)
+    fmi.close()
+    plain = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1)
+    assert not plain.canonical
+    qs = amd.PackedStringSet(orc.pack4(flat), 4, R * 2, fixed_len=k + 2, stride=M, seeds_per_string=2, seed_interval=20)
+    with pytest.raises(amd.NvbioError):
+        plain.match_seed_diagonals_both(qs, M)
+    plain.close()
+    with pytest.raises(amd.NvbioError):
+        amd.FMIndex.build(orc.pack2(text), n, kmer_len=8, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL)      # even k
