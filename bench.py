@@ -248,7 +248,7 @@ def main():
     def step(timers=None):
         if args.with_traceback:
             bs, bp, brc, nc, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, return_windows=True)
-            extras["traceback"] = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=TB_STRIDE, timers=timers, best_pos=bp)
+            extras["traceback"] = pipeline.traceback_best_all(genome, n, batch, params, extras["best_keys"], bwb, cigar_stride=TB_STRIDE, timers=timers)
         else:
             bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras)
         if gatherer is not None:
@@ -287,25 +287,29 @@ def main():
     # ---- traceback of every read's best alignment (not part of the timed step) ----
     tb_ms, tb_info = None, None
     if not args.no_traceback:
-        _, _, _, _, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, None, return_windows=True)
+        tbx = {}
+        _, _, _, _, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, None, return_windows=True, extras=tbx)
         tms = []
         for _ in range(3):
             tt = {}
-            ids, tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best(genome, n, batch, params, bs, brc, bwb, cigar_stride=TB_STRIDE, timers=tt, best_pos=bp)
+            tsc, tpos, tsrc, tsnk, tcig, tln = pipeline.traceback_best_all(genome, n, batch, params, tbx["best_keys"], bwb, cigar_stride=TB_STRIDE, timers=tt)
             torch.cuda.synchronize()
             tms.append(event_ms(tt["traceback"])[0])
         tb_ms = float(np.median(tms))
-        lens_i = tln.to(torch.int64) & 0xFFFFFFFF
-        tb_info = {"kernels": "ungapped_traceback_kernel<31,%s,4,2> (diagonal check, settles ungapped reads) + banded_gotoh_traceback_kernel "
+        lens_all = tln.to(torch.int64) & 0xFFFFFFFF
+        traced = lens_all > 0
+        lens_i = lens_all[traced]
+        tb_info = {"kernels": "traceback_best_batch_kernel (the batch of every read's best alignment, built on the device) + ungapped_traceback_kernel<31,%s,4,2> "
+                              "(diagonal check, settles ungapped reads) + banded_gotoh_traceback_kernel "
                               "(the rest: one DP pass writing 16 B of direction vectors per row, walk back to a run-length CIGAR)%s"
                               % ("SEMI_GLOBAL" if args.mode == "e2e" else "LOCAL",
                                  "; score and sink handed over from the scoring pass" if args.mode == "e2e" else "; scoring pass re-run inside"),
-                   "reads": int(ids.numel()), "ms": tb_ms, "reads_per_s": ids.numel() / (tb_ms * 1e-3),
+                   "reads": int(traced.sum()), "ms": tb_ms, "reads_per_s": int(traced.sum()) / (tb_ms * 1e-3),
                    "gapped_fraction": float((lens_i > 1).float().mean()),
-                   "scores_equal_scoring_pass": bool(torch.equal(tsc, bs[ids])),
+                   "scores_equal_scoring_pass": bool(torch.equal(tsc[traced], bs[traced]) and torch.equal(traced, aligned)),
                    "mean_cigar_elements": float(lens_i.float().mean()), "max_cigar_elements": int(lens_i.max()),
                    "cigar_stride": TB_STRIDE, "cigars_truncated": int((lens_i > TB_STRIDE).sum())}
-        del bwb, ids, tsc, tpos, tsrc, tsnk, tcig, tln
+        del bwb, tsc, tpos, tsrc, tsnk, tcig, tln, tbx
 
     # ---- stage times and the roofline of the dominant HBM kernel (the seed pass) --------------------------------
     stage_ms = {k: float(np.mean(event_ms(v))) for k, v in timers.items()}

@@ -584,6 +584,25 @@ nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, c
 nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* best_dev, uint32_t n_reads, int32_t* scores_dev,
                                          int64_t* end_pos_dev, uint8_t* rc_dev, void* stream);
 
+/* The window of every read's best candidate, for the traceback of the best alignments (nvBowtie's banded_traceback_best re-aligns the
+ * best alignment inside the window it was scored in, traceback_inl.h:191-247): for every candidate i whose selection key equals
+ * best_dev[read] (the final result of nvbio_best_candidate_reduce over ALL candidates),
+ *   best_wb_dev[read] = max( best_wb_dev[read], win_begin_dev[i] ),  best_locus_dev[read] = max( ., max( diagonal of keys_dev[i], 0 ) )
+ * by 64-bit atomic max (several candidates can tie on the whole key: the largest window begin wins).  The caller initialises both
+ * arrays to -1; best_locus_dev may be NULL. */
+nvbio_status nvbio_best_candidate_windows(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                          const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev, int64_t* best_wb_dev,
+                                          int64_t* best_locus_dev, void* stream);
+
+/* ... and the traceback batch of all reads from them (one job per read, job r = read r; the stream of banded_traceback_best):
+ * flags (strand: NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT), window [best_wb, min( best_wb + band + read_len, genome_len )), and
+ * the score and sink the scoring pass already found there (sink = (end position - window begin, read_len): for
+ * NVBIO_TRACEBACK_SINKS_GIVEN).  A read without a candidate, or whose best score is below min_score, gets the empty window
+ * [0, 0), score NVBIO_SCORE_MIN and sink (-1, -1): the traceback reports nothing for it (cigar length 0). */
+nvbio_status nvbio_traceback_best_batch(int device, const uint64_t* best_dev, const int64_t* best_wb_dev, uint32_t n_reads, uint32_t read_len,
+                                        uint32_t band, uint32_t genome_len, int32_t min_score, uint8_t* flags_dev, uint32_t* win_begin_dev,
+                                        uint32_t* win_end_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream);
+
 /* The second-best alignment per read, as nvBowtie's score_reduce keeps it (nvBowtie/bowtie2/cuda/reduce_inl.h:65-140:
  * best a1 and a second a2 that must be `distinct` from a1 -- io::distinct_alignments, nvbio/io/alignments_inl.h:26-38: the other
  * strand, or more than distinct_dist = read_len / 2 positions away -- and score above the read's threshold; candidates at a

@@ -853,6 +853,30 @@ def best_candidate_unpack(best):
     return score, pos, rc
 
 
+def best_candidate_windows(keys, scores, sinks, win_begin, best, best_wb, best_locus=None):
+    """nvbio_best_candidate_windows: atomic max of the window begin (and locus) of the candidates that ARE their read's best (`best`:
+    the final keys of best_candidate_reduce) into best_wb / best_locus (int64 per read, initialised to -1 by the caller)"""
+    if keys.numel() == 0:
+        return
+    _check(lib().nvbio_best_candidate_windows(FMIndex._dev_index(keys.device), _ptr(keys), _ptr(scores), _ptr(sinks), _ptr(win_begin),
+                                              ctypes.c_uint64(keys.numel()), _ptr(best), _ptr(best_wb), _ptr(best_locus),
+                                              _stream_ptr(keys.device)))
+
+
+def traceback_best_batch(best, best_wb, read_len, band, genome_len, min_score):
+    """nvbio_traceback_best_batch: the per-read arrays of the traceback batch of every read's best alignment ->
+    (flags uint8, win_begin int32, win_end int32, scores int32, sinks int32 [R, 2]); unaligned reads get the empty window"""
+    torch = _torch()
+    n, dev = best.shape[0], best.device
+    flags = torch.empty(n, dtype=torch.uint8, device=dev)
+    wb = torch.empty(n, dtype=torch.int32, device=dev); we = torch.empty(n, dtype=torch.int32, device=dev)
+    scores = torch.empty(n, dtype=torch.int32, device=dev); sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    _check(lib().nvbio_traceback_best_batch(FMIndex._dev_index(dev), _ptr(best), _ptr(best_wb), ctypes.c_uint32(n), ctypes.c_uint32(read_len),
+                                            ctypes.c_uint32(band), ctypes.c_uint32(genome_len), ctypes.c_int32(min_score), _ptr(flags),
+                                            _ptr(wb), _ptr(we), _ptr(scores), _ptr(sinks), _stream_ptr(dev)))
+    return flags, wb, we, scores, sinks
+
+
 PE_POLICY_FF, PE_POLICY_FR, PE_POLICY_RF, PE_POLICY_RR = 0, 1, 2, 3
 
 

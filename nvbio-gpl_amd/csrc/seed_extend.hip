@@ -79,6 +79,58 @@ best_unpack_kernel(const unsigned long long* __restrict__ best, const uint32_t n
     }
 }
 
+// the window (and locus) of every read's best candidate: see nvbio_best_candidate_windows
+__global__ void __launch_bounds__(256)
+best_window_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
+                   const uint32_t* __restrict__ wb, const uint64_t n, const unsigned long long* __restrict__ best,
+                   long long* __restrict__ best_wb, long long* __restrict__ best_g)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t k   = keys[i];
+        const int64_t  s   = (int64_t)scores[i] + (1ll << 20);
+        const uint64_t pos = (uint64_t)wb[i] + (uint64_t)sinks[i].x;
+        const uint64_t sel = ((uint64_t)(s > 0 ? s : 0) << 34) | (k & (1ull << 33)) | (pos & ((1ull << 33) - 1ull));
+        if (sel != best[k >> 34]) continue;
+        atomicMax( &best_wb[k >> 34], (long long)wb[i] );
+        if (best_g)
+        {
+            const int64_t d = (int64_t)(k & ((1ull << 33) - 1ull)) - 1024;
+            atomicMax( &best_g[k >> 34], (long long)(d > 0 ? d : 0) );
+        }
+    }
+}
+
+// the traceback batch of every read's best alignment: see nvbio_traceback_best_batch
+__global__ void __launch_bounds__(256)
+traceback_best_batch_kernel(const unsigned long long* __restrict__ best, const long long* __restrict__ best_wb, const uint32_t n,
+                            const uint32_t read_len, const uint32_t band, const uint32_t genome_len, const int32_t min_score,
+                            uint8_t* __restrict__ flags, uint32_t* __restrict__ wb, uint32_t* __restrict__ we, int32_t* __restrict__ scores,
+                            uint2* __restrict__ sinks)
+{
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+    {
+        const unsigned long long k = best[r];
+        const long long w = best_wb[r];
+        const int64_t sv = (int64_t)(k >> 34);
+        const int32_t sc = (k && sv > 0) ? (int32_t)(sv - (1ll << 20)) : NVBIO_SCORE_MIN;
+        const bool aligned = k != 0ull && w >= 0 && sc >= min_score;
+        if (aligned)
+        {
+            const uint64_t end = (uint64_t)w + band + read_len;
+            flags[r]  = ((k >> 33) & 1ull) ? (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT) : (uint8_t)0;
+            wb[r]     = (uint32_t)w;
+            we[r]     = end < genome_len ? (uint32_t)end : genome_len;
+            scores[r] = sc;
+            sinks[r]  = make_uint2( (uint32_t)((k & ((1ull << 33) - 1ull)) - (uint64_t)w), read_len );
+        }
+        else
+        {
+            flags[r] = 0; wb[r] = 0; we[r] = 0; scores[r] = NVBIO_SCORE_MIN; sinks[r] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu );
+        }
+    }
+}
+
 // second-best candidate per read: nvBowtie's score_reduce_kernel (nvBowtie/bowtie2/cuda/reduce_inl.h:65-140) keeps, beside the
 // best alignment a1, a second one a2 that must be `distinct` from a1 (io::distinct_alignments, nvbio/io/alignments_inl.h:26-38:
 // other strand, or more than read_len/2 away) and score above the read's threshold; it skips candidates at a location already
@@ -428,6 +480,33 @@ extern "C" nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* 
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipLaunchKernelGGL( best_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
                         keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (unsigned long long*)best_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_best_candidate_windows(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                     const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev, int64_t* best_wb_dev,
+                                                     int64_t* best_locus_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && scores_dev && sinks_dev && win_begin_dev && best_dev && best_wb_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( best_window_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream, keys_dev, scores_dev, (const uint2*)sinks_dev,
+                        win_begin_dev, n, (const unsigned long long*)best_dev, (long long*)best_wb_dev, (long long*)best_locus_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_traceback_best_batch(int device, const uint64_t* best_dev, const int64_t* best_wb_dev, uint32_t n_reads, uint32_t read_len,
+                                                   uint32_t band, uint32_t genome_len, int32_t min_score, uint8_t* flags_dev, uint32_t* win_begin_dev,
+                                                   uint32_t* win_end_dev, int32_t* scores_dev, nvbio_uint2* sinks_dev, void* stream)
+{
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( best_dev && best_wb_dev && flags_dev && win_begin_dev && win_end_dev && scores_dev && sinks_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( traceback_best_batch_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)best_dev,
+                        (const long long*)best_wb_dev, n_reads, read_len, band, genome_len, min_score, flags_dev, win_begin_dev, win_end_dev,
+                        scores_dev, (uint2*)sinks_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

@@ -92,7 +92,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     second alignment) and "second" (the second-best selection keys): nvBowtie's score_reduce bookkeeping (reduce_inl.h:65-140,
     over the candidates in descending key order) and BowtieMapq2 (mapq.h)."""
     import torch
-    from . import best_candidate_reduce, best_candidate_unpack, diagonals_to_windows, mapq, second_candidate_reduce
+    from . import best_candidate_reduce, best_candidate_unpack, best_candidate_windows, diagonals_to_windows, mapq, second_candidate_reduce
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
@@ -133,14 +133,9 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         e = tick("reduce")
         best_candidate_reduce(keys, scores, sinks, wb, top)
         tock(e)
-        if params.mapq:
+        if params.mapq or return_windows:
             scored.append((keys, scores, sinks, wb))
-        if not return_windows:
-            return None
-        rc = (keys >> 33) & 1
-        pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (sinks[:, 0].to(torch.int64) & 0xFFFFFFFF)   # hit.sink = genome_begin + sink.x (score_inl.h:128-129)
-        g = torch.clamp((keys & ((1 << 33) - 1)) - 1024, min=0)
-        return rid.to(torch.int64), pack_best_key(torch, scores, rc, pos), wb, g
+        return None
 
     use_direct = params.direct and fmi.supports_direct()
     results, n_cand, scored = [], 0, []
@@ -293,15 +288,50 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             return best_score, best_pos, best_rc, 0, none, none.clone()
         return best_score, best_pos, best_rc, 0
 
+    if extras is not None:
+        extras["best_keys"] = top
     if return_windows:
+        # the window begin and the locus of every read's best candidate: one pass over the candidates (those whose selection key is
+        # their read's final best)
         best_wb = torch.full((R,), -1, dtype=torch.int64, device=dev)
         best_g = torch.full((R,), -1, dtype=torch.int64, device=dev)
-        for rid, sel, wb, g in results:
-            win = sel == top[rid]
-            best_wb.scatter_reduce_(0, rid[win], (wb.to(torch.int64) & 0xFFFFFFFF)[win], "amax", include_self=True)
-            best_g.scatter_reduce_(0, rid[win], g[win], "amax", include_self=True)
+        for keys, scores, sinks, wb in scored:
+            best_candidate_windows(keys, scores, sinks, wb, top, best_wb, best_g)
         return best_score, best_pos, best_rc, int(n_cand), best_wb, best_g
     return best_score, best_pos, best_rc, int(n_cand)
+
+
+def traceback_best_all(genome2, genome_len, reads, params, best_keys, best_wb, cigar_stride=32, timers=None):
+    """nvBowtie's banded_traceback_best (traceback_inl.h:191-247) over ALL reads of the batch, job r = read r, the batch built on the
+    device from the per-read best keys (extras["best_keys"] of seed_and_extend) and best_wb: no compaction, no host round trip.
+    The scoring pass's score and sink are handed over (end-to-end; a LOCAL alignment is re-scored by the traceback).  Returns
+    (scores [R], align_pos [R] int64 = text position where the alignment starts, sources, sinks, cigars [R, cigar_stride], cigar_lens
+    [R]); a read that did not align has cigar_len 0 and sink (-1, -1)."""
+    import torch
+    from . import BatchedBandedAlignmentTraceback, traceback_best_batch
+    dev = best_keys.device
+    R, M = reads.n, reads.read_len
+    ev = None
+    if timers is not None:
+        a, ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        timers.setdefault("traceback", []).append((a, ev))
+        a.record()
+    flags, wb, we, scores, sinks = traceback_best_batch(best_keys, best_wb, M, params.band, genome_len, params.min_score_for(M))
+    read_off = getattr(reads, "_read_off", None)
+    if read_off is None:
+        read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, flags=flags, device=dev, max_read_len=M)
+    known = dict(scores=scores, sinks=sinks) if params.aln_type != LOCAL else {}
+    op = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme))
+    # the direction vectors of the gapped alignments (a minority) go to the persistent scratch: a multi-GiB stream-ordered allocation
+    # per call stalls the step for 0.1-0.2 s whenever the HIP pool has handed the memory back (measured)
+    from . import _scratch
+    temp = _scratch(dev, op.min_temp_storage(batch) // 4, cap=6 << 30)
+    sc, src, snk, cig, ln = op.enact(batch, cigar_stride=cigar_stride, temp=temp, **known)
+    pos = (wb.to(torch.int64) & 0xFFFFFFFF) + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+    if ev is not None:
+        ev.record()
+    return sc, pos, src, snk, cig, ln
 
 
 def traceback_best(genome2, genome_len, reads, params, best_score, best_rc, best_wb, cigar_stride=32, timers=None,

@@ -115,6 +115,18 @@ def test_pipeline_equals_cpu_path(amd, orc, mode):
     # reads with one indel carry exactly one gap element; most reads are a single run of matches
     one_run = (tb["lens"] == 1).mean()
     assert one_run > 0.4
+    # the all-reads form (batch built on the device from the per-read best keys, no compaction): the same alignments, row r = read r
+    ex = {}
+    o = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, return_windows=True, extras=ex)
+    assert torch.equal(o[4], bwb) and torch.equal(o[5], bg)
+    asc, apos, asrc, asnk, acig, aln = pipeline.traceback_best_all(g_dev, G, rb, params, ex["best_keys"], bwb, cigar_stride=24)
+    sel = tb["ids"]
+    traced = np.zeros(R, dtype=bool); traced[sel] = True
+    assert np.array_equal(amd.u32(aln) > 0, traced)
+    assert np.array_equal(asc.cpu().numpy()[sel], tb["scores"]) and np.array_equal(apos.cpu().numpy()[sel], tb["pos"])
+    assert np.array_equal(amd.u32(asrc)[sel], tb["sources"]) and np.array_equal(amd.u32(asnk)[sel], tb["sinks"])
+    assert np.array_equal(amd.u32(aln)[sel], tb["lens"]) and np.array_equal(acig.cpu().numpy().view(np.uint16)[sel], tb["cigars"])
+    assert (amd.u32(asnk)[~traced] == 0xFFFFFFFF).all()
     fmi.close()
 
 
