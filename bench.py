@@ -205,8 +205,8 @@ def main():
         tmp.close(); del tmp
         torch.cuda.empty_cache()
         t1 = time.time()
-    canonical = (not args.no_canonical and args.sa_int == 1 and args.kmer >= 3 and args.kmer % 2 == 1 and not args.no_direct
-                 and not args.no_fused_seeds)
+    canonical = (not args.no_canonical and args.sa_int == 1 and args.kmer >= 15 and args.kmer % 2 == 1 and not args.no_direct
+                 and not args.no_fused_seeds)               # the canonical table serves seeds of k .. k + 7 symbols (22-mers: k >= 15)
     try:
         fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify),
                                 table_flags=amd.FM_TABLE_CANONICAL if canonical else 0)

@@ -333,7 +333,8 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
                                                 uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
                                                 uint32_t residual_capacity, uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes,
                                                 void* stream);
-/* 1 if the handle holds the canonical two-strand table (built with NVBIO_FM_TABLE_CANONICAL), else 0 */
+/* the k of the canonical two-strand table the handle holds (built with NVBIO_FM_TABLE_CANONICAL: it serves seeds of k .. k + 7 symbols),
+ * 0 if it holds none */
 int nvbio_fm_index_is_canonical(nvbio_fm_index_t index);
 
 /* the two-phase form nvBowtie uses (locate_init / locate_lookup kernels, locate_inl.h:144-201):

@@ -377,11 +377,15 @@ class FMIndex:
         return buffers
 
     @property
-    def canonical(self):
-        """True if the handle holds the canonical two-strand table (built with FM_TABLE_CANONICAL)"""
+    def canonical_kmer(self):
+        """k of the canonical two-strand table the handle holds (built with FM_TABLE_CANONICAL; seeds of k .. k + 7 symbols), 0 if none"""
         fn = lib().nvbio_fm_index_is_canonical
         fn.restype = ctypes.c_int
-        return bool(fn(self._h))
+        return int(fn(self._h))
+
+    @property
+    def canonical(self):
+        return self.canonical_kmer != 0
 
     def match_seed_diagonals_both(self, seeds, read_len, buffers=None, flags=0, grid_blocks=0, inline_hits=0):
         """the seed pass of BOTH strands in one launch over the canonical table (nvbio_fm_match_seed_diagonals_both) -> the buffers dict:

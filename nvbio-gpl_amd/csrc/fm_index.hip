@@ -1655,7 +1655,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
 
 int nvbio_fm_index_is_canonical(nvbio_fm_index_t index)
 {
-    return index != nullptr && ((FMIndexImpl*)index)->ctab != nullptr ? 1 : 0;
+    return index != nullptr && ((FMIndexImpl*)index)->ctab != nullptr ? (int)((FMIndexImpl*)index)->ckmer : 0;
 }
 
 // scratch of the two-strand pass: 128 key slots and 2 counts per tile

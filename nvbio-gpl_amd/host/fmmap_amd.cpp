@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct Rng { uint64_t s; uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 
 int main(int argc, char** argv)
 {
     const char *genome_path = nullptr, *reads_path = nullptr, *out_path = nullptr;
-    uint64_t genome_len = 0; uint32_t n_reads = 0, read_len = 150, steps = 3, kmer = 17; bool synthetic = false;
+    uint64_t genome_len = 0; uint32_t n_reads = 0, read_len = 150, steps = 3, kmer = 17; bool synthetic = false, canonical = true;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -51,6 +52,7 @@ int main(int argc, char** argv)
         else if (a == "--steps")      steps = (uint32_t)atoi( val() );
         else if (a == "--kmer")       kmer = (uint32_t)atoi( val() );
         else if (a == "--synthetic")  synthetic = true;
+        else if (a == "--no-canonical") canonical = false;
         else { fprintf( stderr, "unknown argument %s\n", a.c_str() ); return 2; }
     }
     if (!genome_len || !n_reads || (!synthetic && !(genome_path && reads_path))) { fprintf( stderr, "usage: see the head of fmmap_amd.cpp\n" ); return 2; }
@@ -85,7 +87,9 @@ int main(int argc, char** argv)
 
         // ---- index: built on the GPU, full suffix array + direct table ----
         const auto tb0 = std::chrono::steady_clock::now();
-        fm_index fmi( d_genome.data(), N, 0, kmer, 0, /*sa_int*/ 1 );
+        // (odd k: the canonical table, one seed pass for both strands; --no-canonical or even k: the direct table, one pass per strand)
+        canonical = canonical && (kmer & 1u) && kmer >= 3u && kmer <= 22u && 22u - kmer <= 7u;      // the canonical table serves seeds of k .. k + 7 symbols
+        fm_index fmi( d_genome.data(), N, 0, kmer, 0, /*sa_int*/ 1, canonical ? (uint32_t)NVBIO_FM_TABLE_CANONICAL : 0u );
         check_hip( hipDeviceSynchronize(), "sync" );
         const double build_s = std::chrono::duration<double>( std::chrono::steady_clock::now() - tb0 ).count();
 
@@ -93,7 +97,10 @@ int main(int argc, char** argv)
         const uint32_t L = 22, S = (uint32_t)(1.0 + 1.15 * std::sqrt( (double)M )), BAND = 31;
         const string_set seeds = string_set::seeds( d_reads.data(), 4, M, R, L, S );
         const uint32_t spr = seeds.c.seeds_per_string, n_seeds = seeds.size();
-        SeedPass pass[2] = { SeedPass( seeds ), SeedPass( seeds ) };
+        std::unique_ptr<SeedPass> pass0, pass1; std::unique_ptr<SeedPassBoth> both;
+        if (canonical) both.reset( new SeedPassBoth( seeds ) );
+        else { pass0.reset( new SeedPass( seeds ) ); pass1.reset( new SeedPass( seeds ) ); }
+        SeedPass* pass[2] = { pass0.get(), pass1.get() };
         device_vector<uint64_t> keys( 2ull * n_seeds ), best( R );
         device_vector<uint32_t> offs( R + 1 ), rid, wb, we, n_unique( 1 );
         device_vector<uint8_t>  flags, rc( R );
@@ -116,33 +123,48 @@ int main(int argc, char** argv)
         {
             check_hip( hipDeviceSynchronize(), "sync" );
             const auto t0 = std::chrono::steady_clock::now();
-            // seeds -> diagonals, both strands enqueued before either count is awaited
-            for (uint32_t strand = 0; strand < 2; ++strand)
-            {
-                pass[strand].enact( fmi, strand ? (NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT) : 0u, M, strand );
-                check_hip( hipMemcpyAsync( h_counts + 2 * strand, pass[strand].counts(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0 ), "hipMemcpyAsync" );
-                check_hip( hipEventRecord( ev[strand], 0 ), "hipEventRecord" );
-            }
             uint64_t n = 0;
-            for (uint32_t strand = 0; strand < 2; ++strand)
+            // seeds on several SA rows (repeats): the ordinary scan + locate, then sort + unique of their diagonals, appended to keys
+            auto residual = [&](const nvbio_uint2* ranges, const uint32_t* ids, const uint32_t nr, const uint32_t strand) {
+                slots.resize( nr );
+                uint64_t n_hits = 0;
+                check( nvbio_fm_filter_scan( fmi.handle(), ranges, nr, slots.data(), &n_hits, 0 ) );
+                if (n + n_hits > keys.size()) keys.resize( n + n_hits );
+                check( nvbio_fm_filter_locate_diagonals( fmi.handle(), ranges, slots.data(), nullptr, nr, 0, n_hits, spr, S, L, M, strand, ids, keys.data() + n, 0 ) );
+                check( nvbio_sort_unique_keys( 0, keys.data() + n, n_hits, n_unique.data(), nullptr, 0, 0 ) );
+                uint32_t nu = 0;
+                check_hip( hipMemcpy( &nu, n_unique.data(), sizeof(uint32_t), hipMemcpyDeviceToHost ), "hipMemcpy" );
+                n += nu;
+            };
+            if (canonical)
             {
-                check_hip( hipEventSynchronize( ev[strand] ), "hipEventSynchronize" );
-                const uint32_t nk = h_counts[2 * strand], nr = h_counts[2 * strand + 1];
-                check_hip( hipMemcpyAsync( keys.data() + n, pass[strand].keys(), (size_t)nk * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0 ), "hipMemcpyAsync" );
-                n += nk;
-                if (nr)
+                // seeds -> diagonals of both strands in one launch; short repeats leave their keys directly
+                both->enact( fmi, NVBIO_FM_INLINE_HITS( 4 ), M );
+                check_hip( hipMemcpyAsync( h_counts, both->counts(), 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0 ), "hipMemcpyAsync" );
+                check_hip( hipEventRecord( ev[0], 0 ), "hipEventRecord" );
+                check_hip( hipEventSynchronize( ev[0] ), "hipEventSynchronize" );
+                const uint32_t nk = h_counts[0];
+                check_hip( hipMemcpyAsync( keys.data(), both->keys(), (size_t)nk * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0 ), "hipMemcpyAsync" );
+                n = nk;
+                if (h_counts[1]) residual( both->residual_ranges(), both->residual_ids(), h_counts[1], 0u );
+                if (h_counts[2]) residual( both->residual_ranges() + both->capacity(), both->residual_ids() + both->capacity(), h_counts[2], 1u );
+            }
+            else
+            {
+                // seeds -> diagonals, both strands enqueued before either count is awaited
+                for (uint32_t strand = 0; strand < 2; ++strand)
                 {
-                    // seeds on several SA rows (repeats): the ordinary scan + locate, then sort + unique of their diagonals
-                    slots.resize( nr );
-                    uint64_t n_hits = 0;
-                    check( nvbio_fm_filter_scan( fmi.handle(), pass[strand].residual_ranges(), nr, slots.data(), &n_hits, 0 ) );
-                    if (n + n_hits > keys.size()) keys.resize( n + n_hits );
-                    check( nvbio_fm_filter_locate_diagonals( fmi.handle(), pass[strand].residual_ranges(), slots.data(), nullptr, nr, 0, n_hits, spr, S, L, M,
-                                                             strand, pass[strand].residual_ids(), keys.data() + n, 0 ) );
-                    check( nvbio_sort_unique_keys( 0, keys.data() + n, n_hits, n_unique.data(), nullptr, 0, 0 ) );
-                    uint32_t nu = 0;
-                    check_hip( hipMemcpy( &nu, n_unique.data(), sizeof(uint32_t), hipMemcpyDeviceToHost ), "hipMemcpy" );
-                    n += nu;
+                    pass[strand]->enact( fmi, strand ? (NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT) : 0u, M, strand );
+                    check_hip( hipMemcpyAsync( h_counts + 2 * strand, pass[strand]->counts(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0 ), "hipMemcpyAsync" );
+                    check_hip( hipEventRecord( ev[strand], 0 ), "hipEventRecord" );
+                }
+                for (uint32_t strand = 0; strand < 2; ++strand)
+                {
+                    check_hip( hipEventSynchronize( ev[strand] ), "hipEventSynchronize" );
+                    const uint32_t nk = h_counts[2 * strand], nr = h_counts[2 * strand + 1];
+                    check_hip( hipMemcpyAsync( keys.data() + n, pass[strand]->keys(), (size_t)nk * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0 ), "hipMemcpyAsync" );
+                    n += nk;
+                    if (nr) residual( pass[strand]->residual_ranges(), pass[strand]->residual_ids(), nr, strand );
                 }
             }
             // diagonals -> windows -> banded Gotoh -> best per read
@@ -184,10 +206,10 @@ int main(int argc, char** argv)
             fwrite( hs.data(), sizeof(int32_t), R, f ); fwrite( hp.data(), sizeof(int64_t), R, f ); fwrite( hr.data(), 1, R, f );
             fclose( f );
         }
-        printf( "{\"program\": \"fmmap_amd (C++ host over the C ABI)\", \"genome_len\": %u, \"reads\": %u, \"read_len\": %u, \"kmer_table\": %u, "
+        printf( "{\"program\": \"fmmap_amd (C++ host over the C ABI)\", \"genome_len\": %u, \"reads\": %u, \"read_len\": %u, \"kmer_table\": %u, \"canonical_table\": %s, "
                 "\"index_build_s\": %.3f, \"ms_per_step\": %.3f, \"reads_per_s\": %.1f, \"candidates\": %llu, \"aligned_fraction\": %.6f, "
                 "\"checksum\": \"%016llx\"}\n",
-                N, R, M, kmer, build_s, step_ms, R / (step_ms * 1e-3), (unsigned long long)n_cand, (double)aligned / R, (unsigned long long)checksum );
+                N, R, M, kmer, canonical ? "true" : "false", build_s, step_ms, R / (step_ms * 1e-3), (unsigned long long)n_cand, (double)aligned / R, (unsigned long long)checksum );
         (void)hipHostFree( h_counts );
     }
     catch (const std::exception& e) { fprintf( stderr, "fmmap_amd: %s\n", e.what() ); return 1; }

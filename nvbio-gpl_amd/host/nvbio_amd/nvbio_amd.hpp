@@ -122,10 +122,12 @@ public:
     fm_index(const nvbio_fm_index_view& view, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0)
         : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_create( &view, device, kmer_len, stream, &m_h ) ); }
     // build on the GPU from a 2-bit packed text in device memory
-    fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0, uint32_t sa_int = 16)
+    // (table_flags: NVBIO_FM_TABLE_*, e.g. NVBIO_FM_TABLE_CANONICAL for the two-strand seed pass)
+    fm_index(const uint32_t* text2_dev, uint32_t length, int device = 0, uint32_t kmer_len = 0, hipStream_t stream = 0, uint32_t sa_int = 16,
+             uint32_t table_flags = 0)
         : m_h( nullptr ), m_device( device )
     {
-        const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u, 0u, 0u, 0u };
+        const nvbio_fm_build_options opts = { kmer_len, sa_int, 0u, 0u, table_flags, 0u };
         check( nvbio_fm_index_build( text2_dev, length, device, &opts, stream, &m_h ) );
     }
     // load the reference's on-disk index files (<prefix>.bwt / .sa as written by nvBWT, read by io::FMIndexDataHost::load,
@@ -134,6 +136,8 @@ public:
         : m_h( nullptr ), m_device( device ) { check( nvbio_fm_index_load( bwt_path, sa_path, device, kmer_len, stream, &m_h ) ); }
     void save(const char* bwt_path, const char* sa_path = nullptr, hipStream_t stream = 0) const { check( nvbio_fm_index_save( m_h, bwt_path, sa_path, stream ) ); }
     bool supports_direct() const { int yes = 0; check( nvbio_fm_index_supports_direct( m_h, &yes ) ); return yes != 0; }
+    uint32_t canonical_kmer() const { return (uint32_t)nvbio_fm_index_is_canonical( m_h ); }    // 0: no canonical table
+    bool canonical() const { return canonical_kmer() != 0; }
     fm_index(const fm_index&) = delete;
     fm_index& operator=(const fm_index&) = delete;
     ~fm_index() { if (m_h) (void)nvbio_fm_index_destroy( m_h ); }
@@ -192,6 +196,39 @@ public:
         check( nvbio_fm_match_seed_diagonals( fmi.handle(), &m_seeds.c, flags, read_len, strand, m_keys.data(), m_ranges.data(), m_ids.data(),
                                               m_counts.data(), m_temp.data(), m_temp.size(), stream ) );
     }
+    const uint64_t*    keys()            const { return m_keys.data(); }
+    const nvbio_uint2* residual_ranges() const { return m_ranges.data(); }
+    const uint32_t*    residual_ids()    const { return m_ids.data(); }
+    const uint32_t*    counts()          const { return m_counts.data(); }
+private:
+    string_set                 m_seeds;
+    device_vector<uint64_t>    m_keys;
+    device_vector<nvbio_uint2> m_ranges;
+    device_vector<uint32_t>    m_ids, m_counts;
+    device_vector<uint8_t>     m_temp;
+};
+
+// the seed pass of BOTH strands in one launch over the canonical table (nvbio_fm_match_seed_diagonals_both; handles built with
+// NVBIO_FM_TABLE_CANONICAL): keys() of both strands tile by tile; the residual seeds of the forward strand in [0, counts()[1]) of
+// residual_ranges() / residual_ids(), of the reverse strand in [capacity(), capacity() + counts()[2]).
+// flags: e.g. NVBIO_FM_INLINE_HITS(4), which keeps the residual lists empty on unique-ish genomes
+class SeedPassBoth
+{
+public:
+    explicit SeedPassBoth(const string_set& seeds) : m_seeds( seeds )
+    {
+        const size_t n = seeds.size();
+        m_keys.resize( 2 * n ); m_ranges.resize( 2 * n ); m_ids.resize( 2 * n ); m_counts.resize( 6 );
+        uint64_t bytes = 0;
+        check( nvbio_fm_match_seed_diagonals_both_temp_bytes( &m_seeds.c, &bytes ) );
+        m_temp.resize( bytes );
+    }
+    void enact(const fm_index& fmi, uint32_t flags, uint32_t read_len, hipStream_t stream = 0)
+    {
+        check( nvbio_fm_match_seed_diagonals_both( fmi.handle(), &m_seeds.c, flags, read_len, m_keys.data(), m_ranges.data(), m_ids.data(),
+                                                   capacity(), m_counts.data(), m_temp.data(), m_temp.size(), stream ) );
+    }
+    uint32_t           capacity()        const { return (uint32_t)m_seeds.size(); }
     const uint64_t*    keys()            const { return m_keys.data(); }
     const nvbio_uint2* residual_ranges() const { return m_ranges.data(); }
     const uint32_t*    residual_ids()    const { return m_ids.data(); }

@@ -156,7 +156,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             rkeys = torch.unique(rkeys)
         return rkeys
 
-    both = fused and fmi.canonical and getattr(params, "two_strand_pass", True)
+    ck = fmi.canonical_kmer if fused else 0
+    both = fused and ck and ck <= L <= ck + 7 and spr <= 64 and getattr(params, "two_strand_pass", True)
     if both:
         # 2.-4. for BOTH strands in one kernel over the canonical table (a k-mer and its reverse complement share an entry): one table
         #    gather per seed window instead of one per window and strand

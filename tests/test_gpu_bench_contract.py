@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_json_contract(extra):
     """the default configuration (canonical table, one seed pass for both strands) and the per-strand one over the direct table"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ref-len", "4e6", "--reads", "40000", "--steps", "2",
-                          "--warmup", "1", "--kmer", "9", "--cpu-sample", "5000"] + extra, capture_output=True, text=True, timeout=600)
+                          "--warmup", "1", "--kmer", "15", "--cpu-sample", "5000"] + extra, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
