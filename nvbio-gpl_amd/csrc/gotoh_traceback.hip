@@ -35,7 +35,8 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
                               const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
                               uint32_t* __restrict__ dirs,
                               int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
-                              uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens)
+                              uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens,
+                              const uint8_t* __restrict__ band_off = nullptr)
 {
     constexpr int WORDS = (BAND + 7) / 8;                        // 32-bit words of direction nibbles per row
 
@@ -56,7 +57,10 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
     const uint32_t fl    = b.flags ? b.flags[job] : 0u;
     const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
     const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
-    const uint32_t tb    = b.win_begin[job];
+    // band_off (a band-15 launch over jobs of a band-31 batch, see the narrow-band route at the entry point): this job's band covers
+    // columns [off, off + 15) of the band the batch asked for -- the window begins `off` symbols later, sink and source move back by it
+    const uint32_t off   = band_off ? band_off[job] : 0u;
+    const uint32_t tb    = b.win_begin[job] + off;
     const uint32_t N     = b.win_end[job] - tb;
 
     int32_t  best   = NVBIO_SCORE_MIN;
@@ -200,7 +204,7 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
     }
 
     scores[job] = best;
-    sinks[job]  = make_uint2( best_x, best_y );
+    sinks[job]  = make_uint2( best_x == 0xFFFFFFFFu ? best_x : best_x + off, best_y );
     if (best_x == 0xFFFFFFFFu || best_y == 0xFFFFFFFFu)         // banded_inl.h:376-379: nothing to trace
     {
         sources[job]    = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu );
@@ -267,7 +271,7 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
     if (!found) { src_y = 0u; src_x = (uint32_t)entry; }
     if (src_y) emit( 3u, src_y );                                // clip the beginning (banded_inl.h:413)
 
-    sources[job]    = make_uint2( src_x, src_y );
+    sources[job]    = make_uint2( src_x + off, src_y );
     cigar_lens[job] = clen;
 }
 
@@ -287,7 +291,8 @@ template <int BAND, int TYPE, int RBITS, int TBITS>
 __global__ void __launch_bounds__(256)
 ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
                           uint2* __restrict__ sources, uint16_t* __restrict__ cigars, const uint32_t cigar_stride,
-                          uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp)
+                          uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp,
+                          uint8_t* __restrict__ band_off = nullptr, const int32_t gap_open_min = 0, const int32_t gap_ext_min = 0)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -369,7 +374,29 @@ ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* _
         if (TYPE == NVBIO_LOCAL && Q == best) found = true;
     }
     if (TYPE != NVBIO_LOCAL) found = (H0 + Q == best);
-    if (!found) { need_dp[job] = 1; return; }
+    if (!found)
+    {
+        // Narrow-band route (band 31, end-to-end, match bonus 0; gap_open_min >= gap_ext_min > 0 are the cheapest open / extension
+        // penalties): every step of a path scores <= 0, so a path that reaches the known optimum S* holds gaps of at most
+        // G = (|S*| - open) / ext + 1 symbols in all (none if |S*| < open) and stays within G diagonals of the column it ends in.  With
+        // G <= 7 all of them fit a band of 15 around the sink's diagonal: the DP over that band alone gives every cell ON such a path
+        // its exact value (its best predecessor is on one too) and can only lower the alternatives a direction rule compares it with,
+        // never one that ties -- a tie would be another optimal path, inside the band as well -- so the directions along the traced
+        // path, hence the CIGAR, are those of the full band at half the cells.  (N >= M + 30: no sentinel column is involved.)
+        uint8_t code = 1;
+        if (BAND == 31 && TYPE == NVBIO_SEMI_GLOBAL && band_off && gap_ext_min > 0 && sink.y == M && N >= M + 30u && best <= 0)
+        {
+            const int32_t a = -best;
+            const int32_t G = a < gap_open_min ? 0 : (a - gap_open_min) / gap_ext_min + 1;
+            if (G <= 7)
+            {
+                code = 2;
+                band_off[job] = (uint8_t)(entry > 7u ? (entry - 7u < 16u ? entry - 7u : 16u) : 0u);
+            }
+        }
+        need_dp[job] = code;
+        return;
+    }
 
     uint16_t* cig = cigars + (size_t)job * cigar_stride;
     uint32_t  clen = 0;
@@ -386,10 +413,11 @@ ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* _
 
 template <int BAND, int TYPE>
 nvbio_status launch_ungapped(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, const int32_t* scores, const uint2* sinks,
-                             uint2* sources, uint16_t* cigars, uint32_t stride, uint32_t* lens, uint8_t* need_dp, hipStream_t s)
+                             uint2* sources, uint16_t* cigars, uint32_t stride, uint32_t* lens, uint8_t* need_dp, uint8_t* band_off, int32_t go_min, int32_t ge_min,
+                             hipStream_t s)
 {
     const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
-#define NVB_GO(RB, TB) hipLaunchKernelGGL( (ungapped_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks, sources, cigars, stride, lens, need_dp )
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (ungapped_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, scores, sinks, sources, cigars, stride, lens, need_dp, band_off, go_min, ge_min )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -405,13 +433,13 @@ nvbio_status launch_ungapped(const BatchDev& b, const SchemeDev& sc, uint32_t rb
 template <int BAND>
 nvbio_status launch_ungapped_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, const int32_t* scores,
                                   const uint2* sinks, uint2* sources, uint16_t* cigars, uint32_t stride, uint32_t* lens, uint8_t* need_dp,
-                                  hipStream_t s)
+                                  uint8_t* band_off, int32_t go_min, int32_t ge_min, hipStream_t s)
 {
     switch (type)
     {
-    case NVBIO_GLOBAL:      return launch_ungapped<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
-    case NVBIO_LOCAL:       return launch_ungapped<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
-    case NVBIO_SEMI_GLOBAL: return launch_ungapped<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, s );
+    case NVBIO_GLOBAL:      return launch_ungapped<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, band_off, go_min, ge_min, s );
+    case NVBIO_LOCAL:       return launch_ungapped<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, band_off, go_min, ge_min, s );
+    case NVBIO_SEMI_GLOBAL: return launch_ungapped<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, scores, sinks, sources, cigars, stride, lens, need_dp, band_off, go_min, ge_min, s );
     }
     set_error( "invalid alignment type %d", type );
     return NVBIO_ERR_INVALID;
@@ -420,10 +448,10 @@ nvbio_status launch_ungapped_type(int type, const BatchDev& b, const SchemeDev& 
 template <int BAND, int TYPE>
 nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
-                         uint32_t* lens, hipStream_t s)
+                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr)
 {
     const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
-#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens )
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, band_off )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -439,19 +467,20 @@ nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits,
 template <int BAND>
 nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
-                         uint32_t* lens, hipStream_t s)
+                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr)
 {
     switch (type)
     {
-    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
-    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
-    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s );
+    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
+    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
+    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
     }
     set_error( "invalid alignment type %d", type );
     return NVBIO_ERR_INVALID;
 }
 
 inline uint64_t row_bytes(const uint32_t band) { return (uint64_t)((band + 7u) / 8u) * sizeof(uint32_t); }
+template <int CODE> struct IsCode { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == (uint8_t)CODE ? 1u : 0u; } };
 
 } // anonymous namespace
 } // namespace nvbio_amd
@@ -501,9 +530,16 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 
     // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
     const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
-    uint8_t*  need_dp   = nullptr;      // [n] flags
+    uint8_t*  need_dp   = nullptr;      // [n] flags: 0 settled, 1 the DP, 2 the DP over a band of 15 (band 31 only)
     uint32_t* job_list  = nullptr;      // [n] compacted job ids
     uint32_t* job_count = nullptr;      // [1]
+    uint8_t*  band_off  = nullptr;      // [n] narrow-band route: first column of the job's band of 15
+    uint32_t* job_list2 = nullptr;      // [n], [1]: its jobs
+    uint32_t* job_count2 = nullptr;
+    // the narrow-band route applies to nvBowtie's end-to-end mode (see ungapped_traceback_kernel)
+    const int32_t go_min = -(sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go), ge_min = -(sc.pat_ge > sc.txt_ge ? sc.pat_ge : sc.txt_ge);
+    const bool narrow = band == 31 && type == NVBIO_SEMI_GLOBAL && sc.match == 0 && sc.mm_min >= 0 && sc.mm_max >= 0 && plain_gotoh( sc ) &&
+                        ge_min > 0 && go_min >= ge_min && !(b.algo & NVBIO_ALN_NO_NARROW_TRACEBACK);
     void*     sel_temp  = nullptr;
     void*     aux       = nullptr;
     if (shortcut)
@@ -515,7 +551,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (hipMallocAsync( &aux, 2u * (flags_bytes + list_bytes + 256u) + sel_bytes, s ) != hipSuccess)
         {
             set_error( "banded traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
@@ -523,10 +559,14 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         need_dp   = (uint8_t*)aux;
         job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
         job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
-        sel_temp  = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        band_off   = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        job_list2  = (uint32_t*)(band_off + flags_bytes);
+        job_count2 = (uint32_t*)(band_off + flags_bytes + list_bytes);
+        sel_temp   = (uint8_t*)aux + 2u * (flags_bytes + list_bytes + 256u);
         nvbio_status st1;
 #define NVB_BAND(B) st1 = launch_ungapped_type<B>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (const uint2*)sinks_dev, \
-                                                   (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp, s )
+                                                   (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp,             \
+                                                   narrow ? band_off : nullptr, go_min, ge_min, s )
         switch (band)
         {
         case 3:  NVB_BAND(3);  break;
@@ -537,7 +577,10 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 #undef NVB_BAND
         if (st1 != NVBIO_OK) { (void)hipFreeAsync( aux, s ); return st1; }
         // ---- 3. the jobs that do need the DP, compacted (their number stays on the device) ----
-        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        hipcub::TransformInputIterator<uint8_t, IsCode<1>, const uint8_t*> is_full( need_dp, IsCode<1>() );
+        hipcub::TransformInputIterator<uint8_t, IsCode<2>, const uint8_t*> is_narrow( need_dp, IsCode<2>() );
+        hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_full, job_list, job_count, (int)b.n, s );
+        if (e == hipSuccess && narrow) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_narrow, job_list2, job_count2, (int)b.n, s );
         if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
@@ -587,6 +630,17 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         default: NVB_BAND(31); break;
         }
 #undef NVB_BAND
+    }
+    if (narrow && shortcut)
+    {
+        // the jobs of the narrow-band route: the band-15 kernel over their list, twice as many per launch in the same scratch
+        const uint64_t cap2 = cap_jobs * per_job / ((uint64_t)b.max_read_len * row_bytes( 15 ));
+        for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap2)
+        {
+            const uint32_t jobs = (uint32_t)((b.n - begin) < cap2 ? (b.n - begin) : cap2);
+            st = launch_type<15>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, job_list2, job_count2, dirs, scores_dev,
+                                  (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s, band_off );
+        }
     }
     if (owned) (void)hipFreeAsync( owned, s );
     if (aux)   (void)hipFreeAsync( aux, s );

@@ -16,11 +16,14 @@ def _i64(t):
     return t.cpu().numpy().astype(np.int64)
 
 
-@pytest.fixture(params=["shortcut", "dp-only"])
+@pytest.fixture(params=["shortcut", "dp-only", "no-narrow"])
 def tb_mode(request, monkeypatch, amd):
-    """the ungapped shortcut (default) and the plain DP-for-every-job path must both equal the reference"""
+    """the default route (ungapped shortcut; band-15 DP for the end-to-end jobs whose optimal paths stay within 7 diagonals of the
+    sink), the plain DP-for-every-job path, and the shortcut with every DP over the whole band must all equal the reference"""
     if request.param == "dp-only":
         monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_UNGAPPED_TRACEBACK)
+    if request.param == "no-narrow":
+        monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_NARROW_TRACEBACK)
     return request.param
 
 
