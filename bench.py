@@ -334,7 +334,7 @@ def main():
         c = bufs["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         n_tiles = -(-R // (64 // spr))
         sectors = float(int(c[4] | (c[5] << 32)))
-        launch_bytes = sectors * SECTOR + float(R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * 2 * n_tiles + 12 * int(c[1] + c[2]))
+        launch_bytes = sectors * SECTOR + float(R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1] + c[2]))
         del bufs
     elif use_fused:
         acc = []

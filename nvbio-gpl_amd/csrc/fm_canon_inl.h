@@ -213,8 +213,8 @@ static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hi
 
 // ---------------------------------------------------------------------------------------------
 // the seed pass of both strands: one wave per tile of whole reads, software-pipelined over the tiles a wave owns as
-// fm_seed_pipe_kernel (words of tile t+2 | table entry of tile t+1 | resolution of tile t).  Keys of the forward strand go to
-// the tile's slots [0, 64), of the reverse strand to [64, 128); tile_counts[2 tile + strand].  Seeds whose k-mer has more than
+// fm_seed_pipe_kernel (words of tile t+2 | table entry of tile t+1 | resolution of tile t).  A tile has 128 key slots: the keys of the
+// forward strand (at most 64), those of the reverse strand right behind them; tile_counts[tile] = both.  Seeds whose k-mer has more than
 // 8 occurrences, or with several hits on a strand (a repeat longer than the seed), take the ordinary search of that strand
 // (plain table + rank steps + finish on the text) inside the kernel; what ends on several rows goes to that strand's residual
 // list: ranges / ids [0, cap) forward, [cap, 2 cap) reverse; counts[1], counts[2].
@@ -318,6 +318,7 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
         }
         uint32_t sectors = e_valid ? (is_group ? 2u : 1u) : 0u;
         const uint32_t i = rid * q.spr + j;
+        uint32_t tile_fill = 0;                                              // keys of this tile written so far: the reverse strand's follow the forward strand's
         #pragma unroll
         for (int s = 0; s < 2; ++s)
         {
@@ -355,7 +356,7 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
                 if (!searched) (void)plain_search();
                 cnt = 0u;
             }
-            uint64_t* slots = tile_keys + (uint64_t)tile * 128u + 64u * s;
+            uint64_t* slots = tile_keys + (uint64_t)tile * 128u + tile_fill;
             uint32_t n_out = 0; uint64_t last = ~0ull;
             const uint32_t x1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? rx : 1u), y1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? ry : 0u);
             emit_seed_results( q, len, read_len, (uint32_t)s, lane, valid, cnt == 1u, x1, y1, rid, j, i, slots, n_out, last,
@@ -375,8 +376,9 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
                     n_out += (uint32_t)__popcll( mk );
                 }
             }
-            if (lane == 0) tile_counts[2u * tile + s] = n_out;
+            tile_fill += n_out;
         }
+        if (lane == 0) tile_counts[tile] = tile_fill;
         if (COUNT)
         {
             uint32_t tot = valid ? sectors : 0u;

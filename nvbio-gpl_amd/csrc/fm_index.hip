@@ -1665,10 +1665,10 @@ static nvbio_status seed_both_layout(const nvbio_string_set* seeds, SeedScratch*
     NVB_REQUIRE( seeds->seeds_per_string <= 64u, "the two-strand seed pass takes at most 64 seeds per read" );
     L->slots        = 128u;
     L->keys_bytes   = ((uint64_t)L->tl.n_tiles * 128u * sizeof(uint64_t) + 255u) & ~255ull;
-    L->counts_bytes = ((uint64_t)(2u * L->tl.n_tiles + 1u) * sizeof(uint32_t) + 255u) & ~255ull;
+    L->counts_bytes = ((uint64_t)(L->tl.n_tiles + 1u) * sizeof(uint32_t) + 255u) & ~255ull;
     size_t scan = 0;
     if (L->tl.n_tiles)
-        NVB_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(2u * L->tl.n_tiles), (hipStream_t)0 ) );
+        NVB_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)L->tl.n_tiles, (hipStream_t)0 ) );
     L->scan_bytes = ((uint64_t)scan + 255u) & ~255ull;
     L->total = L->keys_bytes + 2u * L->counts_bytes + L->scan_bytes + 256u;
     return NVBIO_OK;
@@ -1738,12 +1738,11 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
 #undef NVB_LAUNCH_SB
     hipError_t e = hipGetLastError();
     size_t scan_bytes = L.scan_bytes;
-    const uint32_t n2 = 2u * L.tl.n_tiles;
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)n2, s );
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( n2 ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
-                            (const uint32_t*)tile_offsets, n2, 64u, keys_dev, (unsigned int*)counts_dev );
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+                            (const uint32_t*)tile_offsets, L.tl.n_tiles, 128u, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }
     if (own_temp) (void)hipFreeAsync( temp, s );
