@@ -155,6 +155,7 @@ def main():
                     help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--no-mapq", action="store_true", help="leave nvBowtie's second-best bookkeeping and the mapping quality out of the step")
     ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
+    ap.add_argument("--algo-flags", type=int, default=0, help="A/B: NVBIO_ALN_* flags OR-ed into every alignment batch of the timed step")
     ap.add_argument("--pk-two-waves", action="store_true", help="A/B: the packed band-31 DP kernel built for 2 waves per SIMD (no register spills)")
     ap.add_argument("--with-traceback", action="store_true", help="put the traceback of every aligned read's best alignment (CIGARs) inside the timed step")
     ap.add_argument("--build-breakdown", action="store_true", help="build the index once more without tables to report index_build_s and table_build_s separately")
@@ -233,6 +234,8 @@ def main():
     params.max_seed_hits = args.max_seed_hits or None
     if args.pk_two_waves:
         params.algo_flags = amd.ALN_PK_TWO_WAVES
+    if args.algo_flags:
+        params.algo_flags = (params.algo_flags or 0) | args.algo_flags
     params.fused_seed_pass = not args.no_fused_seeds
     params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c

@@ -569,6 +569,7 @@ enum
     NVBIO_ALN_NO_UNGAPPED_TRACEBACK = 16,  /* every traceback through the direction-vector DP                                   */
     NVBIO_ALN_PK_TWO_WAVES          = 32,  /* packed band-31 kernel built for 2 waves per SIMD (256 VGPRs, no register spills) instead
                                               of 3 (168 VGPRs; SEMI_GLOBAL / GLOBAL spill their prologue state)                  */
+    NVBIO_ALN_NO_SECOND_CHANCE      = 128, /* two-mismatch jobs go to the DP (A/B: what the check costs inside the first pass)           */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs
                                               whose optimal paths provably stay within 7 diagonals of the sink)                  */
 };

@@ -535,15 +535,21 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
 // THIRD = true : the pass over the list of those jobs (job_list / job_count on the device), which resolves each to 0 or 1.
 //   Kept apart because the third chance is ten times the work of the rest and only one job in eight needs it: inside the first
 //   pass every wave paid for it (measured: 0.39 -> 2.1 ms per launch), on a dense list it costs what it saves several times over.
-template <int RBITS, bool THIRD>
+// MODE 0: the pass over every job: best diagonal, settled or not; a job the second (third) chance could still settle is flagged
+//   need_dp = 3 (2) with its best diagonal stashed in scores / sinks -- those checks cost as much as everything else in this pass and
+//   every wave paid for them whenever one lane needed one (the second chance, one job in four, was HALF of this kernel's 1.46 ms).
+// MODE 1 / 2: the pass over the dense list of the need_dp = 3 / 2 jobs (job_list / job_count on the device): the second / third chance,
+//   each job ends as 0 or 1.
+template <int RBITS, int MODE>
 __global__ void __launch_bounds__(256)
 ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
                       int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp,
                       const uint32_t* __restrict__ job_list = nullptr, const uint32_t* __restrict__ job_count = nullptr)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (THIRD ? slot >= *job_count : slot >= b.n) return;
-    const uint32_t job = THIRD ? job_list[slot] : slot;
+    constexpr bool LIST = MODE != 0;
+    if (LIST ? slot >= *job_count : slot >= b.n) return;
+    const uint32_t job = LIST ? job_list[slot] : slot;
     const uint32_t rid   = b.read_id ? b.read_id[job] : job;
     const uint32_t first = b.read_offsets[rid];
     const uint32_t M     = b.read_offsets[rid + 1] - first;
@@ -602,28 +608,46 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     for (int k = 0; k < 7; ++k) { ql0[k] = ql[k]; qh0[k] = qh[k]; }
 
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
-    for (uint32_t d = 0; d < 31u; ++d)
+    if (LIST)
     {
-        if (!(d == 0u || d < m)) break;                          // reportable columns are a prefix of 0..30
-        uint32_t cnt = 0;
-        #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        // the first pass left this job's best diagonal in scores / sinks
+        const int32_t us = scores[job];
+        best_cnt = P > 0 ? (uint32_t)(-us / P) : 0u;
+        best_d   = sinks[job].x - M;
+    }
+    else
+    {
+        for (uint32_t d = 0; d < 31u; ++d)
         {
-            const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
-            cnt += (uint32_t)__popc( mm );
+            if (!(d == 0u || d < m)) break;                          // reportable columns are a prefix of 0..30
+            uint32_t cnt = 0;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                cnt += (uint32_t)__popc( mm );
+            }
+            if (cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+            }
+            ql[6] >>= 1; qh[6] >>= 1;
         }
-        if (cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
-        #pragma unroll
-        for (int k = 0; k < 6; ++k)
-        {
-            ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
-            qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
-        }
-        ql[6] >>= 1; qh[6] >>= 1;
     }
     const int64_t U = -(int64_t)P * (int64_t)best_cnt;
     bool settled = U > (int64_t)G;
-    if (!THIRD && !settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u)
+    auto stash = [&]() { scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); };
+    const bool second_applies = !settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u && !(b.algo & NVBIO_ALN_NO_SECOND_CHANCE);
+    if (MODE == 0 && second_applies)
+    {
+        int32_t gmax = 0;
+        while (gmax < 5 && (int64_t)gap_open + (int64_t)gmax * gap_ext >= U) ++gmax;
+        if (gmax >= 1 && gmax <= 4) { need_dp[job] = 3; stash(); return; }      // for the second-chance launch
+    }
+    if (MODE == 1 && second_applies)
     {
         // Second chance (two mismatches at nvBowtie's -6 / -8 / -3).  U* <= G, but one gap plus one mismatch and two gaps
         // both score below U*: the only gapped alignments that could reach U* have exactly ONE gap and NO mismatch, i.e. a
@@ -695,12 +719,12 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     const bool two11  = 2 * go >= U;
     const bool beyond = gmax0 > 4 || gmax1 > 4 || go - 2 * (int64_t)P >= U || 2 * go + ge >= U || 2 * go - P >= U || 3 * go >= U || ge < go;
     const bool third_applies = !settled && N >= M + 30u && !beyond && gmax0 >= 1 && (gmax1 >= 1 || two11);
-    if (!THIRD && third_applies)
+    if (MODE == 0 && third_applies)
     {
-        need_dp[job] = 2;                                        // for the second launch
+        need_dp[job] = 2; stash();                               // for the third-chance launch
         return;
     }
-    if (THIRD && third_applies)
+    if (MODE != 0 && third_applies)                              // (MODE 1: a job the second chance did not settle)
     {
         // With lead0/lead1(d) = rows before the first / second mismatch of diagonal d and tail0/tail1(d) = rows after its last /
         // last-but-one mismatch:
@@ -844,6 +868,7 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
 }
 
 struct IsTwo { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 2u ? 1u : 0u; } };
+struct FlagIs { const uint8_t* flags; uint8_t code; __host__ __device__ __forceinline__ bool operator()(const uint32_t i) const { return flags[i] == code; } };
 
 template <int TYPE, int RB>
 static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
@@ -861,31 +886,40 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
         const bool third = !(b.algo & NVBIO_ALN_NO_THIRD_CHANCE);
         void* aux = nullptr;
-        if (hipMallocAsync( &aux, flags_bytes + 2u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        // three-way partition of the job ids by flag (3: second chance, 2: third chance), the rest discarded
+        size_t part_bytes = 0;
+        hipcub::DiscardOutputIterator<uint32_t> nowhere;
+        const FlagIs is3 = { nullptr, 3 }, is2 = { nullptr, 2 };
+        NVB_HIP( hipcub::DevicePartition::If( nullptr, part_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, nowhere, (uint32_t*)nullptr, (int)b.n, is3, is2, s ) );
+        if (part_bytes > sel_bytes) sel_bytes = part_bytes;
+        if (hipMallocAsync( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             set_error( "banded score: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
         uint8_t*  need_dp   = (uint8_t*)aux;
         uint32_t* job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
-        uint32_t* list_t    = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
-        uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + 2u * list_bytes);
-        uint32_t* count_t   = job_count + 1;
-        void*     sel_temp  = (uint8_t*)aux + flags_bytes + 2u * list_bytes + 256u;
-        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,false>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+        uint32_t* list_s    = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);          // second-chance jobs
+        uint32_t* list_t    = (uint32_t*)((uint8_t*)aux + flags_bytes + 2u * list_bytes);     // third-chance jobs
+        uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + 3u * list_bytes);
+        uint32_t* count_st  = job_count + 2;                                                  // [2]: second, third
+        void*     sel_temp  = (uint8_t*)aux + flags_bytes + 3u * list_bytes + 256u;
+        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,0>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
                             (const uint32_t*)nullptr, (const uint32_t*)nullptr );
         hipError_t e = hipSuccess;
         {
-            // the jobs a third chance can still settle (need_dp == 2), compacted, through their own launch: each ends as 0 or 1.
-            // (With NVBIO_AMD_NO_THIRD_CHANCE they are simply handed to the DP: a non-zero flag selects.)
-            if (third)
-            {
-                hipcub::TransformInputIterator<uint8_t, IsTwo, const uint8_t*> twos( (const uint8_t*)need_dp, IsTwo() );
-                e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, twos, list_t, count_t, (int)b.n, s );
-                if (e == hipSuccess)
-                    hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,true>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
-                                        (const uint32_t*)list_t, (const uint32_t*)count_t );
-            }
+            // the jobs a second / third chance can still settle (need_dp == 3 / 2), compacted by one three-way partition, each list through
+            // its own launch: every job ends as 0 or 1.  (With NVBIO_ALN_NO_THIRD_CHANCE the third-chance jobs are simply handed to the
+            // DP: a non-zero flag selects; NVBIO_ALN_NO_SECOND_CHANCE keeps the first pass from flagging any.)
+            const FlagIs f3 = { need_dp, 3 }, f2 = { need_dp, 2 };
+            size_t pb = sel_bytes;
+            e = hipcub::DevicePartition::If( sel_temp, pb, ids, list_s, list_t, nowhere, count_st, (int)b.n, f3, f2, s );
+            if (e == hipSuccess)
+                hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,1>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                    (const uint32_t*)list_s, (const uint32_t*)count_st );
+            if (e == hipSuccess && third)
+                hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,2>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                    (const uint32_t*)list_t, (const uint32_t*)(count_st + 1) );
         }
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
