@@ -739,29 +739,30 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
         #pragma unroll
         for (int k = 0; k < 7; ++k) { ql[k] = ql0[k]; qh[k] = qh0[k]; }
         uint32_t lead0_p[4] = { 0, 0, 0, 0 }, lead1_p[4] = { 0, 0, 0, 0 }, tail0_p[4] = { 0, 0, 0, 0 }, tail1_p[4] = { 0, 0, 0, 0 };   // d-1 .. d-4
-        uint32_t mmp[6] = { 0, 0, 0, 0, 0, 0 };                                         // mismatch words of diagonal d-1
         bool gapped = false;
         for (uint32_t d = 0; d <= 31u && !gapped; ++d)
         {
             const bool have = d < 31u;                                                  // d = 31 only closes class C for b = 30
-            uint32_t mm[6];
+            // the first two and the last two mismatching rows of the diagonal, searched from the two ends and only as far as needed: on a
+            // diagonal that is not (nearly) the read's own the first and the top word already hold two mismatches each, and a word is
+            // evaluated by the wave only while some lane is still looking (the values are the same as with all 12 word evaluations)
             uint32_t first = M, second = M, last = 0xFFFFFFFFu, last2 = 0xFFFFFFFFu;
             #pragma unroll
-            for (int k = 0; k < 6; ++k) mm[k] = have ? ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k]) : 0u;
-            #pragma unroll
             for (int k = 0; k < 6; ++k)
-            {
-                uint32_t w = mm[k];
-                if (first == M && w) { first = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
-                if (first != M && second == M && w) second = 32u * k + (uint32_t)__builtin_ctz( w );
-            }
+                if (have && __any( second == M ))                       // a wave-uniform branch: really skipped when no lane is looking
+                {
+                    uint32_t w = (second == M) ? ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k]) : 0u;
+                    if (first == M && w) { first = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                    if (first != M && second == M && w) second = 32u * k + (uint32_t)__builtin_ctz( w );
+                }
             #pragma unroll
             for (int k = 5; k >= 0; --k)
-            {
-                uint32_t w = mm[k];
-                if (last == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); last = 32u * k + t; w &= ~(1u << t); }
-                if (last != 0xFFFFFFFFu && last2 == 0xFFFFFFFFu && w) last2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
-            }
+                if (have && __any( last2 == 0xFFFFFFFFu ))
+                {
+                    uint32_t w = (last2 == 0xFFFFFFFFu) ? ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k]) : 0u;
+                    if (last == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); last = 32u * k + t; w &= ~(1u << t); }
+                    if (last != 0xFFFFFFFFu && last2 == 0xFFFFFFFFu && w) last2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
+                }
             const uint32_t lead0 = first, lead1 = second;                               // rows before the 1st / 2nd mismatch
             const uint32_t tail0 = (last  == 0xFFFFFFFFu) ? M : M - 1u - last;          // rows after the last / last-but-one
             const uint32_t tail1 = (last2 == 0xFFFFFFFFu) ? M : M - 1u - last2;
@@ -808,7 +809,10 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
                                 {
                                     const uint32_t hi_m = (a1 >= 32) ? 0xFFFFFFFFu : ((1u << a1) - 1u);
                                     const uint32_t lo_m = (1u << a0) - 1u;                                       // a0 < a1 <= 32 -> a0 <= 31
-                                    any = any || ((mmp[k] & hi_m & ~lo_m) != 0u);
+                                    // word k of the middle diagonal d-1, from the untouched planes
+                                    const uint32_t tl = __builtin_amdgcn_alignbit( ql0[k + 1], ql0[k], d - 1u ), th = __builtin_amdgcn_alignbit( qh0[k + 1], qh0[k], d - 1u );
+                                    const uint32_t mw = (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k];
+                                    any = any || ((mw & hi_m & ~lo_m) != 0u);
                                 }
                             }
                         }
@@ -818,8 +822,6 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
             #pragma unroll
             for (int k = 3; k > 0; --k) { lead0_p[k] = lead0_p[k - 1]; lead1_p[k] = lead1_p[k - 1]; tail0_p[k] = tail0_p[k - 1]; tail1_p[k] = tail1_p[k - 1]; }
             lead0_p[0] = lead0; lead1_p[0] = lead1; tail0_p[0] = tail0; tail1_p[0] = tail1;
-            #pragma unroll
-            for (int k = 0; k < 6; ++k) mmp[k] = mm[k];
             #pragma unroll
             for (int k = 0; k < 6; ++k)
             {
