@@ -574,19 +574,23 @@ fm_seed_pipe_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
     }
 }
 
-// keys of tile t -> keys_out[offsets[t] ...]; the last tile also writes the total.  One LANE per tile: a tile holds a handful of
-// keys (3.8 on the benchmark), so a lane copies its tile's keys one by one while counts and offsets are read coalesced
+// keys of tile t -> keys_out[offsets[t] ...]; the last tile also writes the total.  A few LANES per tile: a tile holds a handful of
+// keys (3.8 per strand on the benchmark), copied one by one while counts and offsets are read coalesced
 // (one wave per tile, the first version, spent 0.2 ms per launch starting 1.4 M waves that copied four keys each).
 __global__ void __launch_bounds__(256)
 fm_seed_compact_kernel(const uint64_t* __restrict__ tile_keys, const uint32_t* __restrict__ tile_counts, const uint32_t* __restrict__ tile_offsets,
                        const uint32_t n_tiles, const uint32_t slots, uint64_t* __restrict__ keys_out, unsigned int* __restrict__ counts)
 {
-    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += gridDim.x * blockDim.x)
+    // four lanes per tile, each copying every fourth key: a tile of the two-strand pass holds ~8 keys (one lane per tile took 0.25 ms
+    // there, one per tile and strand 0.17), of the per-strand pass ~4
+    const uint64_t total = 4ull * n_tiles;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
     {
+        const uint32_t tile = (uint32_t)(t >> 2), part = (uint32_t)(t & 3u);
         const uint32_t n = tile_counts[tile], off = tile_offsets[tile];
         const uint64_t* src = tile_keys + (uint64_t)tile * slots;
-        for (uint32_t k = 0; k < n; ++k) keys_out[off + k] = src[k];
-        if (tile == n_tiles - 1u) counts[0] = off + n;
+        for (uint32_t k = part; k < n; k += 4u) keys_out[off + k] = src[k];
+        if (tile == n_tiles - 1u && part == 0u) counts[0] = off + n;
     }
 }
 
@@ -1644,7 +1648,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( 4ull * L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, L.slots, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }
@@ -1741,7 +1745,7 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
+        hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( 4ull * L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, 128u, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }
