@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-fused-seeds", action="store_true", help="match_direct + scan + locate_diagonals + dedupe as separate operators instead of the one-kernel seed pass")
     ap.add_argument("--no-canonical", action="store_true", help="the 128 GiB direct table and one seed pass per strand instead of the 64 GiB canonical "
                     "table and one pass for both strands")
+    ap.add_argument("--no-wide-table", action="store_true", help="the canonical table with 8-byte entries (64 GiB at k = 17; a k-mer with two occurrences "
+                    "then takes the group gather) instead of 16-byte ones (128 GiB, two occurrences in line)")
     ap.add_argument("--no-plain-ab", action="store_true", help="skip the (untimed) run through the plain operators without the two exact shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -210,7 +212,7 @@ def main():
                  and not args.no_fused_seeds)               # the canonical table serves seeds of k .. k + 7 symbols (22-mers: k >= 15)
     try:
         fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=args.sa_int, verify=(args.sa_int == 1 and args.verify),
-                                table_flags=amd.FM_TABLE_CANONICAL if canonical else 0)
+                                table_flags=(amd.FM_TABLE_CANONICAL if args.no_wide_table else amd.FM_TABLE_CANONICAL_WIDE) if canonical else 0)
     except amd.NvbioError as e:
         if args.kmer <= 16 or "memory" not in str(e):
             raise
@@ -419,7 +421,7 @@ def main():
                 gj = json.loads(line)
             except Exception:
                 continue
-            if gj.get("footprint_bytes") == ((64 << 30) if use_both else (128 << 30)) and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
+            if gj.get("footprint_bytes") == ((64 << 30) if (use_both and args.no_wide_table) else (128 << 30)) and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
                 ceiling = gj.get("G_gathers_per_s")
     cells = float(nc) * params.band * M
     extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0) + stage_ms.get("extend", 0.0) + stage_ms.get("extend_res", 0.0)
@@ -442,7 +444,7 @@ def main():
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
                    "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
-                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "canonical_table": use_both, "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
+                                 if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "canonical_table": use_both, "wide_entries": bool(use_both and not args.no_wide_table), "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world,
                    "traceback_in_step": bool(args.with_traceback), "repeat_family_copies": args.repeat_family,
                    "max_seed_hits": params.max_seed_hits},

@@ -125,6 +125,9 @@ enum
     NVBIO_FM_TABLE_NO_CONTEXT = 2,  /* direct table, format 1: one-row entries hold the position only (the rest of a seed is then
                                        verified with a gather from the text)                                                      */
     NVBIO_FM_TABLE_NO_GROUPS  = 4,  /* no groups for k-mers with 2..7 occurrences (they keep their SA range and take rank steps)  */
+    NVBIO_FM_TABLE_CANONICAL_WIDE = 16, /* NVBIO_FM_TABLE_CANONICAL with 16-byte entries: a k-mer with TWO occurrences (of either orientation) has
+                                       both rows in its entry, so that only k-mers with three or more take the second gather (1.07 instead
+                                       of 1.25 sectors per seed window on a 3 Gbp text; 128 GiB at k = 17)                         */
     NVBIO_FM_TABLE_CANONICAL  = 8   /* instead of the direct table: ONE table for a k-mer and its reverse complement (kmer_len odd; 64 GiB at
                                        k = 17 where the direct table takes 128), serving nvbio_fm_match_seed_diagonals_both; the plain table of
                                        (kmer_len - 1)-mers is kept for match().  Needs sa_int = 1.                                */

@@ -28,7 +28,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
 FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS, FM_NO_PIPELINE = 1, 2, 4, 8, 16, 32
-FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS, FM_TABLE_CANONICAL = 1, 2, 4, 8      # nvbio_fm_build_options::table_flags
+FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS, FM_TABLE_CANONICAL, FM_TABLE_CANONICAL_WIDE = 1, 2, 4, 8, 16      # nvbio_fm_build_options::table_flags
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
 # nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)

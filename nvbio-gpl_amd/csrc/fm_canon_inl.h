@@ -58,10 +58,11 @@ __device__ __forceinline__ uint2 canon_range(const DevIndex& f, const uint64_t k
 }
 __device__ __forceinline__ uint32_t range_rows(const uint2 r) { return r.x <= r.y ? r.y - r.x + 1u : 0u; }
 
-// 0: empty / heavy   1: one occurrence   2: 2..4 (4 slots)   3: 5..8 (8 slots)
-__device__ __forceinline__ uint32_t canon_class(const uint32_t m)
+// 0: empty / heavy   1: in the entry itself (one occurrence; two with 16-byte entries)   2: up to 4 rows (4 slots)   3: 5..8 (8 slots)
+__device__ __forceinline__ uint32_t canon_class(const uint32_t m, const bool wide)
 {
-    return m == 1u ? 1u : (m >= 2u && m <= 4u ? 2u : (m >= 5u && m <= CTAB_ROWS_MAX ? 3u : 0u));
+    if (m == 1u || (wide && m == 2u)) return 1u;
+    return m >= 2u && m <= 4u ? 2u : (m >= 5u && m <= CTAB_ROWS_MAX ? 3u : 0u);
 }
 
 // the row of an occurrence: o = 0: text[p, p+k) is the canonical k-mer; o = 1: its reverse complement
@@ -84,9 +85,10 @@ __device__ __forceinline__ uint2 canon_row(const uint32_t* __restrict__ text, co
 
 // pass 1: tab[idx] = SA range of the reverse complement of canonical k-mer idx (kept for pass 2); per-tile group counts
 __global__ void __launch_bounds__(256)
-fm_ctab_count_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
+fm_ctab_count_kernel(const DevIndex f, const uint32_t k, const uint32_t wide, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
                      uint32_t* __restrict__ cnt_small, uint32_t* __restrict__ cnt_large)
 {
+    const uint32_t stride = wide ? 2u : 1u;                      // slots per entry
     __shared__ uint32_t s_a[4], s_b[4];
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
     {
@@ -98,8 +100,8 @@ fm_ctab_count_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab
             {
                 const uint64_t key = canon_key( e0 + j, k );
                 const uint2 r1 = canon_range( f, key ), r2 = canon_range( f, canon_revcomp( key, k ) );
-                tab[e0 + j] = r2;
-                const uint32_t c = canon_class( range_rows( r1 ) + range_rows( r2 ) );
+                tab[(e0 + j) * stride] = r2;
+                const uint32_t c = canon_class( range_rows( r1 ) + range_rows( r2 ), wide != 0u );
                 a += (c == 2u); b += (c == 3u);
             }
         a = wave_inclusive_sum( a ); b = wave_inclusive_sum( b );
@@ -112,10 +114,11 @@ fm_ctab_count_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab
 
 // pass 2: the entries and the groups; large groups occupy side slots [0, 8 tot_large), small ones follow
 __global__ void __launch_bounds__(256)
-fm_ctab_fill_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
+fm_ctab_fill_kernel(const DevIndex f, const uint32_t k, const uint32_t wide, uint2* __restrict__ tab, const uint64_t n, const uint32_t n_tiles,
                     const uint32_t* __restrict__ off_small, const uint32_t* __restrict__ off_large, const uint32_t tot_large, uint2* __restrict__ side)
 {
     __shared__ uint32_t s_a[4], s_b[4];
+    const uint32_t stride = wide ? 2u : 1u;
     auto position = [&](const uint32_t row) -> uint32_t { const uint32_t sv = f.ssa[row]; return sv == 0xFFFFFFFFu ? f.length : sv; };
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
     {
@@ -128,8 +131,8 @@ fm_ctab_fill_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab,
             c[j] = 0u; r1[j] = r2[j] = make_uint2( 1u, 0u );
             if (e0 + j < n)
             {
-                r1[j] = canon_range( f, canon_key( e0 + j, k ) ); r2[j] = tab[e0 + j];
-                c[j] = canon_class( range_rows( r1[j] ) + range_rows( r2[j] ) );
+                r1[j] = canon_range( f, canon_key( e0 + j, k ) ); r2[j] = tab[(e0 + j) * stride];
+                c[j] = canon_class( range_rows( r1[j] ) + range_rows( r2[j] ), wide != 0u );
                 a += (c[j] == 2u); b += (c[j] == 3u);
             }
         }
@@ -145,29 +148,32 @@ fm_ctab_fill_kernel(const DevIndex f, const uint32_t k, uint2* __restrict__ tab,
         {
             if (e0 + j >= n) continue;
             const uint32_t n1 = range_rows( r1[j] ), n2 = range_rows( r2[j] ), m = n1 + n2;
+            uint2* ent = tab + (e0 + j) * stride;
+            if (wide) ent[1] = make_uint2( 0u, 0u );                         // no second row
+            auto occurrence = [&](const uint32_t s) -> uint2 {               // row s of the entry: the occurrences of C in SA order, then those of rc(C)
+                return s < n1 ? canon_row( f.text, f.length, k, position( r1[j].x + s ), 0u )
+                              : canon_row( f.text, f.length, k, position( r2[j].x + (s - n1) ), 1u );
+            };
             if (c[j] == 1u)
-                tab[e0 + j] = n1 ? canon_row( f.text, f.length, k, position( r1[j].x ), 0u ) : canon_row( f.text, f.length, k, position( r2[j].x ), 1u );
+            {
+                ent[0] = occurrence( 0u );
+                if (m == 2u) ent[1] = occurrence( 1u );
+            }
             else if (c[j] >= 2u)
             {
                 const uint32_t slots = c[j] == 2u ? 4u : 8u;
                 const uint32_t idx4  = c[j] == 2u ? 2u * tot_large + ga++ : 2u * gb++;
                 uint2* g = side + 4ull * idx4;
-                for (uint32_t s = 0; s < slots; ++s)
-                {
-                    uint2 v = make_uint2( 0u, DTAB_MARK );
-                    if (s < n1)     v = canon_row( f.text, f.length, k, position( r1[j].x + s ), 0u );
-                    else if (s < m) v = canon_row( f.text, f.length, k, position( r2[j].x + (s - n1) ), 1u );
-                    g[s] = v;
-                }
-                tab[e0 + j] = make_uint2( DTAB_MARK | idx4, DTAB_MARK | m );
+                for (uint32_t s = 0; s < slots; ++s) g[s] = s < m ? occurrence( s ) : make_uint2( 0u, DTAB_MARK );
+                ent[0] = make_uint2( DTAB_MARK | idx4, DTAB_MARK | m );
             }
-            else tab[e0 + j] = m ? make_uint2( 0u, 1u ) : make_uint2( 1u, 0u );          // heavy : empty
+            else ent[0] = m ? make_uint2( 0u, 1u ) : make_uint2( 1u, 0u );             // heavy : empty
         }
     }
 }
 
 // the canonical table of k-mers from the plain table of (k-1)-mers the handle keeps (idx->ktab)
-static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hipStream_t stream)
+static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, const bool wide, hipStream_t stream)
 {
     const uint32_t length = idx->view.length;
     if ((uint64_t)length + 2u > DTAB_MARK) { set_error( "canonical table: the text is too long for the position marker" ); return NVBIO_ERR_UNSUPPORTED; }
@@ -176,11 +182,12 @@ static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hi
     const dim3 grid( n_tiles < 256u * 64u ? n_tiles : 256u * 64u ), block( 256 );
     uint2* tab = nullptr; uint32_t* cnt = nullptr; void* temp = nullptr; uint2* side = nullptr;
     size_t temp_bytes = 0;
-    if (hipMalloc( (void**)&tab, entries * sizeof(uint2) ) != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    const uint64_t tab_bytes = entries * sizeof(uint2) * (wide ? 2u : 1u);
+    if (hipMalloc( (void**)&tab, tab_bytes ) != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: out of device memory" ); return NVBIO_ERR_NOMEM; }
     if (hipMalloc( (void**)&cnt, 4ull * n_tiles * sizeof(uint32_t) ) != hipSuccess) { (void)hipGetLastError(); (void)hipFree( tab ); set_error( "canonical table: out of device memory" ); return NVBIO_ERR_NOMEM; }
     uint32_t *cs = cnt, *cl = cnt + n_tiles, *os = cnt + 2ull * n_tiles, *ol = cnt + 3ull * n_tiles;
     const DevIndex f = idx->dev();
-    hipLaunchKernelGGL( fm_ctab_count_kernel, grid, block, 0, stream, f, k, tab, entries, n_tiles, cs, cl );
+    hipLaunchKernelGGL( fm_ctab_count_kernel, grid, block, 0, stream, f, k, wide ? 1u : 0u, tab, entries, n_tiles, cs, cl );
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( nullptr, temp_bytes, cs, os, (int)n_tiles, stream );
     if (e == hipSuccess) e = hipMalloc( &temp, temp_bytes ? temp_bytes : 16 );
@@ -200,14 +207,14 @@ static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hi
     if (st == NVBIO_OK && hipMalloc( (void**)&side, (units ? units : 1u) * 32ull ) != hipSuccess) { (void)hipGetLastError(); set_error( "canonical table: out of device memory" ); st = NVBIO_ERR_NOMEM; }
     if (st == NVBIO_OK)
     {
-        hipLaunchKernelGGL( fm_ctab_fill_kernel, grid, block, 0, stream, f, k, tab, entries, n_tiles, (const uint32_t*)os, (const uint32_t*)ol, tot_large, side );
+        hipLaunchKernelGGL( fm_ctab_fill_kernel, grid, block, 0, stream, f, k, wide ? 1u : 0u, tab, entries, n_tiles, (const uint32_t*)os, (const uint32_t*)ol, tot_large, side );
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize( stream ) != hipSuccess) { set_error( "canonical table: fill pass failed" ); st = NVBIO_ERR_HIP; }
     }
     (void)hipFree( cnt );
     if (temp) (void)hipFree( temp );
     if (st != NVBIO_OK) { (void)hipFree( tab ); if (side) (void)hipFree( side ); return st; }
-    idx->ctab = tab; idx->cside = side; idx->ckmer = k;
-    idx->owned_bytes += entries * sizeof(uint2) + (units ? units : 1u) * 32ull;
+    idx->ctab = tab; idx->cside = side; idx->ckmer = k; idx->cwide = wide ? 1u : 0u;
+    idx->owned_bytes += tab_bytes + (units ? units : 1u) * 32ull;
     return NVBIO_OK;
 }
 
@@ -219,7 +226,8 @@ static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, hi
 // (plain table + rank steps + finish on the text) inside the kernel; what ends on several rows goes to that strand's residual
 // list: ranges / ids [0, cap) forward, [cap, 2 cap) reverse; counts[1], counts[2].
 // ---------------------------------------------------------------------------------------------
-template <int BITS, bool COUNT>
+// WIDE: 16-byte entries (NVBIO_FM_TABLE_CANONICAL_WIDE): a k-mer with TWO occurrences has both rows in its entry, groups start at three
+template <int BITS, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256)
 fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, const uint32_t read_len, const uint32_t inline_max,
                     uint64_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_counts, uint2* __restrict__ res_ranges,
@@ -235,16 +243,24 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
     DevIndex fplain = f; fplain.dtab = nullptr; fplain.dkmer = 0;            // the fallback searches use the plain table only
 
     auto seed_begin = [&](const uint32_t rid) -> uint32_t { return (q.offsets ? q.offsets[rid] : rid * q.stride) + j * q.interval; };
-    auto entry_of = [&](const uint64_t V, uint32_t& qo) -> uint2 {
+    auto entry_of = [&](const uint64_t V, uint32_t& qo) -> uint4 {
         const uint64_t key = V >> (2u * r);
         qo = (uint32_t)(key >> k) & 1u;
-        return load_table_entry( f.ctab, canon_index( qo ? canon_revcomp( key, k ) : key, k ), true );
+        const uint64_t idx = canon_index( qo ? canon_revcomp( key, k ) : key, k );
+        if (WIDE)
+        {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v v = __builtin_nontemporal_load( (const u4v*)f.ctab + idx );
+            return make_uint4( v.x, v.y, v.z, v.w );
+        }
+        const uint2 e = load_table_entry( f.ctab, idx, true );
+        return make_uint4( e.x, e.y, 0u, 0u );
     };
 
     uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= tl.n_tiles) return;
     SeedWords W = { 0, 0, 0, 0, 0 }; uint32_t w_begin = 0; bool w_valid = false;
-    uint64_t V = 0; uint2 e = make_uint2( 1u, 0u ); bool e_valid = false; uint32_t qo = 0;
+    uint64_t V = 0; uint4 e = make_uint4( 1u, 0u, 0u, 0u ); bool e_valid = false; uint32_t qo = 0;
     {
         const uint32_t rid = tile * tl.rpt + lr;
         if (lane_ok && rid < tl.reads)
@@ -274,7 +290,7 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
             if (m > 4u) { q2 = g4[2]; q3 = g4[3]; }
         }
         // ---- stage 2 for the next tile ----
-        uint64_t Vn = 0; uint2 en = make_uint2( 1u, 0u ); bool en_valid = false; uint32_t qon = 0;
+        uint64_t Vn = 0; uint4 en = make_uint4( 1u, 0u, 0u, 0u ); bool en_valid = false; uint32_t qon = 0;
         if (w_valid)
         {
             en_valid = seed_bits_from_words<BITS>( W, w_begin, len, false, false, Vn );
@@ -308,7 +324,7 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
                     ++hits[s];
                 }
         };
-        if (is_one) row( e.x, e.y );
+        if (is_one) { row( e.x, e.y ); if (WIDE && e.w >= DTAB_MARK) row( e.z, e.w ); }
         else if (is_group)
         {
 #define NVB_CROW(jj, P, C) if ((jj) < m) row( (P), (C) );

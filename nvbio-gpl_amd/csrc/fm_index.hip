@@ -40,6 +40,7 @@ struct FMIndexImpl
     uint2*               ctab;        // owned, optional (NVBIO_FM_TABLE_CANONICAL, instead of dtab): the two-strand table (fm_canon_inl.h)
     uint2*               cside;       // owned: its groups
     uint32_t             ckmer;
+    uint32_t             cwide;       // its entries are 16 bytes (two rows)
     uint32_t             table_flags; // NVBIO_FM_TABLE_* of the build
     bool                 owns_arrays; // bwt_occ / ssa allocated by nvbio_fm_index_build
     uint64_t             owned_bytes;
@@ -1170,7 +1171,7 @@ static nvbio_status build_canonical_tables(FMIndexImpl* idx, uint32_t k, hipStre
     if (!ok) { (void)hipFree( a ); set_error( "k-mer table build failed" ); return NVBIO_ERR_HIP; }
     idx->ktab = a; idx->kmer = kk;
     idx->owned_bytes += entries * sizeof(uint2);
-    const nvbio_status st = build_canonical_table( idx, k, stream );
+    const nvbio_status st = build_canonical_table( idx, k, (idx->table_flags & NVBIO_FM_TABLE_CANONICAL_WIDE) != 0, stream );
     if (st != NVBIO_OK) { (void)hipFree( a ); idx->ktab = nullptr; idx->kmer = 0; }
     return st;
 }
@@ -1178,10 +1179,10 @@ static nvbio_status build_canonical_tables(FMIndexImpl* idx, uint32_t k, hipStre
 static nvbio_status build_kmer_table(FMIndexImpl* idx, uint32_t k, hipStream_t stream)
 {
     idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0;
-    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0;
+    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0; idx->cwide = 0;
     if (k == 0) return NVBIO_OK;
     const bool direct = idx->text && idx->view.ssa_dev && idx->view.sa_int == 1 && k >= 2 && !(idx->table_flags & NVBIO_FM_TABLE_NO_DIRECT);
-    if (idx->table_flags & NVBIO_FM_TABLE_CANONICAL)
+    if (idx->table_flags & (NVBIO_FM_TABLE_CANONICAL | NVBIO_FM_TABLE_CANONICAL_WIDE))
     {
         if (!direct || (k & 1u) == 0u || k < 3u)
         {
@@ -1236,7 +1237,7 @@ nvbio_status fm_index_adopt(const nvbio_fm_index_view* view, int device, uint32_
     if (!idx) { set_error( "out of host memory" ); return NVBIO_ERR_NOMEM; }
     idx->device = device; idx->view = *view; idx->ktab = nullptr; idx->kmer = 0; idx->dtab = nullptr; idx->dkmer = 0; idx->isa = nullptr; idx->text = nullptr;
     idx->side = nullptr; idx->dmark = 0xFFFFFFFFu; idx->dctx = 0; idx->table_flags = table_flags;
-    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0;
+    idx->ctab = nullptr; idx->cside = nullptr; idx->ckmer = 0; idx->cwide = 0;
     if (idx->view.sa_int == 0) idx->view.sa_int = 16;
     idx->owns_arrays = owns; idx->owned_bytes = owns ? (view->bwt_occ_words + view->ssa_words) * 4ull : 0ull;
     idx->isa = isa; idx->text = text;
@@ -1734,12 +1735,14 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     // flags bits 8..11: a seed with up to that many hits on a strand leaves them all as keys (0/1: only one-hit seeds do)
     uint32_t inline_max = (flags >> 8) & 15u;
     inline_max = inline_max < 1u ? 1u : (inline_max > CTAB_INLINE ? CTAB_INLINE : inline_max);
-#define NVB_LAUNCH_SB(BITS, CNT) hipLaunchKernelGGL( (fm_seed_both_kernel<BITS,CNT>), grid, block, 0, s, f, q, L.tl, read_len, inline_max, tile_keys, tile_counts, \
+#define NVB_LAUNCH_SB(BITS, CNT) if (idx->cwide) NVB_LAUNCH_SBW( BITS, CNT, true ); else NVB_LAUNCH_SBW( BITS, CNT, false )
+#define NVB_LAUNCH_SBW(BITS, CNT, W) hipLaunchKernelGGL( (fm_seed_both_kernel<BITS,CNT,W>), grid, block, 0, s, f, q, L.tl, read_len, inline_max, tile_keys, tile_counts, \
                                     (uint2*)residual_ranges_dev, residual_ids_dev, residual_capacity, (unsigned int*)counts_dev,                         \
                                     CNT ? (unsigned long long*)(counts_dev + 4) : (unsigned long long*)nullptr )
     if (seeds->symbol_bits == 2) { if (count) NVB_LAUNCH_SB( 2, true ); else NVB_LAUNCH_SB( 2, false ); }
     else                         { if (count) NVB_LAUNCH_SB( 4, true ); else NVB_LAUNCH_SB( 4, false ); }
 #undef NVB_LAUNCH_SB
+#undef NVB_LAUNCH_SBW
     hipError_t e = hipGetLastError();
     size_t scan_bytes = L.scan_bytes;
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );

@@ -87,9 +87,9 @@ int main(int argc, char** argv)
 
         // ---- index: built on the GPU, full suffix array + direct table ----
         const auto tb0 = std::chrono::steady_clock::now();
-        // (odd k: the canonical table, one seed pass for both strands; --no-canonical or even k: the direct table, one pass per strand)
+        // (odd k: the canonical table with 16-byte entries, one seed pass for both strands; --no-canonical or even k: the direct table, one pass per strand)
         canonical = canonical && (kmer & 1u) && kmer >= 3u && kmer <= 22u && 22u - kmer <= 7u;      // the canonical table serves seeds of k .. k + 7 symbols
-        fm_index fmi( d_genome.data(), N, 0, kmer, 0, /*sa_int*/ 1, canonical ? (uint32_t)NVBIO_FM_TABLE_CANONICAL : 0u );
+        fm_index fmi( d_genome.data(), N, 0, kmer, 0, /*sa_int*/ 1, canonical ? (uint32_t)NVBIO_FM_TABLE_CANONICAL_WIDE : 0u );
         check_hip( hipDeviceSynchronize(), "sync" );
         const double build_s = std::chrono::duration<double>( std::chrono::steady_clock::now() - tb0 ).count();
 

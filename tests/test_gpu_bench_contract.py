@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-canonical"]])
+@pytest.mark.parametrize("extra", [[], ["--no-wide-table"], ["--no-canonical"]])
 def test_bench_json_contract(extra):
     """the default configuration (canonical table, one seed pass for both strands) and the per-strand one over the direct table"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ref-len", "4e6", "--reads", "40000", "--steps", "2",
@@ -27,8 +27,9 @@ def test_bench_json_contract(extra):
     assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["config"]["workload"] == "custom" and d["config"]["reads_per_gpu"] == 40000
     assert abs(d["value"] - 40000 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
-    assert d["config"]["canonical_table"] is (not extra) and d["roofline"]["launches_per_step"] == (2 if extra else 1)
-    assert ("match_both" in d["stage_ms"]) == (not extra)
+    canon = extra != ["--no-canonical"]
+    assert d["config"]["canonical_table"] is canon and d["config"]["wide_entries"] is (not extra)
+    assert d["roofline"]["launches_per_step"] == (1 if canon else 2) and ("match_both" in d["stage_ms"]) == canon
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k

@@ -1,5 +1,5 @@
-"""GPU, full size: the configuration bench.py times since round 2 -- 3 Gbp reference, the CANONICAL k = 17 table (2^33 entries, 64 GiB:
-a k-mer and its reverse complement share an entry), full suffix array, ONE seed pass for both strands -- checked against the
+"""GPU, full size: the configuration bench.py times since round 2 -- 3 Gbp reference, the CANONICAL k = 17 table (2^33 entries of 16 bytes,
+128 GiB: a k-mer and its reverse complement share an entry that holds up to two occurrences), full suffix array, ONE seed pass for both strands -- checked against the
 reference's algorithm run by the plain operators on the same index (match() without any table + locate(), which the small-scale tests
 pin on the reference's own outputs).  The shape of nvbio-test/fmindex_test.cu:603-709: match -> locate -> compare, over 1 M reads x 9
 seed windows x 2 strands.  (Its own module: the direct-table handle of test_gpu_fullsize.py has to be released first.)"""
@@ -17,7 +17,7 @@ def headline(amd):
     n = 3_000_000_000
     genome = bench.make_reference(n, "cuda:0", seed=1234)
     try:
-        fmi = amd.FMIndex.build(genome, n, kmer_len=17, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL)
+        fmi = amd.FMIndex.build(genome, n, kmer_len=17, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL_WIDE)
     except amd.NvbioError as e:
         pytest.skip("the k = 17 canonical table does not fit on this device: %s" % e)
     R, M = 1_000_000, 150
@@ -42,7 +42,7 @@ def test_two_strand_seed_pass_equals_reference_algorithm(amd, headline):
     spr = (M - L) // S + 1
     rpt = 64 // spr
     qs = amd.PackedStringSet(h["reads4"], 4, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
-    assert fmi.canonical and fmi.view().sa_int == 1 and 100e9 < fmi.device_bytes() < 150e9     # 32 + 64 GiB of tables, full SA
+    assert fmi.canonical and fmi.view().sa_int == 1 and 170e9 < fmi.device_bytes() < 200e9     # 32 + 128 GiB of tables, full SA
     sid = torch.arange(R * spr, device="cuda:0", dtype=torch.int64)
     b = fmi.match_seed_diagonals_both(qs, M)
     c = [int(v) for v in b["counts"][:4].cpu()]

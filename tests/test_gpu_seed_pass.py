@@ -195,8 +195,9 @@ def _tile_major(keys_f, keys_r, spr):
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
+@pytest.mark.parametrize("wide", [False, True])            # 8-byte entries (one row in line) / 16-byte entries (two)
 @pytest.mark.parametrize("k", [5, 9, 11, 15])
-def test_two_strand_pass_equals_the_per_strand_operators(amd, orc, k):
+def test_two_strand_pass_equals_the_per_strand_operators(amd, orc, k, wide):
     """nvbio_fm_match_seed_diagonals_both over the canonical table (a k-mer and its reverse complement share an entry) against match() of
     every seed and of its reverse complement by the oracle: single-occurrence entries of either orientation, groups that mix both, k-mers
     with more than 8 occurrences (k = 5: every one) and repeats longer than the seed (the per-strand fallback inside the kernel, residual
@@ -209,7 +210,7 @@ def test_two_strand_pass_equals_the_per_strand_operators(amd, orc, k):
     text[160000:160300] = 3 - text[5000:5300][::-1]
     text[170000:170200] = 3 - text[100000:100200][::-1]
     hidx = orc.build_index(text)
-    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL_WIDE if wide else amd.FM_TABLE_CANONICAL)
     assert fmi.canonical
     R, M = 3000, 150
     reads = _reads(rng, text, R, M)
