@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.2
 SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
 TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
 SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"            # the per-strand pass (--no-canonical)
-SEED_BOTH_KERNEL_TAG = "fm_seed_both_kernel<4, false>"   # the two-strand pass over the canonical table (default)
+SEED_BOTH_KERNEL_TAG = "fm_seed_both_kernel<4, false, %s>"   # the two-strand pass over the canonical table (default): % wide entries
 
 
 def log(msg):
@@ -327,7 +327,7 @@ def main():
     use_fused = bool(use_direct and params.fused_seed_pass)
     use_both = bool(use_fused and fmi.canonical)                 # one launch serves both strands
     launches = 1 if use_both else 2
-    seed_tag = SEED_BOTH_KERNEL_TAG if use_both else SEED_KERNEL_TAG
+    seed_tag = (SEED_BOTH_KERNEL_TAG % ("false" if args.no_wide_table else "true")) if use_both else SEED_KERNEL_TAG
     # (1) bytes the TIMED launch has to move, at the 64-byte sector granularity of the fabric (outside the timed region, by the
     #     kernel's accounting instantiation, NVBIO_FM_COUNT_SECTORS): every gather of a search -- direct-table entry, group of a
     #     2..7-occurrence k-mer, bwt_occ records of the rank steps that are left, SA word, text words -- counted as one sector

@@ -67,7 +67,7 @@ for sub in ("sq", "tcc", "utcl", "ea"):
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 
 # the seed-pass kernel of the timed region: the direct (match + locate fused) instantiation when the run used it
-key = ([k for k in pmc if "fm_seed_both_kernel<4, false>" in k] or [k for k in pmc if "fm_seed_pipe_kernel<4>" in k] or [k for k in pmc if "fm_seed_tiles_kernel<4, false>" in k]
+key = ([k for k in pmc if "fm_seed_both_kernel<4, false, true>" in k] or [k for k in pmc if "fm_seed_both_kernel<4, false, false>" in k] or [k for k in pmc if "fm_seed_pipe_kernel<4>" in k] or [k for k in pmc if "fm_seed_tiles_kernel<4, false>" in k]
        or [k for k in pmc if "fm_seed_diagonals_kernel<4>" in k] or [k for k in pmc if "fm_match_kernel<4, false, true, true>" in k]
        or [k for k in pmc if "fm_match_kernel<4, false, true" in k])
 if key:
@@ -80,7 +80,8 @@ if key:
     cfg = bench["config"]
     json.dump({"tag": tag, "ref_len": cfg["ref_len"], "reads": cfg["reads_per_gpu"], "kmer": cfg["kmer_table"],
                "sa_int": cfg.get("sa_int", 16), "direct": bool(cfg.get("match_direct", False)), "fused": bool(cfg.get("fused_seed_pass", False)), "kernel": key[0][:80],
-               "kernel_tag": ("fm_seed_both_kernel<4, false>" if "fm_seed_both_kernel<4, false>" in key[0] else
+               "kernel_tag": ("fm_seed_both_kernel<4, false, true>" if "fm_seed_both_kernel<4, false, true>" in key[0] else
+                              "fm_seed_both_kernel<4, false, false>" if "fm_seed_both_kernel<4, false, false>" in key[0] else
                               "fm_seed_pipe_kernel<4>" if "fm_seed_pipe_kernel<4>" in key[0] else key[0].split("(")[0].replace("void nvbio_amd::", "")),
                "match_hbm_bytes_per_launch": hbm, "fetch_KiB": m.get("FETCH_SIZE_KiB_mean"),
                "write_KiB": m.get("WRITE_SIZE_KiB_mean"),
