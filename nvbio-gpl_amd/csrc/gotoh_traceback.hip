@@ -57,8 +57,8 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
     const uint32_t fl    = b.flags ? b.flags[job] : 0u;
     const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
     const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
-    // band_off (a band-15 launch over jobs of a band-31 batch, see the narrow-band route at the entry point): this job's band covers
-    // columns [off, off + 15) of the band the batch asked for -- the window begins `off` symbols later, sink and source move back by it
+    // band_off (a band-15 / band-7 launch over jobs of a band-31 batch, see the narrow-band route at the entry point): this job's band covers
+    // columns [off, off + BAND) of the band the batch asked for -- the window begins `off` symbols later, sink and source move back by it
     const uint32_t off   = band_off ? band_off[job] : 0u;
     const uint32_t tb    = b.win_begin[job] + off;
     const uint32_t N     = b.win_end[job] - tb;
@@ -388,7 +388,12 @@ ungapped_traceback_kernel(const BatchDev b, const SchemeDev sc, const int32_t* _
         {
             const int32_t a = -best;
             const int32_t G = a < gap_open_min ? 0 : (a - gap_open_min) / gap_ext_min + 1;
-            if (G <= 7)
+            if (G <= 3)                                                    // a band of 7 (one short indel and at most one mismatch)
+            {
+                code = 3;
+                band_off[job] = (uint8_t)(entry > 3u ? (entry - 3u < 24u ? entry - 3u : 24u) : 0u);
+            }
+            else if (G <= 7)
             {
                 code = 2;
                 band_off[job] = (uint8_t)(entry > 7u ? (entry - 7u < 16u ? entry - 7u : 16u) : 0u);
@@ -530,12 +535,14 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 
     // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
     const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
-    uint8_t*  need_dp   = nullptr;      // [n] flags: 0 settled, 1 the DP, 2 the DP over a band of 15 (band 31 only)
+    uint8_t*  need_dp   = nullptr;      // [n] flags: 0 settled, 1 the DP, 2 / 3 the DP over a band of 15 / 7 (band 31 only)
     uint32_t* job_list  = nullptr;      // [n] compacted job ids
     uint32_t* job_count = nullptr;      // [1]
-    uint8_t*  band_off  = nullptr;      // [n] narrow-band route: first column of the job's band of 15
-    uint32_t* job_list2 = nullptr;      // [n], [1]: its jobs
+    uint8_t*  band_off  = nullptr;      // [n] narrow-band route: first column of the job's band of 15 / 7
+    uint32_t* job_list2 = nullptr;      // [n], [1]: the jobs of the band-15 route
     uint32_t* job_count2 = nullptr;
+    uint32_t* job_list3 = nullptr;      // ... and of the band-7 route
+    uint32_t* job_count3 = nullptr;
     // the narrow-band route applies to nvBowtie's end-to-end mode (see ungapped_traceback_kernel)
     const int32_t go_min = -(sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go), ge_min = -(sc.pat_ge > sc.txt_ge ? sc.pat_ge : sc.txt_ge);
     const bool narrow = band == 31 && type == NVBIO_SEMI_GLOBAL && sc.match == 0 && sc.mm_min >= 0 && sc.mm_max >= 0 && plain_gotoh( sc ) &&
@@ -551,7 +558,7 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, 2u * (flags_bytes + list_bytes + 256u) + sel_bytes, s ) != hipSuccess)
+        if (hipMallocAsync( &aux, 2u * (flags_bytes + list_bytes + 256u) + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             set_error( "banded traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
@@ -562,7 +569,9 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         band_off   = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
         job_list2  = (uint32_t*)(band_off + flags_bytes);
         job_count2 = (uint32_t*)(band_off + flags_bytes + list_bytes);
-        sel_temp   = (uint8_t*)aux + 2u * (flags_bytes + list_bytes + 256u);
+        job_list3  = (uint32_t*)((uint8_t*)aux + 2u * (flags_bytes + list_bytes + 256u));
+        job_count3 = (uint32_t*)((uint8_t*)job_list3 + list_bytes);
+        sel_temp   = (uint8_t*)aux + 2u * (flags_bytes + list_bytes + 256u) + list_bytes + 256u;
         nvbio_status st1;
 #define NVB_BAND(B) st1 = launch_ungapped_type<B>( type, b, sc, batch->read_bits, batch->text_bits, scores_dev, (const uint2*)sinks_dev, \
                                                    (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp,             \
@@ -581,6 +590,8 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
         hipcub::TransformInputIterator<uint8_t, IsCode<2>, const uint8_t*> is_narrow( need_dp, IsCode<2>() );
         hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_full, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess && narrow) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_narrow, job_list2, job_count2, (int)b.n, s );
+        hipcub::TransformInputIterator<uint8_t, IsCode<3>, const uint8_t*> is_narrow7( need_dp, IsCode<3>() );
+        if (e == hipSuccess && narrow) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_narrow7, job_list3, job_count3, (int)b.n, s );
         if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
@@ -640,6 +651,13 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
             const uint32_t jobs = (uint32_t)((b.n - begin) < cap2 ? (b.n - begin) : cap2);
             st = launch_type<15>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, job_list2, job_count2, dirs, scores_dev,
                                   (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s, band_off );
+        }
+        const uint64_t cap3 = cap_jobs * per_job / ((uint64_t)b.max_read_len * row_bytes( 7 ));
+        for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap3)
+        {
+            const uint32_t jobs = (uint32_t)((b.n - begin) < cap3 ? (b.n - begin) : cap3);
+            st = launch_type<7>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, job_list3, job_count3, dirs, scores_dev,
+                                 (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s, band_off );
         }
     }
     if (owned) (void)hipFreeAsync( owned, s );
