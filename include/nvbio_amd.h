@@ -324,7 +324,9 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
  *                                       reads: a tile's forward keys in seed order, then its reverse-strand keys in seed order
  *   residual_*_dev[0 .. counts_dev[1])                              forward-strand searches that ended on several rows (range, seed id)
  *   residual_*_dev[residual_capacity .. + counts_dev[2])            the same for the reverse strand
- * keys_dev: 2 * seeds->n entries; residual arrays: 2 * residual_capacity entries, residual_capacity >= seeds->n.  counts_dev: 4 uint32
+ * keys_dev: nvbio_fm_match_seed_diagonals_both_keys_capacity() entries (128 per tile of 64 / seeds_per_string reads: with
+ * NVBIO_FM_INLINE_HITS a seed can leave several keys, a tile at most 64 per strand -- slightly more than 2 * seeds->n when 64 is not a
+ * multiple of seeds_per_string); residual arrays: 2 * residual_capacity entries, residual_capacity >= seeds->n.  counts_dev: 4 uint32
  * (6, 8-byte aligned, with NVBIO_FM_COUNT_SECTORS: the distinct 64-byte sectors gathered from the index as a uint64 at counts_dev + 4).
  * Seeds: packed 2 or 4 bits, fixed length in [kmer_len, kmer_len + 7], at most 64 per read.  flags: NVBIO_FM_COUNT_SECTORS, the grid
  * knob (bits 16..31) of nvbio_fm_match_seed_diagonals, and NVBIO_FM_INLINE_HITS(h), h in 2..4: a search that ends on up to h rows leaves
@@ -332,6 +334,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
  * FMIndexFilter's scan + locate would add for it, without the trip; only larger ranges reach the residual lists. */
 #define NVBIO_FM_INLINE_HITS(h) (((uint32_t)(h) & 15u) << 8)
 nvbio_status nvbio_fm_match_seed_diagonals_both_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes);
+nvbio_status nvbio_fm_match_seed_diagonals_both_keys_capacity(const nvbio_string_set* seeds, uint64_t* n_keys);
 nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                                 uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
                                                 uint32_t residual_capacity, uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes,

@@ -400,7 +400,9 @@ class FMIndex:
         qs = seeds.c_struct()
         if buffers.get("n") != n or buffers.get("spr") != seeds.seeds_per_string:
             buffers["n"], buffers["spr"] = n, seeds.seeds_per_string
-            buffers["keys"] = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+            cap = ctypes.c_uint64(0)
+            _check(lib().nvbio_fm_match_seed_diagonals_both_keys_capacity(ctypes.byref(qs), ctypes.byref(cap)))
+            buffers["keys"] = torch.empty(max(int(cap.value), 1), dtype=torch.int64, device=self.device)
             buffers["ranges"] = torch.empty((2 * n, 2), dtype=torch.int32, device=self.device)
             buffers["ids"] = torch.empty(2 * n, dtype=torch.int32, device=self.device)
             buffers["counts"] = torch.empty(6, dtype=torch.int32, device=self.device)     # [4:6]: FM_COUNT_SECTORS' uint64

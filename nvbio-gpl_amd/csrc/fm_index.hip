@@ -1687,6 +1687,14 @@ nvbio_status nvbio_fm_match_seed_diagonals_both_temp_bytes(const nvbio_string_se
     return NVBIO_OK;
 }
 
+nvbio_status nvbio_fm_match_seed_diagonals_both_keys_capacity(const nvbio_string_set* seeds, uint64_t* n_keys)
+{
+    NVB_REQUIRE( n_keys != nullptr, "n_keys is NULL" );
+    SeedScratch L; NVB_CHECK( seed_both_layout( seeds, &L ) );
+    *n_keys = 128ull * L.tl.n_tiles;                            // a tile of 64 / seeds_per_string reads can leave up to 64 keys per strand
+    return NVBIO_OK;
+}
+
 nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                                 uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
                                                 uint32_t residual_capacity, uint32_t* counts_dev, void* temp_dev, uint64_t temp_bytes,

@@ -101,7 +101,7 @@ int main(int argc, char** argv)
         if (canonical) both.reset( new SeedPassBoth( seeds ) );
         else { pass0.reset( new SeedPass( seeds ) ); pass1.reset( new SeedPass( seeds ) ); }
         SeedPass* pass[2] = { pass0.get(), pass1.get() };
-        device_vector<uint64_t> keys( 2ull * n_seeds ), best( R );
+        device_vector<uint64_t> keys( 2ull * n_seeds + 128ull * (R / (spr <= 64u ? 64u / spr : 1u) + 1u) ), best( R );   // room for the two-strand pass's 128 keys per tile
         device_vector<uint32_t> offs( R + 1 ), rid, wb, we, n_unique( 1 );
         device_vector<uint8_t>  flags, rc( R );
         device_vector<int32_t>  scores, best_score( R );

@@ -218,8 +218,9 @@ public:
     explicit SeedPassBoth(const string_set& seeds) : m_seeds( seeds )
     {
         const size_t n = seeds.size();
-        m_keys.resize( 2 * n ); m_ranges.resize( 2 * n ); m_ids.resize( 2 * n ); m_counts.resize( 6 );
-        uint64_t bytes = 0;
+        uint64_t bytes = 0, cap = 0;
+        check( nvbio_fm_match_seed_diagonals_both_keys_capacity( &m_seeds.c, &cap ) );
+        m_keys.resize( cap ? cap : 1 ); m_ranges.resize( 2 * n ); m_ids.resize( 2 * n ); m_counts.resize( 6 );
         check( nvbio_fm_match_seed_diagonals_both_temp_bytes( &m_seeds.c, &bytes ) );
         m_temp.resize( bytes );
     }

@@ -175,6 +175,7 @@ def _run_both(amd, fmi, packed, bits, R, M, L, S, grid_blocks=0, flags=0, inline
     qs = amd.PackedStringSet(packed, bits, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
     b = fmi.match_seed_diagonals_both(qs, M, flags=flags, grid_blocks=grid_blocks, inline_hits=inline_hits)
     c = [int(v) for v in b["counts"][:4].cpu().numpy()]
+    assert b["keys"].numel() >= 128 * -(-R // (64 // spr)) and c[0] <= b["keys"].numel()      # 128 key slots per tile of whole reads
     keys = b["keys"][:c[0]].cpu().numpy()
     n = R * spr
     res = []
