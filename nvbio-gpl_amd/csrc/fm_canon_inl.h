@@ -26,6 +26,11 @@
 // A window whose last k symbols are W looks up C = W (qo = 0) or C = rc(W) (qo = 1).  Row (p, o): it is an occurrence of W if o = qo and of
 // rc(W) otherwise; qo = 0 compares `before` with A reversed (the seed's remaining symbols in scan order), qo = 1 compares `after` with their
 // complement (rc(A) follows C = rc(W)).  A forward hit needs p >= r, a reverse one p + len <= length.
+//
+// Entries of 16 bytes (NVBIO_FM_TABLE_CANONICAL_WIDE, 128 GiB at k = 17): two slots.  Slot 0 is as above; a k-mer with exactly TWO
+// occurrences has the second row in slot 1 (hi >= MARK there; (0, 0) otherwise), and groups begin at three occurrences (3..4 rows in 32
+// bytes, 5..8 in 64).  On a 3 Gbp text one seed window in four has a k-mer that occurs once more somewhere, in either orientation:
+// 1.25 gathered sectors per window with 8-byte entries, 1.04 with 16-byte ones.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t CTAB_FLANK    = 7u;            // symbols stored on each side of an occurrence: seeds of up to k + 7 symbols
 constexpr uint32_t CTAB_ROWS_MAX = 8u;
