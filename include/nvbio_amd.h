@@ -710,6 +710,17 @@ nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_align
                                           uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
                                           uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* The same for the linear-gap SmithWatermanAligner (and so for the EditDistanceAligner's scheme (0, -1, -1, -1)):
+ * aln::banded_alignment_traceback<band, MAX_PATTERN_LEN, CHECKPOINTS>( SmithWatermanAligner<type>, ... ) (nvbio/alignment/banded_inl.h:354-417
+ * over sw/sw_banded_inl.h:281-520 and its walk, :741-797), deletion and insertion costs unequal or not.  As the reference's code behaves,
+ * the direction vectors of this aligner carry no SINK (sw_banded_inl.h:420-468): a LOCAL walk does not stop where the score reaches 0
+ * but runs on to the first pattern row, so that source.y = 0 for every traced job. */
+nvbio_status nvbio_banded_sw_traceback(int device, uint32_t band, nvbio_alignment_type type,
+                                       const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                       int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                       uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                       uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
+
 /* Full-matrix Gotoh traceback: aln::alignment_traceback<..,CHECKPOINTS> / BatchedAlignmentTraceback
  * (nvbio/alignment/alignment_inl.h:355-517, gotoh/gotoh_inl.h:458-538,1573-1640; nvBowtie traceback_best,
  * traceback_inl.h:249-275) with nvBowtie's run-length Backtracker: outputs as nvbio_banded_gotoh_traceback, with

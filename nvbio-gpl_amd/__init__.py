@@ -711,9 +711,11 @@ class BatchedBandedAlignmentTraceback:
         cigars = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev)
         lens = torch.empty(n, dtype=torch.int32, device=dev)
         bs = batch.c_struct()
-        _check(lib().nvbio_banded_gotoh_traceback(
+        sw = getattr(self.aligner, "sw", None)                      # the linear-gap Smith-Waterman / edit-distance aligners
+        fn = lib().nvbio_banded_sw_traceback if sw is not None else lib().nvbio_banded_gotoh_traceback
+        _check(fn(
             FMIndex._dev_index(dev), ctypes.c_uint32(self.band_len), ctypes.c_int(self.aligner.type),
-            ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs), _ptr(scores), _ptr(sources), _ptr(sinks), _ptr(cigars),
+            ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c), ctypes.byref(bs), _ptr(scores), _ptr(sources), _ptr(sinks), _ptr(cigars),
             ctypes.c_uint32(cigar_stride), _ptr(lens), ctypes.c_uint32(TRACEBACK_SINKS_GIVEN if given else 0), _ptr(temp),
             ctypes.c_uint64(0 if temp is None else temp.numel() * temp.element_size()), _stream_ptr(dev)))
         return scores, sources, sinks, cigars, lens

@@ -90,7 +90,11 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
             else        cache_raw[j] = g;
         }
 
-        const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+        const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;             // F: the text advances alone
+        const int32_t I_o = sc.ins_go, I_e = sc.ins_ge;             // E: the pattern advances alone (= G for the Gotoh aligner; the
+                                                                    // Smith-Waterman aligner's insertion, sw_banded_inl.h:420-436)
+        // the Smith-Waterman aligner's direction vectors carry no SINK: its LOCAL walk runs on to the first row (sw_banded_inl.h:420-436,758-790)
+        const bool sink_marks = !sc.wide;
         const int32_t infimum = -32768 - max2( max2( G_o, G_e ), max2( sc.txt_go, sc.txt_ge ) );
         const int32_t V = sc.match;
 
@@ -155,17 +159,17 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
                 if (TYPE == NVBIO_LOCAL)
                 {
                     h = max2( h, 0 );
-                    if (h == 0) hdir = D_SINK;
+                    if (h == 0 && sink_marks) hdir = D_SINK;
                     row_key = max2( row_key, (h << 5) | j );
                 }
                 H[j] = h;
                 dw[j >> 3] |= (hdir | edir | fdir) << (4 * (j & 7));
 
                 // E for the next column and its direction (:507,560-565)
-                if (j == 0) { E = h + G_o; edir = D_SUB; }
+                if (j == 0) { E = h + I_o; edir = D_SUB; }
                 else
                 {
-                    const int32_t eleft = E + G_e, ediag = h + G_o;
+                    const int32_t eleft = E + I_e, ediag = h + I_o;
                     edir = eleft > ediag ? D_INS_EXT : D_SUB;
                     E = max2( ediag, eleft );
                 }
@@ -501,13 +505,17 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback_temp_bytes(const nvbio_alig
     return NVBIO_OK;
 }
 
-extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
-                                                     const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
-                                                     int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
-                                                     uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
-                                                     uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+// the banded traceback of both aligner families: `gotoh` or `sw` is given (the other NULL)
+static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_alignment_type type,
+                                          const nvbio_gotoh_scheme* gotoh, const nvbio_sw_scheme* sw, const nvbio_alignment_batch* batch,
+                                          int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                          uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                          uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
 {
-    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    NVB_REQUIRE( gotoh != nullptr || sw != nullptr, "scheme is NULL" );
+    nvbio_gotoh_scheme as_gotoh;                                 // the magnitudes of the scheme, for the int16 bound below
+    if (sw) as_gotoh = nvbio_gotoh_scheme{ sw->match, -sw->mismatch, -sw->mismatch, sw->deletion, sw->deletion, sw->insertion, sw->insertion };
+    const nvbio_gotoh_scheme* scheme = gotoh ? gotoh : &as_gotoh;
     BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
     if (b.n == 0) return NVBIO_OK;
     NVB_REQUIRE( band == 3 || band == 7 || band == 15 || band == 31, "band must be 3, 7, 15 or 31" );
@@ -531,10 +539,11 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
 
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    SchemeDev sc = scheme_dev( scheme );
+    SchemeDev sc = sw ? scheme_dev( sw, false ) : scheme_dev( gotoh );
 
     // ---- 1. scoring pass (the packed 16-bit kernel when the scheme allows) + 2. the ungapped shortcut ----------
-    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
+    // (the diagonal shortcut of a LOCAL job rests on the walk stopping at the first SINK cell: not for the Smith-Waterman aligner)
+    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK) && !(sw && type == NVBIO_LOCAL);
     uint8_t*  need_dp   = nullptr;      // [n] flags: 0 settled, 1 the DP, 2 / 3 the DP over a band of 15 / 7 (band 31 only)
     uint32_t* job_list  = nullptr;      // [n] compacted job ids
     uint32_t* job_count = nullptr;      // [1]
@@ -552,7 +561,8 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     if (shortcut)
     {
         if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
-            NVB_CHECK( nvbio_banded_gotoh_score( device, band, type, scheme, batch, scores_dev, sinks_dev, stream ) );
+            NVB_CHECK( sw ? nvbio_banded_sw_score( device, band, type, sw, batch, scores_dev, sinks_dev, stream )
+                          : nvbio_banded_gotoh_score( device, band, type, gotoh, batch, scores_dev, sinks_dev, stream ) );
         size_t sel_bytes = 0;
         hipcub::CountingInputIterator<uint32_t> ids( 0u );
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
@@ -663,4 +673,26 @@ extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, 
     if (owned) (void)hipFreeAsync( owned, s );
     if (aux)   (void)hipFreeAsync( aux, s );
     return st;
+}
+
+extern "C" nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
+                                                     const nvbio_gotoh_scheme* scheme, const nvbio_alignment_batch* batch,
+                                                     int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                     uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                     uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    return banded_traceback_impl( device, band, type, scheme, nullptr, batch, scores_dev, sources_dev, sinks_dev, cigars_dev, cigar_stride,
+                                  cigar_lens_dev, flags, temp_dev, temp_bytes, stream );
+}
+
+extern "C" nvbio_status nvbio_banded_sw_traceback(int device, uint32_t band, nvbio_alignment_type type,
+                                                  const nvbio_sw_scheme* scheme, const nvbio_alignment_batch* batch,
+                                                  int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                  uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                  uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    return banded_traceback_impl( device, band, type, nullptr, scheme, batch, scores_dev, sources_dev, sinks_dev, cigars_dev, cigar_stride,
+                                  cigar_lens_dev, flags, temp_dev, temp_bytes, stream );
 }

@@ -377,6 +377,14 @@ template <AlignmentType T, typename S>
 nvbio_status full_score(const SmithWatermanAligner<T,S>& a, int device, int tb, const nvbio_alignment_batch* b, uint32_t mp, uint32_t mt, const int32_t* ms,
                         int32_t* sc, nvbio_uint2* sk, void* temp, uint64_t temp_size, hipStream_t s)
 { const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_full_sw_score( device, (nvbio_alignment_type)T, tb, &f, b, mp, mt, ms, sc, sk, temp, temp_size, s ); }
+template <AlignmentType T, typename S>
+nvbio_status banded_traceback(const GotohAligner<T,S>& a, int device, uint32_t band, const nvbio_alignment_batch* b, int32_t* sc, nvbio_uint2* src, nvbio_uint2* sk,
+                              uint16_t* cig, uint32_t stride, uint32_t* lens, uint32_t flags, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_gotoh_scheme f = a.scheme.flat(); return nvbio_banded_gotoh_traceback( device, band, (nvbio_alignment_type)T, &f, b, sc, src, sk, cig, stride, lens, flags, temp, temp_size, s ); }
+template <AlignmentType T, typename S>
+nvbio_status banded_traceback(const SmithWatermanAligner<T,S>& a, int device, uint32_t band, const nvbio_alignment_batch* b, int32_t* sc, nvbio_uint2* src, nvbio_uint2* sk,
+                              uint16_t* cig, uint32_t stride, uint32_t* lens, uint32_t flags, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_banded_sw_traceback( device, band, (nvbio_alignment_type)T, &f, b, sc, src, sk, cig, stride, lens, flags, temp, temp_size, s ); }
 } // namespace detail
 
 struct AmdDeviceScheduler {};
@@ -497,11 +505,10 @@ struct BatchedBandedAlignmentTraceback
     static uint64_t max_temp_storage(uint32_t p, uint32_t t, uint32_t n) { return min_temp_storage( p, t, n ); }
     void enact(stream_type stream, uint64_t temp_size = 0u, uint8_t* temp = nullptr, int device = 0, hipStream_t s = 0)
     {
-        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
-        check( nvbio_banded_gotoh_traceback( device, BAND_LEN, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(),
-                                             stream.scores(), stream.sources(), stream.sinks(), stream.cigars(), stream.cigar_stride(),
-                                             stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
-                                             temp, temp_size, s ) );
+        check( detail::banded_traceback( stream.aligner(), device, BAND_LEN, &stream.batch(),
+                                         stream.scores(), stream.sources(), stream.sinks(), stream.cigars(), stream.cigar_stride(),
+                                         stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
+                                         temp, temp_size, s ) );
     }
 };
 

@@ -308,6 +308,19 @@ class Oracle:
             _p(sinks, _u32p), cigars.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cigar_stride), _p(lens, _u32p))
         return scores, sources, sinks, cigars, lens
 
+    def banded_sw_traceback(self, band, typ, sw, pat, txt, cap=4096):
+        """linear-gap Smith-Waterman aligner -> (traced, score, source, sink, cigar uint16[] in backtracking order)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sw = np.ascontiguousarray(np.asarray(sw, dtype=np.int32))
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        cig = np.zeros(cap, dtype=np.uint16); cl = ctypes.c_uint32()
+        ok = self.lib.orc_banded_sw_traceback(ctypes.c_uint32(band), ctypes.c_int(typ), _p(sw, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                              _p(txt, _u8p), ctypes.c_uint32(len(txt)), ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p),
+                                              cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap), ctypes.byref(cl))
+        assert cl.value <= cap
+        return ok, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), cig[:cl.value].copy()
+
     def finish_alignment(self, pat, txt, cigar, cigar_offset, cap=1024):
         """nvBowtie finish_alignment: (edit distance, MDS bytes) of a traced alignment"""
         pat, txt = _c8(pat), _c8(txt)
@@ -768,6 +781,24 @@ class Reference:
             ctypes.c_uint32(len(pat)), _p(txt, _u8p), ctypes.c_uint32(n_txt), ctypes.c_int32(SCORE_MIN),
             ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p), _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no),
             _p(clips, _u32p))
+        assert no.value <= cap
+        return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
+
+    def banded_sw_traceback(self, band, typ, sw, pat, txt, cap=4096):
+        """the reference's banded_alignment_traceback<BAND,1024,16> for SmithWatermanAligner<TYPE> with a recording backtracer
+        -> (n_clip_calls, score, source, sink, ops uint8[] in backtracking order, (clip_before, clip_after)); the text is handed over
+        followed by sentinel bytes (the checkpointed recomputation re-reads text[window_begin + j] unconditionally)"""
+        pat = _c8(pat)
+        n_txt = len(txt)
+        txt = np.ascontiguousarray(np.concatenate([np.asarray(txt, dtype=np.uint8), np.full(64, 255, dtype=np.uint8)]))
+        sw = np.ascontiguousarray(np.asarray(sw, dtype=np.int32))
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        ops = np.zeros(cap, dtype=np.uint8); clips = np.zeros(2, dtype=np.uint32)
+        no = ctypes.c_uint32()
+        r = self.lib.ref_banded_sw_traceback(ctypes.c_uint32(band), ctypes.c_int(typ), _p(sw, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
+                                             _p(txt, _u8p), ctypes.c_uint32(n_txt), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc), _p(src, _u32p),
+                                             _p(sk, _u32p), _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no), _p(clips, _u32p))
         assert no.value <= cap
         return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
 

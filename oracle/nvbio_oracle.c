@@ -893,6 +893,83 @@ int orc_banded_sw(uint32_t B, int type, const int32_t sw[4], const uint8_t* pat,
     return 1;
 }
 
+/* banded traceback of the linear-gap Smith-Waterman aligner: banded_alignment_traceback (nvbio/alignment/banded_inl.h:354-417) over
+ * sw/sw_banded_inl.h -- the score pass of orc_banded_sw with every cell's direction as SmithWatermanSubmatrixContext::new_cell stores
+ * it (:420-468: INSERTION if top wins, DELETION if left wins, else SUBSTITUTION; strict `>`, top against left first; NO SINK mark, so
+ * that a LOCAL walk runs on to row 0), then the walk of :741-797, run-length encoded as nvBowtie's Backtracker does.  Outputs as
+ * orc_banded_gotoh_traceback.  Returns 1 if an alignment was traced, 0 if nothing was reported. */
+int orc_banded_sw_traceback(uint32_t B, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                            int32_t* score, uint32_t source[2], uint32_t sink_out[2],
+                            uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len)
+{
+    best_sink sink; sink_init( &sink );
+    *score = sink.score; sink_out[0] = sink_out[1] = source[0] = source[1] = 0xFFFFFFFFu; *cigar_len = 0;
+    if (B < 2 || B > 64) return -1;
+    if (N < M) return 0;
+    const int32_t V = sw[0], S = sw[1], G = sw[2], I = sw[3];
+    uint8_t cache[64];
+    int32_t band[64];
+    uint8_t* dirs = (uint8_t*)malloc( (size_t)(M ? M : 1) * B );
+    const uint8_t cmask = (B == 31u) ? 3u : 255u;
+    for (uint32_t j = 0; j + 1u < B; ++j) cache[j] = (uint8_t)((j < N ? txt[j] : 255u) & cmask);
+    for (uint32_t j = 0; j < B; ++j) band[j] = (type == ORC_GLOBAL) ? (int32_t)j * G : 0;
+    for (uint32_t i = 0; i < M; ++i)
+    {
+        const uint8_t q = pat[i];
+        int32_t hi, top, left, diag;
+        {
+            const uint8_t g = cache[0];
+            diag = band[0] + (g == q ? V : S); top = band[1] + G;
+            hi = imax( top, diag );
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + 1u, i + 1u ); }
+            band[0] = hi; dirs[(size_t)i*B] = top > diag ? 1u : 0u;
+        }
+        for (uint32_t j = 1; j + 1u < B; ++j)
+        {
+            const uint8_t g = cache[j]; cache[j-1] = g;
+            diag = band[j] + (g == q ? V : S); top = band[j+1] + G; left = band[j-1] + I;
+            hi = imax( imax( top, left ), diag );
+            if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + j + 1u, i + 1u ); }
+            band[j] = hi;
+            dirs[(size_t)i*B + j] = top > left ? (top > diag ? 1u : 0u) : (left > diag ? 2u : 0u);
+        }
+        const uint8_t g = (i + B - 1u < N) ? txt[i + B - 1u] : 255u;
+        cache[B-2u] = (uint8_t)(g & cmask);
+        diag = band[B-1u] + (g == q ? V : S); left = band[B-2u] + I;
+        hi = imax( left, diag );
+        if (type == ORC_LOCAL) { hi = imax( hi, 0 ); sink_report( &sink, hi, i + B, i + 1u ); }
+        band[B-1u] = hi; dirs[(size_t)i*B + B-1u] = left > diag ? 2u : 0u;
+    }
+    if (type == ORC_GLOBAL) sink_report( &sink, band[B-1u], M + B - 1u, M );
+    else if (type == ORC_SEMI_GLOBAL)
+    {
+        const uint32_t m = (M + B - 1u < N ? M + B - 1u : N) - (M - 1u);
+        sink_report( &sink, band[0], M, M );
+        for (uint32_t j = 1; j < B; ++j) if (j < m) sink_report( &sink, band[j], M + j, M );
+    }
+    *score = sink.score;
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu) { free( dirs ); return 0; }
+    sink_out[0] = sink.x; sink_out[1] = sink.y;
+    uint32_t clen = 0; int prev = 255;
+#define CIG_PUSH(type_, len_) do { if (clen < cigar_cap) cigar[clen] = (uint16_t)((type_) | ((len_) << 2)); ++clen; } while (0)
+#define OP_PUSH(op_) do { if (prev == (int)(op_)) { if (clen - 1 < cigar_cap) cigar[clen-1] += 4; } else { CIG_PUSH( op_, 1u ); prev = (int)(op_); } } while (0)
+    if (M - sink.y) CIG_PUSH( 3u, M - sink.y );
+    int32_t entry = (int32_t)(sink.x - sink.y), row = (int32_t)sink.y - 1;
+    while (row >= 0)
+    {
+        const uint8_t op = dirs[(size_t)row*B + entry];
+        if (op == 2u)      { --entry; OP_PUSH( 2u ); }
+        else if (op == 1u) { ++entry; --row; OP_PUSH( 1u ); }
+        else               { --row; OP_PUSH( 0u ); }
+    }
+#undef OP_PUSH
+#undef CIG_PUSH
+    source[0] = (uint32_t)entry; source[1] = 0u;
+    *cigar_len = clen;
+    free( dirs );
+    return 1;
+}
+
 #define SW_STRIPE 16u
 int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                 int32_t min_score, int32_t* score, uint32_t sink_out[2])

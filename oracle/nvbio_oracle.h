@@ -182,6 +182,8 @@ int orc_full_gotoh_best2(int type, int blocking, const orc_gotoh_scheme* s, cons
 /* linear-gap Smith-Waterman / edit-distance aligners (sw/sw_banded_inl.h, sw/sw_inl.h); sw = {match, mismatch, deletion, insertion} */
 int orc_banded_sw(uint32_t band, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                   int32_t* score, uint32_t sink[2]);
+int orc_banded_sw_traceback(uint32_t band, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                            int32_t* score, uint32_t source[2], uint32_t sink[2], uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len);
 int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                 int32_t min_score, int32_t* score, uint32_t sink[2]);
 int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* s,

@@ -524,6 +524,37 @@ int full_tb_type(int type, const scheme_type& scheme,
     return -1;
 }
 
+// the banded traceback of the linear-gap Smith-Waterman aligner: aln::banded_alignment_traceback<BAND,1024,16>( SmithWatermanAligner<TYPE>, ... )
+// (nvbio/alignment/banded_inl.h:354-417 over sw/sw_banded_inl.h); sw[4] = { match, mismatch, deletion, insertion }; outputs as
+// ref_banded_gotoh_traceback_ex
+template <uint32 BAND, aln::AlignmentType TYPE>
+int banded_sw_tb_run(const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                     int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    typedef vector_view<const uint8*> string_type;
+    const aln::Alignment<int32> a = aln::banded_alignment_traceback<BAND,1024u,16u>(
+        aln::make_smith_waterman_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        min_score,
+        bt );
+    *score = a.score; source[0] = a.source.x; source[1] = a.source.y; sink[0] = a.sink.x; sink[1] = a.sink.y;
+    return (int)bt.n_clips;
+}
+template <uint32 BAND>
+int banded_sw_tb_type(int type, const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                      int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    switch (type)
+    {
+    case 0: return banded_sw_tb_run<BAND,aln::GLOBAL>     ( scheme, pat, M, txt, N, min_score, score, source, sink, bt );
+    case 1: return banded_sw_tb_run<BAND,aln::LOCAL>      ( scheme, pat, M, txt, N, min_score, score, source, sink, bt );
+    case 2: return banded_sw_tb_run<BAND,aln::SEMI_GLOBAL>( scheme, pat, M, txt, N, min_score, score, source, sink, bt );
+    }
+    return -1;
+}
+
 extern "C" {
 
 // Build an FM-index over text[0,n) (one 2-bit symbol per byte) exactly as
@@ -814,6 +845,27 @@ int ref_banded_gotoh_traceback_ex(uint32_t band, int type, const int32_t* sc,
     const int r = quals ?
         banded_tb_band( band, type, scheme, pat, quals, M, txt, N, min_score, score, source, sink, bt ) :
         banded_tb_band( band, type, scheme, pat, aln::trivial_quality_string(), M, txt, N, min_score, score, source, sink, bt );
+    *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
+    return r;
+}
+
+// the banded traceback of the linear-gap Smith-Waterman aligner (banded_sw_tb_type above); sw[4] = { match, mismatch, deletion, insertion }
+int ref_banded_sw_traceback(uint32_t band, int type, const int32_t* sw,
+                            const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                            int32_t* score, uint32_t* source, uint32_t* sink,
+                            uint8_t* ops, uint32_t cap, uint32_t* n_ops, uint32_t* clips)
+{
+    if (M > 1024u) return -1;
+    const aln::SimpleSmithWatermanScheme scheme( sw[0], sw[1], sw[2], sw[3] );
+    RecordingBacktracer bt; bt.ops = ops; bt.cap = cap; bt.n = 0; bt.n_clips = 0; bt.clips[0] = bt.clips[1] = 0;
+    int r = -1;
+    switch (band)
+    {
+    case 3:  r = banded_sw_tb_type<3> ( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    case 7:  r = banded_sw_tb_type<7> ( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    case 15: r = banded_sw_tb_type<15>( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    case 31: r = banded_sw_tb_type<31>( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    }
     *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
     return r;
 }

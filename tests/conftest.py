@@ -77,6 +77,11 @@ def myers_golden():
 
 
 @pytest.fixture(scope="session")
+def swtb_golden():
+    return np.load(os.path.join(GOLDEN, "swtb_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def staged_golden():
     return np.load(os.path.join(GOLDEN, "staged_golden.npz"), allow_pickle=False)
 

@@ -549,6 +549,52 @@ def make_staged(R):
     print("staged_golden.npz: %d cases, %d stop early" % (len(cases), int((out[:, 0] == 0).sum())))
 
 
+SWTB_SCHEMES = [(2, -3, -5, -2), (1, -1, -1, -1), (0, -1, -1, -1), (2, -2, -1, -4), (5, -4, -8, -8)]
+
+
+def swtb_cases(seed=123):
+    """(band, type, scheme index, pattern, text) for the traceback of the linear-gap Smith-Waterman aligner: unequal and equal deletion /
+    insertion costs, the edit-distance scheme, near-matches at every diagonal of the band, indels of 1-3 symbols, far-off pairs, N's in
+    the pattern, texts shorter than the pattern and barely longer"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(2500):
+        band = int(rng.choice([3, 7, 15, 31])); typ = int(rng.integers(0, 3))
+        M = int(rng.integers(1, 200)); N = max(M + int(rng.integers(-1, band + 4)), band)
+        txt = rng.integers(0, 4, N).astype(np.uint8)
+        d = int(rng.integers(0, band))
+        pat = np.resize(txt[min(d, N - 1):], M).copy()
+        mut = rng.random(M) < (0.03 if rng.random() < 0.6 else 0.3)
+        pat[mut] = rng.integers(0, 4, int(mut.sum()))
+        if rng.random() < 0.4 and M > 12:
+            p_ = int(rng.integers(3, M - 3)); g = int(rng.integers(1, 4))
+            pat = (np.concatenate([pat[:p_], pat[p_ + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5
+                   else np.concatenate([pat[:p_], rng.integers(0, 4, g).astype(np.uint8), pat[p_:M - g]]))
+        if rng.random() < 0.1:
+            pat[rng.integers(0, M)] = 4
+        cases.append((band, typ, int(rng.integers(0, len(SWTB_SCHEMES))), pat, txt))
+    return cases
+
+
+def make_swtb(R):
+    cases = swtb_cases()
+    po = np.zeros(len(cases) + 1, dtype=np.uint32); to = np.zeros(len(cases) + 1, dtype=np.uint32)
+    out = np.zeros((len(cases), 6), dtype=np.int64); co = np.zeros(len(cases) + 1, dtype=np.uint32)
+    cigs = []
+    for k, (band, typ, si, pat, txt) in enumerate(cases):
+        r, sc, src, snk, ops, clips = R.banded_sw_traceback(band, typ, SWTB_SCHEMES[si], pat, txt)
+        cig = oracle.cigar_from_ops(ops, clips[0], clips[1]) if r else np.zeros(0, np.uint16)
+        out[k] = (1 if r else 0, sc, src[0], src[1], snk[0], snk[1])
+        cigs.append(cig); co[k + 1] = co[k] + len(cig)
+        po[k + 1] = po[k] + len(pat); to[k + 1] = to[k] + len(txt)
+    np.savez_compressed(os.path.join(HERE, "swtb_golden.npz"), band=np.array([c[0] for c in cases], dtype=np.uint32),
+                        typ=np.array([c[1] for c in cases], dtype=np.int32), scheme=np.array([c[2] for c in cases], dtype=np.int32),
+                        schemes=np.array(SWTB_SCHEMES, dtype=np.int32), pats=np.concatenate([c[3] for c in cases]),
+                        txts=np.concatenate([c[4] for c in cases]), pat_off=po, txt_off=to, out=out, cig_off=co,
+                        cigars=np.concatenate(cigs).astype(np.uint16))
+    print("swtb_golden.npz: %d cases, %d traced, %d cigar elements" % (len(cases), int(out[:, 0].sum()), int(co[-1])))
+
+
 if __name__ == "__main__":
     if not oracle.Reference.available():
         oracle.build()
@@ -565,3 +611,4 @@ if __name__ == "__main__":
     make_rankdict(R)
     make_myers(R)
     make_staged(R)
+    make_swtb(R)

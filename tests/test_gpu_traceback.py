@@ -159,6 +159,38 @@ def test_traceback_packed_batch_vs_oracle(amd, orc, typ, tb_mode):
     assert checked > 5000
 
 
+def test_sw_traceback_golden(amd, swtb_golden, tb_mode):
+    """nvbio_banded_sw_traceback (the linear-gap Smith-Waterman / edit-distance aligners through BatchedBandedAlignmentTraceback) against
+    the reference's own outputs: scores, sources, sinks, CIGARs; unequal deletion / insertion costs; LOCAL walks that run to row 0"""
+    g = swtb_golden
+    max_len = int(np.diff(g["pat_off"]).max())
+    STRIDE = 64
+    seen = 0
+    for band in (3, 7, 15, 31):
+        for typ in range(3):
+            for si in range(len(g["schemes"])):
+                sel = np.nonzero((g["band"] == band) & (g["typ"] == typ) & (g["scheme"] == si))[0].astype(np.uint32)
+                if len(sel) == 0:
+                    continue
+                batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][sel], g["txt_off"][sel + 1], read_id=sel,
+                                           max_read_len=max_len)
+                al = amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*[int(v) for v in g["schemes"][si]]))
+                sc, src, snk, cig, ln = amd.BatchedBandedAlignmentTraceback(band, al).enact(batch, cigar_stride=STRIDE)
+                sc, src, snk, ln = _i64(sc), amd.u32(src).astype(np.int64), amd.u32(snk).astype(np.int64), _i64(ln)
+                cig = cig.cpu().numpy().view(np.uint16)
+                for k, i in enumerate(sel):
+                    want = g["out"][i]
+                    assert sc[k] == want[1], (i, band, typ, si)
+                    if want[0]:
+                        lo, hi = int(g["cig_off"][i]), int(g["cig_off"][i + 1])
+                        assert tuple(src[k]) == (want[2], want[3]) and tuple(snk[k]) == (want[4], want[5]), (i, band, typ, si)
+                        assert ln[k] == hi - lo and np.array_equal(cig[k, :min(hi - lo, STRIDE)], g["cigars"][lo:lo + min(hi - lo, STRIDE)]), (i, band, typ, si)
+                    else:
+                        assert ln[k] == 0
+                seen += len(sel)
+    assert seen == len(g["band"])
+
+
 def test_traceback_argument_errors(amd, orc):
     txt = np.zeros(256, dtype=np.uint8)
     pats = np.zeros(80, dtype=np.uint8)

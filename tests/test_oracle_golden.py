@@ -563,3 +563,18 @@ def test_staged_banded_golden(orc, staged_golden):
         assert (ok, sc, sk[0], sk[1]) == tuple(int(v) for v in g["out"][k][:4]), k
         early += ok == 0
     assert early > 500
+
+
+def test_banded_sw_traceback_golden(orc, swtb_golden):
+    """traceback of the linear-gap Smith-Waterman aligner (banded_inl.h:354-417 over sw/sw_banded_inl.h; unequal deletion / insertion
+    costs, the edit-distance scheme; its LOCAL walk that never meets a SINK) against the reference's own outputs: 2,500 cases"""
+    g = swtb_golden
+    for k in range(len(g["band"])):
+        pat = g["pats"][g["pat_off"][k]:g["pat_off"][k + 1]]; txt = g["txts"][g["txt_off"][k]:g["txt_off"][k + 1]]
+        ok, sc, src, snk, cig = orc.banded_sw_traceback(int(g["band"][k]), int(g["typ"][k]), g["schemes"][g["scheme"][k]], pat, txt)
+        want = g["out"][k]
+        assert ok == want[0] and sc == want[1], k
+        if ok:
+            assert src == (want[2], want[3]) and snk == (want[4], want[5]), k
+            assert np.array_equal(cig, g["cigars"][g["cig_off"][k]:g["cig_off"][k + 1]]), k
+    assert int(g["out"][:, 0].sum()) > 2000
