@@ -367,8 +367,9 @@ def traceback_best(genome2, genome_len, reads, params, best_score, best_rc, best
         # alignment ends in the last pattern row, so the sink is (end position - window begin, read length))
         sx = (best_pos[ids] - wb).to(torch.int32)
         known = dict(scores=best_score[ids].contiguous(), sinks=torch.stack([sx, torch.full_like(sx, M)], dim=1).contiguous())
-    sc, src, snk, cig, ln = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme)).enact(
-        batch, cigar_stride=cigar_stride, **known)
+    from . import _scratch
+    op = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme))
+    sc, src, snk, cig, ln = op.enact(batch, cigar_stride=cigar_stride, temp=_scratch(dev, op.min_temp_storage(batch) // 4, cap=6 << 30), **known)
     if ev is not None:
         ev.record()
     pos = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
@@ -488,7 +489,11 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
         batch = AlignmentBatch(a.reads4, 4, a_off, genome2, 2, i32(wb), i32(we), quals=a.quals, read_id=rid32,
                                flags=(a_rc.to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8), device=dev,
                                max_read_len=a.read_len)
-        _, src, _, cig, ln = BatchedBandedAlignmentTraceback(params.band, aligner).enact(batch, cigar_stride=cigar_stride)
+        # (direction vectors to the persistent scratch: a multi-GiB stream-ordered allocation inside the call stalls for ~0.1 s
+        # whenever the HIP pool has handed the memory back)
+        from . import _scratch
+        tb_op = BatchedBandedAlignmentTraceback(params.band, aligner)
+        _, src, _, cig, ln = tb_op.enact(batch, cigar_stride=cigar_stride, temp=_scratch(dev, tb_op.min_temp_storage(batch) // 4, cap=6 << 30))
         out["begin%d" % am][ids] = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
         out["cigars%d" % am][ids] = cig; out["cigar_lens%d" % am][ids] = ln
         # opposite mate: full matrix, in the opposite-mate window; its score and sink are known from the scoring pass

@@ -27,7 +27,9 @@ def main():
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 3_000_000_000
     M = 150
     genome = bench.make_reference(n, dev, seed=1234)
-    fmi = amd.FMIndex.build(genome, n, kmer_len=int(os.environ.get("PE_KMER", "17")), sa_int=1)
+    # the canonical two-strand table (16-byte entries) unless PE_TABLE_FLAGS says otherwise (0: the per-strand direct table)
+    fmi = amd.FMIndex.build(genome, n, kmer_len=int(os.environ.get("PE_KMER", "17")), sa_int=1,
+                            table_flags=int(os.environ.get("PE_TABLE_FLAGS", str(amd.FM_TABLE_CANONICAL_WIDE))))
     g = torch.Generator(device=dev); g.manual_seed(77)
     ins = torch.clamp((torch.randn(P, device=dev, generator=g) * 50 + 350).round().to(torch.int64), 160, 500)
     # mate 1 forward at the fragment start, mate 2 reverse-complemented at its end; make_reads draws loci itself, so
