@@ -63,7 +63,8 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
                             const uint32_t job_begin, const uint32_t jobs, const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
                             const int32_t* __restrict__ min_scores, uint32_t* __restrict__ column, uint32_t* __restrict__ dirs,
                             int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
-                            uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens)
+                            uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens,
+                            const uint8_t* __restrict__ band_code = nullptr)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -91,13 +92,33 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
     const int32_t V = sc.match;
     const uint32_t nst = (max_M + STRIPE - 1u) / STRIPE;        // direction words per text row
 
+    // Restricted rows (end-to-end jobs whose score S* and sink are known, band_code[job] = 2 + G): every step of a path scores <= 0, so a
+    // path that reaches S* holds gaps of at most G symbols in all and stays within G diagonals of the one it ends on; a stripe of 8
+    // pattern columns then only needs the text rows within G of that diagonal -- 8 + 2 G + 1 of them instead of all N (an opposite-mate
+    // window has 500).  Cells on such a path get their exact values from the restricted DP (their best predecessor is on one too),
+    // every alternative a direction rule compares them with can only come out lower, never one that ties (a tie would be another
+    // optimal path, inside the region as well): the traced path is the full DP's.  Cells outside the region read as -infinity.
+    const uint32_t code = (TYPE == NVBIO_SEMI_GLOBAL && band_code) ? band_code[job] : 1u;
+    const bool restricted = code >= 2u;
+    const int64_t band_G = (int64_t)code - 2, delta = (int64_t)sinks[job].x - (int64_t)sinks[job].y;   // (the sink given by the scoring pass)
+    auto rows_of = [&](const uint32_t block, int64_t& lo, int64_t& hi) {
+        lo = 0; hi = (int64_t)N - 1;
+        if (restricted)
+        {
+            lo = (int64_t)block + delta - band_G; hi = (int64_t)block + 7 + delta + band_G;
+            if (lo < 0) lo = 0;
+            if (hi > (int64_t)N - 1) hi = (int64_t)N - 1;
+        }
+    };
+
     uint32_t* col = column + t;                                 // element i at col[i * jobs]
-    for (uint32_t i = 0; i < N; ++i)
-    {
-        const int32_t x = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + sc.txt_ge * (int32_t)i : 0;
-        const int32_t y = (TYPE == NVBIO_LOCAL) ? 0 : infimum;
-        col[(size_t)i * jobs] = pack_cell( x, y );
-    }
+    if (!restricted)
+        for (uint32_t i = 0; i < N; ++i)
+        {
+            const int32_t x = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + sc.txt_ge * (int32_t)i : 0;
+            const int32_t y = (TYPE == NVBIO_LOCAL) ? 0 : infimum;
+            col[(size_t)i * jobs] = pack_cell( x, y );
+        }
 
     Sink sink; sink.init();
     const uint32_t nb        = (M + STRIPE - 1u) / STRIPE;
@@ -132,11 +153,32 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         int32_t temp_i    = H[0];
         uint32_t* drow = dirs + (size_t)(block / STRIPE) * jobs + t;          // word of row i at drow[i * nst * jobs]
 
-        for (uint32_t i = 0; i < N; ++i)
+        int64_t lo, hi, plo = 0, phi = -1;
+        rows_of( block, lo, hi );
+        if (restricted && block > 0u) rows_of( block - STRIPE, plo, phi );   // the rows the previous stripe left in `col`
+        // the boundary column of the stripe at row i: the carried column of the previous stripe, -infinity where that stripe did not go,
+        // the DP's first column for the first stripe
+        // (restricted: rows are stored RELATIVE to the first row of the stripe that writes them, so that the lanes of a wave -- whose
+        // bands lie at different text offsets -- still touch the same scratch lines in the same iteration)
+        auto col_at = [&](const int64_t i) -> uint32_t {
+            if (!restricted) return col[(size_t)i * jobs];
+            if (block == 0u) return pack_cell( 0, infimum );
+            return (i >= plo && i <= phi) ? col[(size_t)(i - plo) * jobs] : pack_cell( infimum, infimum );
+        };
+        if (restricted && lo > 0)
         {
+            // the row above the first one of the region lies outside it for every column of this stripe
+            #pragma unroll
+            for (int j = 1; j <= STRIPE; ++j) { H[j] = infimum; F[j] = infimum; }
+            temp_i = cell_h( col_at( lo - 1 ) );
+        }
+
+        for (int64_t ii = lo; ii <= hi; ++ii)
+        {
+            const uint32_t i = (uint32_t)ii;
             const uint32_t r_sym = trd.get( J.tb + i );
             int32_t H_diag = temp_i;
-            const uint32_t cell = col[(size_t)i * jobs];
+            const uint32_t cell = col_at( ii );
             H[0] = temp_i = cell_h( cell );
             int32_t E = cell_e( cell );
             uint32_t dw = 0;
@@ -158,8 +200,10 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
                 dw |= (hdir | (eleft > hleft ? D_INS_EXT : 0u) | (ftop > htop ? D_DEL_EXT : 0u)) << (4 * (j - 1));
                 if (TYPE == NVBIO_LOCAL && (!last || block + j <= M)) key = max2( key, (hi << 4) | j );
             }
-            col[(size_t)i * jobs] = pack_cell( H[STRIPE], E );
-            drow[(size_t)i * nst * jobs] = dw;
+            const size_t ri = restricted ? (size_t)(ii - lo) : (size_t)i;   // row index in the scratch
+            // (in place: the slot written, row - lo, lies at or below the slot just read, row - plo, and below every slot still to be read)
+            col[ri * jobs] = restricted ? pack_cell( max2( H[STRIPE], infimum ), max2( E, infimum ) ) : pack_cell( H[STRIPE], E );
+            drow[ri * nst * jobs] = dw;
             max_score = max2( max_score, H[STRIPE] );
             if (TYPE == NVBIO_LOCAL)
             {
@@ -173,7 +217,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
                 sink.report( v, i + 1u, M );
             }
         }
-        if (!last)
+        if (!last && !restricted)
         {
             const int32_t missing = (int32_t)(M - block - STRIPE);
             if (max_score + missing * V < min_score) ok = false;
@@ -210,7 +254,9 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         if (row != w_row || (ccol >> 3) != w_st)
         {
             w_row = row; w_st = ccol >> 3;
-            word = dirs[((size_t)(row - 1) * nst + (uint32_t)w_st) * jobs + t];
+            int64_t slo, shi; rows_of( (uint32_t)w_st * STRIPE, slo, shi );
+            const size_t ri = restricted ? (size_t)((int64_t)(row - 1) - slo) : (size_t)(row - 1);
+            word = dirs[(ri * nst + (uint32_t)w_st) * jobs + t];
         }
         const uint32_t op = (word >> (4 * (ccol & 7))) & 15u, h_op = op & 3u;
         if (TYPE == NVBIO_LOCAL && state == 0u && h_op == D_SINK) break;
@@ -244,7 +290,8 @@ __global__ void __launch_bounds__(256)
 ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t max_M, const uint32_t max_N,
                                const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
                                uint2* __restrict__ sources, uint16_t* __restrict__ cigars, const uint32_t cigar_stride,
-                               uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp)
+                               uint32_t* __restrict__ cigar_lens, uint8_t* __restrict__ need_dp,
+                               const int32_t gap_open_min = 0, const int32_t gap_ext_min = 0)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -277,7 +324,20 @@ ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint3
         if (TYPE == NVBIO_LOCAL && Q == best) found = true;
     }
     if (TYPE == NVBIO_SEMI_GLOBAL) found = (k == sink.y && Q == best);
-    if (!found) { need_dp[job] = 1; return; }
+    if (!found)
+    {
+        // the DP, over the rows within G diagonals of the sink's when G can be bounded (end-to-end, match bonus 0, gap_ext_min > 0: see
+        // full_gotoh_traceback_kernel): need_dp = 2 + G
+        uint32_t code = 1u;
+        if (TYPE == NVBIO_SEMI_GLOBAL && gap_ext_min > 0 && sink.y == J.M && best <= 0)
+        {
+            const int32_t a = -best;
+            const int32_t G = a < gap_open_min ? 0 : (a - gap_open_min) / gap_ext_min + 1;
+            if (G <= 250) code = 2u + (uint32_t)G;
+        }
+        need_dp[job] = (uint8_t)code;
+        return;
+    }
 
     uint16_t* cig = cigars + (size_t)job * cigar_stride;
     uint32_t  clen = 0;
@@ -428,7 +488,11 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
 
     // ---- 1. scoring pass (pattern blocking) unless handed over; 2. the ungapped shortcut; 3. job list ----
     const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
-    uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr;
+    uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr; uint8_t* need_dp = nullptr;
+    // the row-restricted DP applies to nvBowtie's end-to-end mode (see full_gotoh_traceback_kernel)
+    const int32_t go_min = -(sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go), ge_min = -(sc.pat_ge > sc.txt_ge ? sc.pat_ge : sc.txt_ge);
+    const bool narrow = type == NVBIO_SEMI_GLOBAL && sc.match == 0 && sc.mm_min >= 0 && sc.mm_max >= 0 && plain_gotoh( sc ) &&
+                        ge_min > 0 && go_min >= ge_min && !(b.algo & NVBIO_ALN_NO_NARROW_TRACEBACK);
     if (shortcut)
     {
         if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
@@ -444,13 +508,14 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
             set_error( "full traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
-        uint8_t* need_dp = (uint8_t*)aux;
+        need_dp   = (uint8_t*)aux;
         job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
         job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
         void* sel_temp = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
         const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
 #define NVB_UNG(TYPE_, RB, TB) hipLaunchKernelGGL( (ungapped_full_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, \
-                                                   (const int32_t*)scores_dev, (const uint2*)sinks_dev, (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp )
+                                                   (const int32_t*)scores_dev, (const uint2*)sinks_dev, (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp, \
+                                                   go_min, narrow ? ge_min : 0 )
 #define NVB_UNG_BITS(TYPE_) \
         if      (rb == 4 && tbits == 2) NVB_UNG( TYPE_, 4, 2 ); else if (rb == 2 && tbits == 2) NVB_UNG( TYPE_, 2, 2 ); \
         else if (rb == 8 && tbits == 2) NVB_UNG( TYPE_, 8, 2 ); else if (rb == 8 && tbits == 8) NVB_UNG( TYPE_, 8, 8 ); \
@@ -500,7 +565,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
         const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
 #define NVB_TB(TYPE_, RB, TB) hipLaunchKernelGGL( (full_gotoh_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)begin, jobs, \
                                                   (const uint32_t*)job_list, (const uint32_t*)job_count, min_scores_dev, column, dirs, scores_dev, (uint2*)sources_dev, \
-                                                  (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev )
+                                                  (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, (const uint8_t*)(narrow ? need_dp : nullptr) )
 #define NVB_TB_BITS(TYPE_) \
         if      (rb == 4 && tbits == 2) NVB_TB( TYPE_, 4, 2 ); else if (rb == 2 && tbits == 2) NVB_TB( TYPE_, 2, 2 ); \
         else if (rb == 8 && tbits == 2) NVB_TB( TYPE_, 8, 2 ); else if (rb == 8 && tbits == 8) NVB_TB( TYPE_, 8, 8 ); \
