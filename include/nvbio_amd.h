@@ -727,7 +727,8 @@ nvbio_status nvbio_banded_sw_traceback(int device, uint32_t band, nvbio_alignmen
  * x = text and y = pattern coordinates and INSERTION = pattern symbol without text, DELETION = text symbol without
  * pattern.  The scoring is the pattern-blocking pass (the one alignment_traceback itself runs), min_scores_dev
  * (optional) its stripe early exit.  max_pattern_len / max_text_len must bound every job (they size the scratch: a
- * boundary column plus 4 bits per DP cell); a longer job is skipped and flagged with cigar_lens = 0xFFFFFFFF.
+ * boundary column plus 4 bits per DP cell, for whole waves of 64 jobs: temp_bytes must hold at least 64 jobs); a longer job is
+ * skipped and flagged with cigar_lens = 0xFFFFFFFF.
  * flags: NVBIO_TRACEBACK_SINKS_GIVEN as above (scores / sinks from nvbio_full_gotoh_score with text_blocking = 0 and
  * the same min_scores).  NVBIO_ERR_UNSUPPORTED when scores could leave the reference's int16 checkpoints. */
 nvbio_status nvbio_full_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t max_pattern_len,

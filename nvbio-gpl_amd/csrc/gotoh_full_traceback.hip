@@ -111,13 +111,19 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         }
     };
 
-    uint32_t* col = column + t;                                 // element i at col[i * jobs]
+    // scratch layout: wave-major -- the 64 jobs of a wave own one contiguous block (boundary column: max_N lines of 256 bytes, direction
+    // words: max_N * nst lines), so that a wave's working set is a few hundred KB of neighbouring pages whatever the number of jobs in
+    // the launch (job-interleaved over the whole launch, the first version, put every line of a wave 0.86 MB from the next: one TLB
+    // entry per access)
+    const size_t wv = t >> 6, ln = t & 63u;
+    uint32_t* col = column + wv * ((size_t)max_N * 64u) + ln;   // element i at col[i * 64]
+    uint32_t* const dbase = dirs + wv * ((size_t)max_N * nst * 64u) + ln;
     if (!restricted)
         for (uint32_t i = 0; i < N; ++i)
         {
             const int32_t x = (TYPE == NVBIO_GLOBAL) ? sc.txt_go + sc.txt_ge * (int32_t)i : 0;
             const int32_t y = (TYPE == NVBIO_LOCAL) ? 0 : infimum;
-            col[(size_t)i * jobs] = pack_cell( x, y );
+            col[(size_t)i * 64u] = pack_cell( x, y );
         }
 
     Sink sink; sink.init();
@@ -151,7 +157,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         }
         int32_t max_score = NVBIO_SCORE_MIN;
         int32_t temp_i    = H[0];
-        uint32_t* drow = dirs + (size_t)(block / STRIPE) * jobs + t;          // word of row i at drow[i * nst * jobs]
+        uint32_t* drow = dbase + (size_t)(block / STRIPE) * 64u;              // word of row i at drow[i * nst * 64]
 
         int64_t lo, hi, plo = 0, phi = -1;
         rows_of( block, lo, hi );
@@ -161,9 +167,9 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         // (restricted: rows are stored RELATIVE to the first row of the stripe that writes them, so that the lanes of a wave -- whose
         // bands lie at different text offsets -- still touch the same scratch lines in the same iteration)
         auto col_at = [&](const int64_t i) -> uint32_t {
-            if (!restricted) return col[(size_t)i * jobs];
+            if (!restricted) return col[(size_t)i * 64u];
             if (block == 0u) return pack_cell( 0, infimum );
-            return (i >= plo && i <= phi) ? col[(size_t)(i - plo) * jobs] : pack_cell( infimum, infimum );
+            return (i >= plo && i <= phi) ? col[(size_t)(i - plo) * 64u] : pack_cell( infimum, infimum );
         };
         if (restricted && lo > 0)
         {
@@ -202,8 +208,8 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
             }
             const size_t ri = restricted ? (size_t)(ii - lo) : (size_t)i;   // row index in the scratch
             // (in place: the slot written, row - lo, lies at or below the slot just read, row - plo, and below every slot still to be read)
-            col[ri * jobs] = restricted ? pack_cell( max2( H[STRIPE], infimum ), max2( E, infimum ) ) : pack_cell( H[STRIPE], E );
-            drow[ri * nst * jobs] = dw;
+            col[ri * 64u] = restricted ? pack_cell( max2( H[STRIPE], infimum ), max2( E, infimum ) ) : pack_cell( H[STRIPE], E );
+            drow[ri * nst * 64u] = dw;
             max_score = max2( max_score, H[STRIPE] );
             if (TYPE == NVBIO_LOCAL)
             {
@@ -256,7 +262,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
             w_row = row; w_st = ccol >> 3;
             int64_t slo, shi; rows_of( (uint32_t)w_st * STRIPE, slo, shi );
             const size_t ri = restricted ? (size_t)((int64_t)(row - 1) - slo) : (size_t)(row - 1);
-            word = dirs[(ri * nst + (uint32_t)w_st) * jobs + t];
+            word = dbase[(ri * nst + (uint32_t)w_st) * 64u];
         }
         const uint32_t op = (word >> (4 * (ccol & 7))) & 15u, h_op = op & 3u;
         if (TYPE == NVBIO_LOCAL && state == 0u && h_op == D_SINK) break;
@@ -304,7 +310,18 @@ ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint3
     need_dp[job] = 0;
     if (J.M > max_M || J.N > max_N) { sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0xFFFFFFFFu; return; }
     if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu) { sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0; return; }
-    if (TYPE == NVBIO_GLOBAL || (TYPE == NVBIO_SEMI_GLOBAL && sink.x < sink.y)) { need_dp[job] = 1; return; }
+    // the DP, over the rows within G diagonals of the sink's when G can be bounded (end-to-end, match bonus 0, gap_ext_min > 0: see
+    // full_gotoh_traceback_kernel): need_dp = 2 + G, else 1.  (One job over all rows in a launch of restricted ones is the launch's time.)
+    auto dp_code = [&]() -> uint8_t {
+        if (TYPE == NVBIO_SEMI_GLOBAL && gap_ext_min > 0 && sink.y == J.M && best <= 0)
+        {
+            const int32_t a = -best;
+            const int32_t G = a < gap_open_min ? 0 : (a - gap_open_min) / gap_ext_min + 1;
+            if (G <= 250) return (uint8_t)(2 + G);
+        }
+        return (uint8_t)1;
+    };
+    if (TYPE == NVBIO_GLOBAL || (TYPE == NVBIO_SEMI_GLOBAL && sink.x < sink.y)) { need_dp[job] = dp_code(); return; }
 
     SymbolReader<TBITS> trd( b.text );
     SymbolReader<RBITS> prd( b.reads );
@@ -324,20 +341,7 @@ ungapped_full_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint3
         if (TYPE == NVBIO_LOCAL && Q == best) found = true;
     }
     if (TYPE == NVBIO_SEMI_GLOBAL) found = (k == sink.y && Q == best);
-    if (!found)
-    {
-        // the DP, over the rows within G diagonals of the sink's when G can be bounded (end-to-end, match bonus 0, gap_ext_min > 0: see
-        // full_gotoh_traceback_kernel): need_dp = 2 + G
-        uint32_t code = 1u;
-        if (TYPE == NVBIO_SEMI_GLOBAL && gap_ext_min > 0 && sink.y == J.M && best <= 0)
-        {
-            const int32_t a = -best;
-            const int32_t G = a < gap_open_min ? 0 : (a - gap_open_min) / gap_ext_min + 1;
-            if (G <= 250) code = 2u + (uint32_t)G;
-        }
-        need_dp[job] = (uint8_t)code;
-        return;
-    }
+    if (!found) { need_dp[job] = dp_code(); return; }
 
     uint16_t* cig = cigars + (size_t)job * cigar_stride;
     uint32_t  clen = 0;
@@ -452,7 +456,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback_temp_bytes(const nvbio_alignm
 {
     NVB_REQUIRE( batch && bytes, "batch/bytes is NULL" );
     NVB_REQUIRE( max_pattern_len > 0 && max_text_len > 0, "max_pattern_len / max_text_len must be positive" );
-    *bytes = (uint64_t)batch->n * full_tb_bytes_per_job( max_pattern_len, max_text_len );
+    *bytes = (((uint64_t)batch->n + 63u) & ~63ull) * full_tb_bytes_per_job( max_pattern_len, max_text_len );   // whole waves of 64 jobs own scratch
     return NVBIO_OK;
 }
 
@@ -532,8 +536,8 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     void* owned = nullptr; uint8_t* scratch = (uint8_t*)temp_dev; uint64_t cap_jobs;
     if (scratch)
     {
-        cap_jobs = temp_bytes / per_job;
-        if (!(cap_jobs >= 64 || cap_jobs >= b.n))
+        cap_jobs = (temp_bytes / per_job) & ~63ull;                  // whole waves of 64 jobs
+        if (cap_jobs < 64)
         {
             if (aux) (void)hipFreeAsync( aux, s );
             set_error( "invalid argument: temp_bytes too small (see nvbio_full_gotoh_traceback_temp_bytes)" );
@@ -546,7 +550,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
         if (cap_jobs < 16384u) cap_jobs = b.n < 16384u ? b.n : 16384u;
         const uint64_t budget = 8ull << 30;
         if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
-        if (cap_jobs < 64) cap_jobs = 64;
+        cap_jobs = (cap_jobs + 63u) & ~63ull;
         if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
             if (aux) (void)hipFreeAsync( aux, s );
@@ -555,13 +559,13 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
         }
         scratch = (uint8_t*)owned;
     }
-    if (cap_jobs > b.n) cap_jobs = b.n;
     nvbio_status st = NVBIO_OK;
     for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
     {
         const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);
         uint32_t* column = (uint32_t*)scratch;
-        uint32_t* dirs   = column + (size_t)jobs * max_text_len;
+        const uint64_t jobs64 = ((uint64_t)jobs + 63u) & ~63ull;                  // whole waves own scratch
+        uint32_t* dirs   = column + (size_t)jobs64 * max_text_len;
         const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
 #define NVB_TB(TYPE_, RB, TB) hipLaunchKernelGGL( (full_gotoh_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)begin, jobs, \
                                                   (const uint32_t*)job_list, (const uint32_t*)job_count, min_scores_dev, column, dirs, scores_dev, (uint2*)sources_dev, \

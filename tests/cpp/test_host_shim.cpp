@@ -217,7 +217,7 @@ int main()
         typedef aln::GotohAligner<aln::LOCAL,aln::SimpleGotohScheme> aligner_t;
         typedef aln::FlatTracebackStream<aligner_t> stream_t;
         aln::BatchedAlignmentTraceback<64,stream_t> tb;
-        REQUIRE( tb.min_temp_storage( M, M + 31, J ) == (uint64_t)J * (M + 31) * 4 * (1 + (M + 7) / 8) );
+        REQUIRE( tb.min_temp_storage( M, M + 31, J ) == (uint64_t)((J + 63) / 64 * 64) * (M + 31) * 4 * (1 + (M + 7) / 8) );   // whole waves own scratch
         tb.enact( stream_t( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, d_scores.data(), d_src.data(), d_sinks.data(),
                             d_cig.data(), STRIDE, d_len.data() ), M, M + 31 );
         check_hip( hipDeviceSynchronize(), "sync" );
