@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--no-mapq", action="store_true", help="leave nvBowtie's second-best bookkeeping and the mapping quality out of the step")
     ap.add_argument("--no-traceback", action="store_true", help="skip the (untimed) traceback-stage measurement")
     ap.add_argument("--algo-flags", type=int, default=0, help="A/B: NVBIO_ALN_* flags OR-ed into every alignment batch of the timed step")
-    ap.add_argument("--pk-two-waves", action="store_true", help="A/B: the packed band-31 DP kernel built for 2 waves per SIMD (no register spills)")
+    ap.add_argument("--pk-three-waves", action="store_true", help="A/B: the packed band-31 DP kernel built for 3 waves per SIMD (168 VGPRs, prologue state spills) instead of 2")
     ap.add_argument("--with-traceback", action="store_true", help="put the traceback of every aligned read's best alignment (CIGARs) inside the timed step")
     ap.add_argument("--build-breakdown", action="store_true", help="build the index once more without tables to report index_build_s and table_build_s separately")
     ap.add_argument("--max-seed-hits", type=int, default=0, help="extend at most this many SA rows of a seed's range (0: all; needed with --repeat-family)")
@@ -234,8 +234,8 @@ def main():
     params = pipeline.SeedExtendParams.end_to_end() if args.mode == "e2e" else pipeline.SeedExtendParams()
     params.direct = not args.no_direct
     params.max_seed_hits = args.max_seed_hits or None
-    if args.pk_two_waves:
-        params.algo_flags = amd.ALN_PK_TWO_WAVES
+    if args.pk_three_waves:
+        params.algo_flags = amd.ALN_PK_THREE_WAVES
     if args.algo_flags:
         params.algo_flags = (params.algo_flags or 0) | args.algo_flags
     params.fused_seed_pass = not args.no_fused_seeds
@@ -379,13 +379,13 @@ def main():
     if not args.no_plain_ab:
         prev_direct = params.direct
         params.direct = False
-        params.algo_flags = amd.ALN_NO_UNGAPPED_SCORE | (amd.ALN_PK_TWO_WAVES if args.pk_two_waves else 0)   # algo_flags: DP for every candidate
+        params.algo_flags = amd.ALN_NO_UNGAPPED_SCORE | (amd.ALN_PK_THREE_WAVES if args.pk_three_waves else 0)   # algo_flags: DP for every candidate
         pipeline.seed_and_extend(fmi, genome, n, batch, params, None)                 # warm
         pt = {}
         torch.cuda.synchronize(); p0 = time.perf_counter()
         pbs, pbp, pbrc, pnc = pipeline.seed_and_extend(fmi, genome, n, batch, params, pt)
         torch.cuda.synchronize(); pdt = time.perf_counter() - p0
-        params.algo_flags = amd.ALN_PK_TWO_WAVES if args.pk_two_waves else 0
+        params.algo_flags = (amd.ALN_PK_THREE_WAVES if args.pk_three_waves else 0) | (args.algo_flags or 0)
         params.direct = prev_direct
         pst = {k: float(np.mean(event_ms(v))) for k, v in pt.items()}
         plain = {"ms_per_step": pdt * 1e3, "match_ms_per_launch": 0.5 * (pst.get("match_fw", 0.0) + pst.get("match_rc", 0.0)),

@@ -573,8 +573,9 @@ enum
     NVBIO_ALN_NO_PACKED_DP          = 4,   /* int32 kernels only                                                                */
     NVBIO_ALN_FORCE_PACKED_DP       = 8,   /* packed full-matrix kernel also for small batches                                  */
     NVBIO_ALN_NO_UNGAPPED_TRACEBACK = 16,  /* every traceback through the direction-vector DP                                   */
-    NVBIO_ALN_PK_TWO_WAVES          = 32,  /* packed band-31 kernel built for 2 waves per SIMD (256 VGPRs, no register spills) instead
-                                              of 3 (168 VGPRs; SEMI_GLOBAL / GLOBAL spill their prologue state)                  */
+    NVBIO_ALN_PK_THREE_WAVES        = 32,  /* packed band-31 kernel built for 3 waves per SIMD (168 VGPRs; the prologue state spills)
+                                              instead of 2 (256 VGPRs, nothing spills: the default since the row loop issues without
+                                              idle slots and no longer gains from a third wave)                                  */
     NVBIO_ALN_NO_SECOND_CHANCE      = 128, /* two-mismatch jobs go to the DP (A/B: what the check costs inside the first pass)           */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs
                                               whose optimal paths provably stay within 7 diagonals of the sink)                  */

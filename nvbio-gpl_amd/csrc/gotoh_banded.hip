@@ -240,16 +240,28 @@ __device__ __forceinline__ uint32_t clamp_u32(const int64_t v, const uint32_t lo
     return v < (int64_t)lo ? lo : (v > (int64_t)hi ? hi : (uint32_t)v);
 }
 
+// bit k of the result = bit 2k of x
+__device__ __forceinline__ uint32_t even_bits64(uint64_t x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16));
+    return (uint32_t)x;
+}
+
 // Rows are processed in chunks of 8.  At the top of a chunk every lane assembles the chunk's 8 read
 // symbols and 8 incoming text symbols (per alignment) from words loaded one chunk EARLIER, then
 // issues the loads for the next chunk: one wave-uniform wait point per 8 rows with an 8-row
 // (~5,000 instruction) head start, and no per-row branches.  Reads are packed RBITS (2 or 4) per
 // symbol, the text 2 bits per symbol.
-// MINW: the occupancy the register allocator must reach.  3 waves per SIMD leave 168 VGPRs: LOCAL fits; SEMI_GLOBAL / GLOBAL spill
-// 34 / 72 registers (140 / 276 bytes of scratch per lane) -- all of it prologue / epilogue state (the scratch accesses sit outside
-// the row loop).  2 waves leave 256: nothing spills.  Which is faster is measured, not assumed: NVBIO_ALN_PK_TWO_WAVES runs the
-// 2-wave build.
-template <int TYPE, int RBITS, int MINW = 3>
+// MINW: the occupancy the register allocator must reach.  3 waves per SIMD leave 168 VGPRs: about 90 registers of prologue / epilogue
+// state spill (the scratch accesses sit outside the row loop).  2 waves leave 256: nothing spills.  Which is faster is measured, not
+// assumed: 3 waves won while the row loop still had idle issue slots to fill; with the hand-ordered loop 2 waves are 4 % ahead and
+// are the default, NVBIO_ALN_PK_THREE_WAVES runs the other build.
+template <int TYPE, int RBITS, int MINW = 3, bool M0 = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MINW, 3)))
 banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
                               const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
@@ -311,10 +323,16 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     const bool has_quals = (b.quals != nullptr);
 
     const v2s GO = pk( sc.pat_go, sc.pat_go ), GE = pk( sc.pat_ge, sc.pat_ge );
-    const int gm = sc.pat_go > sc.pat_ge ? sc.pat_go : sc.pat_ge;
-    const v2s GM = pk( gm, gm );                                     // max(GO,GE): E' = max(t + GO, E + GM)
     const v2s INF = pk( -16384, -16384 ), ZERO = pk( 0, 0 ), K32 = pk( 32, 32 );
     const int V = sc.match;
+    const int S_noq = s_mm[0];                                       // without qualities every row scores a mismatch like this
+    uint32_t cx[2], lim[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        cx[u]  = comp[u] ? 3u : 0u;                                  // complement: A<->T, C<->G
+        lim[u] = N[u] > (uint32_t)(BAND - 1) ? N[u] - (uint32_t)(BAND - 1) : 0u;     // row i's column 30 lies past the text end iff i >= lim
+    }
 
     int32_t  best[2]   = { NVBIO_SCORE_MIN, NVBIO_SCORE_MIN };
     uint32_t best_x[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, best_y[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu };
@@ -333,8 +351,10 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
         rows_u[1] = (split && pass != 1) ? 0u : rows_all[1];
         const uint32_t rows = rows_u[0] > rows_u[1] ? rows_u[0] : rows_u[1];
 
-        // ---- text cache: columns 0..29 of row 0, big-endian (column j at bits [62-2j, 63-2j]) ------------
-        uint64_t cache[2];
+        // ---- text cache: two bit planes per alignment, c0 / c1 = low / high bits of the symbols.  Inside a row column j sits at bit
+        // 30-j: the row's incoming symbol (column 30) is shifted in at bit 0 (one v_alignbit per plane) and every other column
+        // thereby moves to the next row's position; between rows the planes hold columns 0..29 at bits 29-j ------------------------
+        uint32_t c0[2], c1[2];
         #pragma unroll
         for (int u = 0; u < 2; ++u)
         {
@@ -344,10 +364,12 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
             const uint32_t w2 = twords[clamp_u32( w + 2u, t_lo[u], t_hi[u] )];
             const uint32_t bit = (tb[u] & 15u) * 2u;
             const uint64_t hi = ((uint64_t)funnel32( w0, w1, bit ) << 32) | funnel32( w1, w2, bit );
-            uint64_t c = hi & ~0xFull;                               // 30 symbols = top 60 bits
+            uint64_t c = hi & ~0xFull;                               // 30 symbols = top 60 bits, column j at bits [62-2j, 63-2j]
             // symbols at or past the text end read as 3 (the 255 sentinel through a 2-bit cache)
             if (N[u] < 30u) c |= (~0ull >> (2u * N[u])) & ~0xFull;
-            cache[u] = c;
+            // even / odd bits of c, gathered: column j at bit 31-j, moved to bit 29-j (the row's incoming symbol is shifted in at bit 0)
+            c0[u] = even_bits64( c ) >> 2;
+            c1[u] = even_bits64( c >> 1 ) >> 2;
         }
 
         // ---- stream words for chunk 0 (loaded now, consumed at the top of the loop) ----------------------
@@ -381,18 +403,18 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
         };
         issue_loads( 0 );
 
-        v2s H[BAND], F[BAND];
+        v2s H[BAND], Hg[BAND], F[BAND];                              // Hg = H + GO, kept beside H: feeds the next row's F and this row's E
         #pragma unroll
         for (int j = 0; j < BAND; ++j)
         {
             const int h0 = (TYPE == NVBIO_GLOBAL && j > 0) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;      // init_row_zero (:37-68)
-            H[j] = pk( h0, h0 ); F[j] = INF;
+            H[j] = pk( h0, h0 ); F[j] = INF; Hg[j] = H[j] + GO;
         }
 
         for (uint32_t r0 = 0; r0 < rows; r0 += 8u)
         {
             // ---- assemble this chunk from the words loaded a chunk ago, then request the next chunk ----
-            uint32_t rchunk[2], tchunk[2]; int rsh[2], rstep[2];
+            uint32_t rchunk[2], tchunk[2], tchunk1[2]; int rsh[2], rstep[2];
             uint64_t qchunk[2] = { 0, 0 }; int qsh[2], qstep[2];
             #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -411,7 +433,13 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                 rsh[u]    = rev[u] ? (32 - RBITS) - 7 * RBITS : (32 - RBITS);   // row 0 of the chunk: last / first symbol
                 rstep[u]  = rev[u] ? RBITS : -RBITS;
                 const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);
-                tchunk[u] = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
+                uint32_t tc = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
+                // symbols at or past the text end enter the cache as 3 (the 255 sentinel through a 2-bit cache): symbol k of the
+                // chunk is text symbol r0 + 30 + k
+                const int64_t kk = (int64_t)N[u] - (int64_t)(BAND - 1) - (int64_t)r0;
+                if (kk < 16) tc |= (kk <= 0) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (2u * (uint32_t)kk));
+                tchunk[u]  = tc;                                     // top bit = high bit of the next symbol
+                tchunk1[u] = tc << 1;                                // top bit = its low bit
             }
             if (r0 + 8u < rows) issue_loads( r0 + 8u );
 
@@ -419,61 +447,90 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
             for (uint32_t t = 0; t < r_end; ++t)
             {
                 const uint32_t i = r0 + t;
-                // the row's pattern symbols / mismatch scores and the text symbols entering column 30
-                uint32_t q[2], gn[2]; int S[2];
+                // the row's pattern symbols / mismatch scores, the text symbols entering column 30, and the row's mismatch flags:
+                // nq(u) bit 30-j = column j of alignment u does NOT match (31 columns from the two planes; an N in the read matches
+                // nothing; a column-30 symbol past the text end is the 255 sentinel for this row and a 3 once it is in the cache).
+                // (A half that has no rows left -- or never had any -- keeps computing on whatever its streams hold: nothing of it
+                // is reported.)
+                uint32_t nq[2]; int S[2];
+                if (has_quals)
+                {
+                    #pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                    {
+                        const uint32_t ql = (uint32_t)(qchunk[u] >> qsh[u]) & 0xFFu; qsh[u] += qstep[u];
+                        S[u] = s_mm[ql < 63u ? ql : 63u];
+                    }
+                }
+                else S[0] = S[1] = S_noq;
                 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                 {
-                    uint32_t qq = (rchunk[u] >> rsh[u]) & RMASK; rsh[u] += rstep[u];
-                    if (comp[u] && qq < 4u) qq = 3u - qq;
-                    q[u] = (i < rows_u[u]) ? qq : 255u;
-                    uint32_t ql = (uint32_t)(qchunk[u] >> qsh[u]) & 0xFFu; qsh[u] += qstep[u];
-                    if (i >= rows_u[u]) ql = 0;
-                    S[u] = s_mm[ql < 63u ? ql : 63u];
-                    gn[u] = (i + (uint32_t)(BAND - 1) < N[u]) ? (tchunk[u] >> 30) : 255u;
-                    tchunk[u] <<= 2;
+                    const uint32_t q = ((rchunk[u] >> rsh[u]) & RMASK) ^ cx[u]; rsh[u] += rstep[u];     // (complementing keeps an N an N)
+                    c1[u] = __builtin_amdgcn_alignbit( c1[u], tchunk[u],  31 );
+                    c0[u] = __builtin_amdgcn_alignbit( c0[u], tchunk1[u], 31 );
+                    tchunk[u] <<= 2; tchunk1[u] <<= 2;
+                    uint32_t x = (c0[u] ^ (0u - (q & 1u))) | (c1[u] ^ (0u - ((q >> 1) & 1u)));
+                    if (RBITS > 2 && q >= 4u) x = 0xFFFFFFFFu;
+                    if (i >= lim[u]) x |= 1u;                         // column 30 past the text end
+                    nq[u] = x;
                 }
+                // both alignments side by side: column j >= 15 at bits 30-j / 46-j of NWa, column j < 15 at bits 14-j / 30-j of NWb
+                const uint32_t NWa = __builtin_amdgcn_perm( nq[1], nq[0], 0x05040100u );
+                const uint32_t NWb = __builtin_amdgcn_perm( nq[1], nq[0], 0x07060302u );
 
-                // match flags of the 30 cached columns, e(u) at the LOW bit of each 2-bit slot, then alignment 1
-                // moved to the high bit: column j at bits 62-2j (alignment 0) and 63-2j (alignment 1)
-                uint64_t e[2];
-                #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                {
-                    e[u] = 0;
-                    if (q[u] < 4u) { const uint64_t x = cache[u] ^ ((uint64_t)q[u] * 0x5555555555555555ull); e[u] = ~(x | (x >> 1)) & 0x5555555555555555ull; }
-                }
-                const uint64_t EQ = e[0] | (e[1] << 1);
+                const v2s SS = pk( S[0], S[1] );                      // M0 (match = 0): d = H + mismatch * S
+                const v2s SD = pk( S[0] - V, S[1] - V );              // else          : d = (H + V) + mismatch * (S - V)
+                const v2s VV = pk( V, V );
 
-                const v2s SS = pk( S[0], S[1] );
-                const v2s DV = pk( V - S[0], V - S[1] );
-
-                v2s E = ZERO;
+                // One cell is 10 operations: f = max(F[j+1] + GE, Hg[j+1]); d = H[j] + mismatch * S; t = max(f, d); h = max(t, E);
+                // hg = h + GO; E' = max(hg, E + GE).  Only E runs along the row; gfx950 needs one idle slot between a packed 16-bit
+                // operation and a consumer issued right behind it, so the row is software-pipelined by hand: the E steps of cell j
+                // are interleaved with everything of cell j+1 that does not depend on E, in an order in which no operation directly
+                // follows its producer (sched_barrier keeps the compiler from undoing it: measured 15 -> 10 issue slots per cell).
+                v2s E = ZERO, a = ZERO, tt;
                 v2s key = pk( -1, -1 );
+                {
+                    const v2s x  = F[1] + GE;
+                    const v2s t0 = pk_from_bits( (NWb >> 14) & 0x00010001u );
+                    const v2s d  = M0 ? H[0] + t0 * SS : (H[0] + VV) + t0 * SD;
+                    const v2s f  = pk_max( x, Hg[1] );
+                    F[0] = f;
+                    tt = pk_max( f, d );
+                    if (TYPE == NVBIO_LOCAL) tt = pk_max( tt, ZERO );
+                }
                 #pragma unroll
                 for (int j = 0; j < BAND; ++j)
                 {
-                    const v2s f = (j < BAND - 1) ? pk_max( F[j + 1] + GE, H[j + 1] + GO ) : INF;
-                    F[j] = f;
-
-                    uint32_t eq01;
-                    if (j == BAND - 1) eq01 = (gn[0] == q[0] ? 1u : 0u) | (gn[1] == q[1] ? 0x10000u : 0u);
-                    else               eq01 = (uint32_t)((EQ >> (62 - 2 * j)) & 1ull) | ((uint32_t)((EQ >> (63 - 2 * j)) & 1ull) << 16);
-                    const v2s d = H[j] + SS + pk_from_bits( eq01 ) * DV;
-
-                    // everything that does not depend on E first: t = max(f, d [, 0]); then h = max(t, E) and the
-                    // E recurrence E' = max(t + GO, E + max(GO,GE)) (== max(h + GO, E + GE)): two dependent ops per cell
-                    v2s tt = (j == BAND - 1) ? d : pk_max( f, d );
-                    if (TYPE == NVBIO_LOCAL) tt = pk_max( tt, ZERO );
+                    constexpr int Z = 0;
+                    const int j1 = j + 1, j2 = j + 2;
+                    v2s x = INF, d = ZERO, f = INF, t1 = ZERO, tn = ZERO, an = ZERO;
+                    uint32_t q1 = 0;
+                    if (j2 < BAND) x  = F[j2] + GE;
+                    __builtin_amdgcn_sched_barrier( Z );
                     const v2s h = (j == 0) ? tt : pk_max( tt, E );
+                    if (j1 < BAND) q1 = (j1 < 15) ? NWb >> (14 - j1) : NWa >> (30 - j1);
+                    __builtin_amdgcn_sched_barrier( Z );
+                    const v2s hg = h + GO;
+                    if (j2 < BAND) f  = pk_max( x, Hg[j2] );
+                    __builtin_amdgcn_sched_barrier( Z );
+                    const v2s En = (j == 0) ? hg : pk_max( hg, a );
+                    if (j1 < BAND) t1 = pk_from_bits( q1 & 0x00010001u );
+                    if (j1 < BAND) d  = M0 ? H[j1] + t1 * SS : (H[j1] + VV) + t1 * SD;
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j1 < BAND) an = En + GE;
                     if (TYPE == NVBIO_LOCAL) key = pk_max( key, h * K32 + pk( j, j ) );
-                    H[j] = h;
-                    E = (j == 0) ? tt + GO : pk_max( tt + GO, E + GM );
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j1 < BAND)
+                    {
+                        tn = (j2 < BAND) ? pk_max( f, d ) : d;
+                        if (TYPE == NVBIO_LOCAL) tn = pk_max( tn, ZERO );
+                        F[j1] = f;
+                    }
+                    H[j] = h; Hg[j] = hg;
+                    E = En; a = an; tt = tn;
+                    __builtin_amdgcn_sched_barrier( Z );
                 }
-
-                // shift the caches by one column and append the new symbols
-                #pragma unroll
-                for (int u = 0; u < 2; ++u) cache[u] = ((cache[u] << 2) & ~0xFull) | ((uint64_t)(gn[u] & 3u) << 4);
 
                 if (TYPE == NVBIO_LOCAL)
                 {
@@ -872,6 +929,26 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
 struct IsTwo { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 2u ? 1u : 0u; } };
 struct FlagIs { const uint8_t* flags; uint8_t code; __host__ __device__ __forceinline__ bool operator()(const uint32_t i) const { return flags[i] == code; } };
 
+// the packed kernel's instantiation for this scheme: match = 0 (every end-to-end scheme of nvBowtie) drops one operation per cell
+template <int TYPE, int RB>
+static void launch_pk_kernel(const BatchDev& b, const SchemeDev& sc, const uint32_t pairs, int32_t* scores, uint2* sinks,
+                             const uint32_t* job_list, const uint32_t* job_count, hipStream_t s)
+{
+    const dim3 grid( (pairs + 127u) / 128u ), block( 128 );
+    const bool two = (b.algo & NVBIO_ALN_PK_THREE_WAVES) == 0;
+    if (TYPE != NVBIO_LOCAL && sc.match == 0)
+    {
+        constexpr int T = (TYPE == NVBIO_LOCAL) ? NVBIO_SEMI_GLOBAL : TYPE;      // (never LOCAL here: keeps that instantiation out)
+        if (two) hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        else     hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,3,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+    }
+    else
+    {
+        if (two) hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,2,false>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        else     hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,3,false>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+    }
+}
+
 template <int TYPE, int RB>
 static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
@@ -926,24 +1003,14 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
         {
-            if (b.algo & NVBIO_ALN_PK_TWO_WAVES)
-                hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,2>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                                    (const uint32_t*)job_list, (const uint32_t*)job_count );
-            else
-                hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,3>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                                    (const uint32_t*)job_list, (const uint32_t*)job_count );
+            launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, job_list, job_count, s );
         }
         (void)hipFreeAsync( aux, s );
         if (e != hipSuccess) { set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
         NVB_HIP( hipGetLastError() );
         return NVBIO_OK;
     }
-    if (b.algo & NVBIO_ALN_PK_TWO_WAVES)
-        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,2>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
-    else
-        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<TYPE,RB,3>), dim3( (pairs + 127u) / 128u ), dim3( 128 ), 0, s, b, sc, scores, sinks,
-                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+    launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, nullptr, nullptr, s );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out
 FAST="--steps 5 --warmup 2 --no-cpu-baseline --no-traceback"
 run() { tag=$1; shift; timeout -k 10 280 python3 $REPO/bench.py $FAST "$@" > $OUT/ab_$tag.json 2> $OUT/ab_$tag.err; echo "$tag done: $(python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/ab_$tag.json') if l.startswith('{')][0]); print(round(d['ms_per_step'],3), {k:round(v,2) for k,v in d['stage_ms'].items()})")"; }
 run base
-run two_waves --pk-two-waves
+run three_waves --pk-three-waves
 run with_tb --with-traceback
 run breakdown --build-breakdown --no-plain-ab
 run k16 --kmer 16 --no-plain-ab
