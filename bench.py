@@ -30,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+GPU_CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
+DP_ROW_INSTRUCTIONS = 360            # banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4,2,true>: instructions of one pass through the row loop (profiles/r02h_pk_row_loop.s)
 SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
 TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
 SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"            # the per-strand pass (--no-canonical)
@@ -489,7 +491,13 @@ def main():
                    # GCUPS of the DP kernel itself: the A/B run below, where the DP computes every cell of every candidate
                    "gcups": plain.get("extend_gcups") if plain else None,
                    # cells of the full band DP / time of the step's extension stage, in which the exact shortcuts settle most candidates
-                   "effective_gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0},
+                   "effective_gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0,
+                   # what bounds the DP kernel: VALU issue.  One row of a wave = 64 lanes x 2 alignments x 31 cells in DP_ROW_INSTRUCTIONS
+                   # instructions (the row loop's listing: profiles/r02h_pk_row_loop.s), 4 cycles each on a 16-lane SIMD, 1024 SIMDs
+                   "dp_issue_bound": (lambda peak: {"instructions_per_row": DP_ROW_INSTRUCTIONS, "cells_per_wave_row": 64 * 2 * 31,
+                                                     "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": GPU_CLOCK_GHZ, "peak_gcups": peak,
+                                                     "frac": (plain.get("extend_gcups") / peak) if plain and plain.get("extend_gcups") else None})(
+                                          64 * 2 * 31 / (DP_ROW_INSTRUCTIONS * 4.0) * 1024 * GPU_CLOCK_GHZ)},
         "traceback": tb_info,
         "mapq": ({"evaluator": "BowtieMapq2 over (best, second best) of nvBowtie's score_reduce; inside the timed step (stage_ms.mapq)",
                   "second_alignment_fraction": float((extras["second"] != 0).float().mean()),

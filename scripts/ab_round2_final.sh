@@ -6,6 +6,7 @@ OUT=$REPO/gpurun_out
 FAST="--steps 6 --warmup 2 --no-cpu-baseline --no-traceback --no-plain-ab"
 run() { tag=$1; shift; timeout -k 10 280 python3 $REPO/bench.py $FAST "$@" > $OUT/abf_$tag.json 2> $OUT/abf_$tag.err || { echo "$tag FAILED"; tail -2 $OUT/abf_$tag.err; return 1; }; echo "$tag done: $(python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/abf_$tag.json') if l.startswith('{')][0]); print(round(d['ms_per_step'],3), {k:round(v,2) for k,v in d['stage_ms'].items()})")"; }
 run default &&
+run three_waves --pk-three-waves &&
 run narrow_entries --no-wide-table &&
 run per_strand --no-canonical &&
 run with_tb --with-traceback &&
