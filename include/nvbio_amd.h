@@ -741,6 +741,19 @@ nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, c
                                         uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
                                         uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
 
+/* The same for the linear-gap SmithWatermanAligner (and the EditDistanceAligner's scheme (0, -1, -1, -1)), deletion and insertion costs
+ * unequal or not: aln::alignment_traceback<MAX_PATTERN_LEN, MAX_TEXT_LEN, CHECKPOINTS>( SmithWatermanAligner<type>, ... )
+ * (nvbio/alignment/alignment_inl.h:355-517 over sw/sw_inl.h:306-392 -- the direction of a cell, SINK where a LOCAL score is 0 --,
+ * :1476-1600 -- checkpoints and submatrices, swept in stripes of 16 pattern columns -- and its walk, :1644-1694).  Score and sink are
+ * those of nvbio_full_sw_score with text_blocking = 0 (run here unless NVBIO_TRACEBACK_SINKS_GIVEN); scratch as
+ * nvbio_full_gotoh_traceback_temp_bytes. */
+nvbio_status nvbio_full_sw_traceback(int device, nvbio_alignment_type type, const nvbio_sw_scheme* scheme,
+                                     const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                     const int32_t* min_scores_dev,
+                                     int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                     uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                     uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream);
+
 /* nvBowtie finish_alignment (nvBowtie/bowtie2/cuda/traceback_inl.h:536-705) for a batch that has been traced back by
  * either traceback call: from each job's CIGAR (as written by the traceback: backtracking order), its read as aligned and
  * its text window,

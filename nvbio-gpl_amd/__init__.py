@@ -749,8 +749,10 @@ class BatchedAlignmentTraceback:
         bs = batch.c_struct()
         if temp is None and n:
             temp = _scratch(dev, self.min_temp_storage(batch, max_pattern_len, max_text_len))
-        _check(lib().nvbio_full_gotoh_traceback(
-            FMIndex._dev_index(dev), ctypes.c_int(self.aligner.type), ctypes.byref(self.aligner.scheme.c), ctypes.byref(bs),
+        sw = getattr(self.aligner, "sw", None)                      # the linear-gap Smith-Waterman / edit-distance aligners
+        fn = lib().nvbio_full_sw_traceback if sw is not None else lib().nvbio_full_gotoh_traceback
+        _check(fn(
+            FMIndex._dev_index(dev), ctypes.c_int(self.aligner.type), ctypes.byref(sw.c if sw is not None else self.aligner.scheme.c), ctypes.byref(bs),
             ctypes.c_uint32(max_pattern_len), ctypes.c_uint32(max_text_len), _ptr(ms), _ptr(scores), _ptr(sources), _ptr(sinks),
             _ptr(cigars), ctypes.c_uint32(cigar_stride), _ptr(lens), ctypes.c_uint32(TRACEBACK_SINKS_GIVEN if given else 0),
             _ptr(temp), ctypes.c_uint64(0 if temp is None else temp.numel() * temp.element_size()), _stream_ptr(dev)))

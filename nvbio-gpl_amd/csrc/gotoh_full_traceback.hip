@@ -64,7 +64,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
                             const int32_t* __restrict__ min_scores, uint32_t* __restrict__ column, uint32_t* __restrict__ dirs,
                             int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
                             uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens,
-                            const uint8_t* __restrict__ band_code = nullptr)
+                            const uint8_t* __restrict__ band_code = nullptr, const uint32_t given_sinks = 0u)
 {
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
@@ -74,6 +74,14 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
     if (t >= jobs) return;
     if (job_list && job_begin + t >= *job_count) return;
     const uint32_t job = job_list ? job_list[job_begin + t] : job_begin + t;
+    // given_sinks (the linear-gap Smith-Waterman aligner): score and sink are the scoring pass's -- which sweeps the matrix in its own
+    // logical stripes of 16 columns (sw/sw_inl.h:1322-1325), what decides LOCAL ties and the early exit -- and this kernel only has to
+    // supply the direction vectors, which do not depend on the sweep
+    if (given_sinks && (sinks[job].x == 0xFFFFFFFFu || sinks[job].y == 0xFFFFFFFFu))
+    {
+        sources[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); cigar_lens[job] = 0;
+        return;
+    }
     const JobInfo J = load_job( b, job );
     const uint32_t M = J.M, N = J.N;
     const int32_t min_score = min_scores ? min_scores[job] : NVBIO_SCORE_MIN;
@@ -87,8 +95,12 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
 
     SymbolReader<TBITS> trd( b.text );
     SymbolReader<RBITS> prd( b.reads );
-    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
-    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;             // F: the text advances alone
+    const int32_t I_o = sc.ins_go, I_e = sc.ins_ge;             // E: the pattern advances alone (= G for the Gotoh aligner; the Smith-Waterman
+                                                                // aligner's insertion, sw/sw_inl.h:628-629), T_*: the stripe-top boundary
+    const int32_t T_o = sc.top_go, T_e = sc.top_ge;
+    const int32_t g_min = G_o < G_e ? G_o : G_e, i_min = I_o < I_e ? I_o : I_e;
+    const int32_t infimum = -32768 - (g_min < i_min ? g_min : i_min);
     const int32_t V = sc.match;
     const uint32_t nst = (max_M + STRIPE - 1u) / STRIPE;        // direction words per text row
 
@@ -152,7 +164,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         #pragma unroll
         for (int j = 0; j <= STRIPE; ++j)
         {
-            H[j] = (TYPE != NVBIO_LOCAL) ? ((block + j > 0) ? G_o + G_e * (int32_t)(block + j - 1u) : 0) : 0;
+            H[j] = (TYPE != NVBIO_LOCAL) ? ((block + j > 0) ? T_o + T_e * (int32_t)(block + j - 1u) : 0) : 0;
             F[j] = infimum;
         }
         int32_t max_score = NVBIO_SCORE_MIN;
@@ -194,7 +206,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
             {
                 const int32_t ftop = F[j] + G_e, htop = H[j] + G_o;
                 F[j] = max2( ftop, htop );
-                const int32_t eleft = E + G_e, hleft = H[j - 1] + G_o;
+                const int32_t eleft = E + I_e, hleft = H[j - 1] + I_o;
                 E = max2( eleft, hleft );
                 const int32_t d = H_diag + ((c_sym[j - 1] == r_sym) ? V : c_mm[j - 1]);
                 const int32_t top = F[j], left = E;
@@ -223,7 +235,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
                 sink.report( v, i + 1u, M );
             }
         }
-        if (!last && !restricted)
+        if (!last && !restricted && !given_sinks)
         {
             const int32_t missing = (int32_t)(M - block - STRIPE);
             if (max_score + missing * V < min_score) ok = false;
@@ -237,6 +249,7 @@ full_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32_t
         sink.report( v, N, M );
     }
 
+    if (given_sinks) { sink.score = scores[job]; sink.x = sinks[job].x; sink.y = sinks[job].y; }
     scores[job] = sink.score;
     sinks[job]  = make_uint2( sink.x, sink.y );
     if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu)
@@ -460,14 +473,18 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback_temp_bytes(const nvbio_alignm
     return NVBIO_OK;
 }
 
-extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, const nvbio_gotoh_scheme* scheme,
-                                                   const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
-                                                   const int32_t* min_scores_dev,
-                                                   int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
-                                                   uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
-                                                   uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+// gotoh != NULL: the Gotoh aligner; sw != NULL: the linear-gap Smith-Waterman / edit-distance aligner (deletion and insertion may differ)
+static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, const nvbio_gotoh_scheme* gotoh, const nvbio_sw_scheme* sw,
+                                        const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                        const int32_t* min_scores_dev,
+                                        int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                        uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                        uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
 {
-    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    NVB_REQUIRE( gotoh != nullptr || sw != nullptr, "scheme is NULL" );
+    nvbio_gotoh_scheme as_gotoh;                                 // the magnitudes of the scheme, for the int16 bound below
+    if (sw) as_gotoh = nvbio_gotoh_scheme{ sw->match, -sw->mismatch, -sw->mismatch, sw->deletion, sw->deletion, sw->insertion, sw->insertion };
+    const nvbio_gotoh_scheme* scheme = gotoh ? gotoh : &as_gotoh;
     BatchDev b; NVB_CHECK( make_batch( batch, &b ) );
     if (b.n == 0) return NVBIO_OK;
     NVB_REQUIRE( type == NVBIO_GLOBAL || type == NVBIO_LOCAL || type == NVBIO_SEMI_GLOBAL, "invalid alignment type" );
@@ -487,11 +504,16 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     }
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    const SchemeDev sc = scheme_dev( scheme );
+    const SchemeDev sc = sw ? scheme_dev( sw, false ) : scheme_dev( gotoh );
     const uint32_t rb = batch->read_bits, tbits = batch->text_bits;
 
     // ---- 1. scoring pass (pattern blocking) unless handed over; 2. the ungapped shortcut; 3. job list ----
-    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK);
+    // (Smith-Waterman aligner: score and sink always come from its own scoring pass -- the kernel below is told so -- and every job
+    // takes the DP: the shortcut's tie rules are the Gotoh aligner's)
+    if (sw && !(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
+        NVB_CHECK( nvbio_full_sw_score( device, type, 0, sw, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sinks_dev,
+                                        nullptr, 0, stream ) );
+    const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK) && !sw;
     uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr; uint8_t* need_dp = nullptr;
     // the row-restricted DP applies to nvBowtie's end-to-end mode (see full_gotoh_traceback_kernel)
     const int32_t go_min = -(sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go), ge_min = -(sc.pat_ge > sc.txt_ge ? sc.pat_ge : sc.txt_ge);
@@ -500,7 +522,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     if (shortcut)
     {
         if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
-            NVB_CHECK( nvbio_full_gotoh_score( device, type, 0, scheme, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sinks_dev,
+            NVB_CHECK( nvbio_full_gotoh_score( device, type, 0, gotoh, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sinks_dev,
                                                nullptr, 0, stream ) );
         size_t sel_bytes = 0;
         hipcub::CountingInputIterator<uint32_t> ids( 0u );
@@ -569,7 +591,7 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
         const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
 #define NVB_TB(TYPE_, RB, TB) hipLaunchKernelGGL( (full_gotoh_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)begin, jobs, \
                                                   (const uint32_t*)job_list, (const uint32_t*)job_count, min_scores_dev, column, dirs, scores_dev, (uint2*)sources_dev, \
-                                                  (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, (const uint8_t*)(narrow ? need_dp : nullptr) )
+                                                  (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, (const uint8_t*)(narrow ? need_dp : nullptr), sw ? 1u : 0u )
 #define NVB_TB_BITS(TYPE_) \
         if      (rb == 4 && tbits == 2) NVB_TB( TYPE_, 4, 2 ); else if (rb == 2 && tbits == 2) NVB_TB( TYPE_, 2, 2 ); \
         else if (rb == 8 && tbits == 2) NVB_TB( TYPE_, 8, 2 ); else if (rb == 8 && tbits == 8) NVB_TB( TYPE_, 8, 8 ); \
@@ -582,4 +604,28 @@ extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_t
     if (owned) (void)hipFreeAsync( owned, s );
     if (aux)   (void)hipFreeAsync( aux, s );
     return st;
+}
+
+extern "C" nvbio_status nvbio_full_gotoh_traceback(int device, nvbio_alignment_type type, const nvbio_gotoh_scheme* scheme,
+                                                   const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                                   const int32_t* min_scores_dev,
+                                                   int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                   uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                   uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    return full_traceback_impl( device, type, scheme, nullptr, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sources_dev, sinks_dev,
+                                cigars_dev, cigar_stride, cigar_lens_dev, flags, temp_dev, temp_bytes, stream );
+}
+
+extern "C" nvbio_status nvbio_full_sw_traceback(int device, nvbio_alignment_type type, const nvbio_sw_scheme* scheme,
+                                                const nvbio_alignment_batch* batch, uint32_t max_pattern_len, uint32_t max_text_len,
+                                                const int32_t* min_scores_dev,
+                                                int32_t* scores_dev, nvbio_uint2* sources_dev, nvbio_uint2* sinks_dev,
+                                                uint16_t* cigars_dev, uint32_t cigar_stride, uint32_t* cigar_lens_dev,
+                                                uint32_t flags, void* temp_dev, uint64_t temp_bytes, void* stream)
+{
+    NVB_REQUIRE( scheme != nullptr, "scheme is NULL" );
+    return full_traceback_impl( device, type, nullptr, scheme, batch, max_pattern_len, max_text_len, min_scores_dev, scores_dev, sources_dev, sinks_dev,
+                                cigars_dev, cigar_stride, cigar_lens_dev, flags, temp_dev, temp_bytes, stream );
 }

@@ -385,6 +385,14 @@ template <AlignmentType T, typename S>
 nvbio_status banded_traceback(const SmithWatermanAligner<T,S>& a, int device, uint32_t band, const nvbio_alignment_batch* b, int32_t* sc, nvbio_uint2* src, nvbio_uint2* sk,
                               uint16_t* cig, uint32_t stride, uint32_t* lens, uint32_t flags, void* temp, uint64_t temp_size, hipStream_t s)
 { const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_banded_sw_traceback( device, band, (nvbio_alignment_type)T, &f, b, sc, src, sk, cig, stride, lens, flags, temp, temp_size, s ); }
+template <AlignmentType T, typename S>
+nvbio_status full_traceback(const GotohAligner<T,S>& a, int device, const nvbio_alignment_batch* b, uint32_t mp, uint32_t mt, const int32_t* ms, int32_t* sc, nvbio_uint2* src,
+                            nvbio_uint2* sk, uint16_t* cig, uint32_t stride, uint32_t* lens, uint32_t flags, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_gotoh_scheme f = a.scheme.flat(); return nvbio_full_gotoh_traceback( device, (nvbio_alignment_type)T, &f, b, mp, mt, ms, sc, src, sk, cig, stride, lens, flags, temp, temp_size, s ); }
+template <AlignmentType T, typename S>
+nvbio_status full_traceback(const SmithWatermanAligner<T,S>& a, int device, const nvbio_alignment_batch* b, uint32_t mp, uint32_t mt, const int32_t* ms, int32_t* sc, nvbio_uint2* src,
+                            nvbio_uint2* sk, uint16_t* cig, uint32_t stride, uint32_t* lens, uint32_t flags, void* temp, uint64_t temp_size, hipStream_t s)
+{ const nvbio_sw_scheme f = a.scheme.flat_sw(); return nvbio_full_sw_traceback( device, (nvbio_alignment_type)T, &f, b, mp, mt, ms, sc, src, sk, cig, stride, lens, flags, temp, temp_size, s ); }
 } // namespace detail
 
 struct AmdDeviceScheduler {};
@@ -528,11 +536,10 @@ struct BatchedAlignmentTraceback
     void enact(stream_type stream, uint32_t max_pattern_len, uint32_t max_text_len, uint64_t temp_size = 0u, uint8_t* temp = nullptr,
                int device = 0, hipStream_t s = 0, const int32_t* min_scores_dev = nullptr)
     {
-        const nvbio_gotoh_scheme sc = stream.aligner().scheme.flat();
-        check( nvbio_full_gotoh_traceback( device, (nvbio_alignment_type)aligner_type::TYPE, &sc, &stream.batch(), max_pattern_len, max_text_len,
-                                           min_scores_dev, stream.scores(), stream.sources(), stream.sinks(), stream.cigars(),
-                                           stream.cigar_stride(), stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
-                                           temp, temp_size, s ) );
+        check( detail::full_traceback( stream.aligner(), device, &stream.batch(), max_pattern_len, max_text_len,
+                                       min_scores_dev, stream.scores(), stream.sources(), stream.sinks(), stream.cigars(),
+                                       stream.cigar_stride(), stream.cigar_lens(), stream.sinks_given() ? NVBIO_TRACEBACK_SINKS_GIVEN : 0u,
+                                       temp, temp_size, s ) );
     }
 };
 

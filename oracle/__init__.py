@@ -321,6 +321,19 @@ class Oracle:
         assert cl.value <= cap
         return ok, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), cig[:cl.value].copy()
 
+    def full_sw_traceback(self, typ, sw, pat, txt, min_score=SCORE_MIN, cap=4096):
+        """full-matrix traceback of the linear-gap Smith-Waterman aligner -> (traced, score, source, sink, cigar uint16[] in backtracking order)"""
+        pat, txt = _c8(pat), _c8(txt)
+        sw = np.ascontiguousarray(np.asarray(sw, dtype=np.int32))
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        cig = np.zeros(cap, dtype=np.uint16); cl = ctypes.c_uint32()
+        ok = self.lib.orc_full_sw_traceback(ctypes.c_int(typ), _p(sw, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                            ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p),
+                                            cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap), ctypes.byref(cl))
+        assert cl.value <= cap
+        return ok, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), cig[:cl.value].copy()
+
     def finish_alignment(self, pat, txt, cigar, cigar_offset, cap=1024):
         """nvBowtie finish_alignment: (edit distance, MDS bytes) of a traced alignment"""
         pat, txt = _c8(pat), _c8(txt)
@@ -799,6 +812,21 @@ class Reference:
         r = self.lib.ref_banded_sw_traceback(ctypes.c_uint32(band), ctypes.c_int(typ), _p(sw, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)),
                                              _p(txt, _u8p), ctypes.c_uint32(n_txt), ctypes.c_int32(SCORE_MIN), ctypes.byref(sc), _p(src, _u32p),
                                              _p(sk, _u32p), _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no), _p(clips, _u32p))
+        assert no.value <= cap
+        return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
+
+    def full_sw_traceback(self, typ, sw, pat, txt, min_score=SCORE_MIN, cap=8192):
+        """the reference's alignment_traceback<256,1024,64> for SmithWatermanAligner<TYPE> with a recording backtracer
+        -> (n_clip_calls, score, source, sink, ops uint8[] in backtracking order, (clip_before, clip_after))"""
+        pat, txt = _c8(pat), _c8(txt)
+        sw = np.ascontiguousarray(np.asarray(sw, dtype=np.int32))
+        sc = ctypes.c_int32()
+        src = np.zeros(2, dtype=np.uint32); sk = np.zeros(2, dtype=np.uint32)
+        ops = np.zeros(cap, dtype=np.uint8); clips = np.zeros(2, dtype=np.uint32)
+        no = ctypes.c_uint32()
+        r = self.lib.ref_full_sw_traceback(ctypes.c_int(typ), _p(sw, _i32p), _p(pat, _u8p), ctypes.c_uint32(len(pat)), _p(txt, _u8p),
+                                           ctypes.c_uint32(len(txt)), ctypes.c_int32(min_score), ctypes.byref(sc), _p(src, _u32p), _p(sk, _u32p),
+                                           _p(ops, _u8p), ctypes.c_uint32(cap), ctypes.byref(no), _p(clips, _u32p))
         assert no.value <= cap
         return r, sc.value, (int(src[0]), int(src[1])), (int(sk[0]), int(sk[1])), ops[:no.value].copy(), (int(clips[0]), int(clips[1]))
 

@@ -971,8 +971,11 @@ int orc_banded_sw_traceback(uint32_t B, int type, const int32_t sw[4], const uin
 }
 
 #define SW_STRIPE 16u
-int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
-                int32_t min_score, int32_t* score, uint32_t sink_out[2])
+/* dirs (pattern blocking only, may be NULL): the flow of cell (text row i, pattern column c) at dirs[i*M + c] -- 0 SUBSTITUTION,
+ * 1 INSERTION, 2 DELETION, 3 SINK (a LOCAL cell of score 0), as SWSubmatrixContext::new_cell stores it (sw/sw_inl.h:371-388) from the
+ * comparison of sw_alignment_score_dispatch (:484-490) */
+static int full_sw_core(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                        int32_t min_score, int32_t* score, uint32_t sink_out[2], uint8_t* dirs)
 {
     best_sink sink; sink_init( &sink );
     const int32_t V = sw[0], S = sw[1], G = sw[2], I = sw[3];
@@ -1008,9 +1011,15 @@ int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat,
             for (uint32_t j = 1; j <= SW_STRIPE; ++j)
             {
                 const int32_t d  = prev + (c_cache[j-1] == r ? V : S);
-                int32_t       hi = imax( imax( band[j] + top_c, band[j-1] + left_c ), d );
+                const int32_t top = band[j] + top_c, left = band[j-1] + left_c;
+                int32_t       hi = imax( imax( top, left ), d );
                 if (type == ORC_LOCAL) hi = imax( hi, 0 );
                 prev = band[j]; band[j] = hi;
+                if (dirs && !blocking && block + j <= M)
+                {
+                    const uint8_t dir = top > left ? (top > d ? 2u : 0u) : (left > d ? 1u : 0u);
+                    dirs[(size_t)i * M + (block + j - 1u)] = (type == ORC_LOCAL && hi == 0) ? 3u : dir;
+                }
             }
             temp[i] = (int16_t)band[SW_STRIPE];
             max_score = imax( max_score, band[SW_STRIPE] );
@@ -1046,6 +1055,55 @@ int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat,
     free( temp );
     *score = sink.score; sink_out[0] = sink.x; sink_out[1] = sink.y;
     return ok;
+}
+
+int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
+                int32_t min_score, int32_t* score, uint32_t sink_out[2])
+{
+    return full_sw_core( type, blocking, sw, pat, M, txt, N, min_score, score, sink_out, NULL );
+}
+
+/* Full-matrix traceback of the linear-gap Smith-Waterman aligner: aln::alignment_traceback<..>( SmithWatermanAligner<type>, .. )
+ * (nvbio/alignment/alignment_inl.h:355-455: score pass with checkpoints, clip, walk, implicit first row / column, clip) over
+ * sw/sw_inl.h:1476-1600 (checkpoints every 64 pattern columns, the flow submatrix between two of them) and the walk :1644-1694:
+ * one state, DELETION moves along the text only, INSERTION along the pattern only, a LOCAL walk stops at a SINK cell.
+ * Outputs as orc_full_gotoh_traceback.  (The reference recomputes the submatrices from int16 checkpoints; equal to the single pass
+ * here while every score fits int16.) */
+int orc_full_sw_traceback(int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                          int32_t* score, uint32_t source[2], uint32_t sink_out[2], uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len)
+{
+    uint8_t* dirs = (uint8_t*)malloc( (size_t)(N ? N : 1) * (M ? M : 1) );
+    uint32_t best[2];
+    full_sw_core( type, 0, sw, pat, M, txt, N, min_score, score, best, dirs );
+    sink_out[0] = sink_out[1] = source[0] = source[1] = 0xFFFFFFFFu; *cigar_len = 0;
+    if (best[0] == 0xFFFFFFFFu || best[1] == 0xFFFFFFFFu) { free( dirs ); return 0; }
+    sink_out[0] = best[0]; sink_out[1] = best[1];
+
+    uint32_t clen = 0; int prev = 255;
+#define CIG_PUSH(type_, len_) do { if (clen < cigar_cap) cigar[clen] = (uint16_t)((type_) | ((len_) << 2)); ++clen; } while (0)
+#define OP_PUSH(op_) do { if (prev == (int)(op_)) { if (clen - 1 < cigar_cap) cigar[clen-1] += 4; } else { CIG_PUSH( op_, 1u ); prev = (int)(op_); } } while (0)
+    if (M - best[1]) CIG_PUSH( 3u, M - best[1] );
+    int32_t row = (int32_t)best[0], col = (int32_t)best[1] - 1;
+    while (row > 0 && col >= 0)
+    {
+        const uint8_t op = dirs[(size_t)(row - 1) * M + col];
+        if (type == ORC_LOCAL && op == 3u) break;
+        if (op != 2u) --col;
+        if (op != 1u) --row;
+        OP_PUSH( op );
+    }
+    uint32_t sx = (uint32_t)row, sy = (uint32_t)(col + 1);
+    if (type == ORC_SEMI_GLOBAL || type == ORC_GLOBAL)                       /* the implicit first row (alignment_inl.h:437-445) */
+        if (sx == 0) for (; sy > 0; --sy) OP_PUSH( 1u );
+    if (type == ORC_GLOBAL)                                                  /* ... and first column (:446-452) */
+        if (sy == 0) for (; sx > 0; --sx) OP_PUSH( 2u );
+    if (sy) CIG_PUSH( 3u, sy );
+#undef OP_PUSH
+#undef CIG_PUSH
+    source[0] = sx; source[1] = sy;
+    *cigar_len = clen;
+    free( dirs );
+    return 1;
 }
 
 /* the same two DPs reporting into a Best2Sink<int32>( distinct_dist ): out = { score1, sink1.x, sink1.y, score2, sink2.x, sink2.y } */

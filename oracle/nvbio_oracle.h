@@ -184,6 +184,9 @@ int orc_banded_sw(uint32_t band, int type, const int32_t sw[4], const uint8_t* p
                   int32_t* score, uint32_t sink[2]);
 int orc_banded_sw_traceback(uint32_t band, int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                             int32_t* score, uint32_t source[2], uint32_t sink[2], uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len);
+/* full-matrix traceback of the linear-gap Smith-Waterman aligner (pattern blocking); outputs as orc_full_gotoh_traceback */
+int orc_full_sw_traceback(int type, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                          int32_t* score, uint32_t source[2], uint32_t sink[2], uint16_t* cigar, uint32_t cigar_cap, uint32_t* cigar_len);
 int orc_full_sw(int type, int blocking, const int32_t sw[4], const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N,
                 int32_t min_score, int32_t* score, uint32_t sink[2]);
 int orc_full_gotoh(int type, int blocking, const orc_gotoh_scheme* s,

@@ -555,6 +555,24 @@ int banded_sw_tb_type(int type, const aln::SimpleSmithWatermanScheme& scheme, co
     return -1;
 }
 
+// the full-matrix traceback of the linear-gap Smith-Waterman aligner: aln::alignment_traceback<256,1024,64>( SmithWatermanAligner<TYPE>, ... )
+// (nvbio/alignment/alignment_inl.h:478-517 -> :355-455 over sw/sw_inl.h:1476-1694); outputs as ref_full_gotoh_traceback_ex
+template <aln::AlignmentType TYPE>
+int full_sw_tb_run(const aln::SimpleSmithWatermanScheme& scheme, const uint8* pat, uint32 M, const uint8* txt, uint32 N, int32 min_score,
+                   int32* score, uint32* source, uint32* sink, RecordingBacktracer& bt)
+{
+    typedef vector_view<const uint8*> string_type;
+    const aln::Alignment<int32> a = aln::alignment_traceback<256u,1024u,64u>(
+        aln::make_smith_waterman_aligner<TYPE>( scheme ),
+        string_type( M, pat ),
+        aln::trivial_quality_string(),
+        string_type( N, txt ),
+        min_score,
+        bt );
+    *score = a.score; source[0] = a.source.x; source[1] = a.source.y; sink[0] = a.sink.x; sink[1] = a.sink.y;
+    return (int)bt.n_clips;
+}
+
 extern "C" {
 
 // Build an FM-index over text[0,n) (one 2-bit symbol per byte) exactly as
@@ -865,6 +883,25 @@ int ref_banded_sw_traceback(uint32_t band, int type, const int32_t* sw,
     case 7:  r = banded_sw_tb_type<7> ( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
     case 15: r = banded_sw_tb_type<15>( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
     case 31: r = banded_sw_tb_type<31>( type, scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    }
+    *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
+    return r;
+}
+
+// the full-matrix traceback of the linear-gap Smith-Waterman aligner (full_sw_tb_run above; M <= 256, N <= 1024);
+// sw[4] = { match, mismatch, deletion, insertion }
+int ref_full_sw_traceback(int type, const int32_t* sw, const uint8_t* pat, uint32_t M, const uint8_t* txt, uint32_t N, int32_t min_score,
+                          int32_t* score, uint32_t* source, uint32_t* sink, uint8_t* ops, uint32_t cap, uint32_t* n_ops, uint32_t* clips)
+{
+    if (M > 256u || N > 1024u) return -1;
+    const aln::SimpleSmithWatermanScheme scheme( sw[0], sw[1], sw[2], sw[3] );
+    RecordingBacktracer bt; bt.ops = ops; bt.cap = cap; bt.n = 0; bt.n_clips = 0; bt.clips[0] = bt.clips[1] = 0;
+    int r = -1;
+    switch (type)
+    {
+    case 0: r = full_sw_tb_run<aln::GLOBAL>     ( scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    case 1: r = full_sw_tb_run<aln::LOCAL>      ( scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
+    case 2: r = full_sw_tb_run<aln::SEMI_GLOBAL>( scheme, pat, M, txt, N, min_score, score, source, sink, bt ); break;
     }
     *n_ops = bt.n; clips[0] = bt.clips[0]; clips[1] = bt.clips[1];
     return r;

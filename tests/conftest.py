@@ -82,6 +82,11 @@ def swtb_golden():
 
 
 @pytest.fixture(scope="session")
+def fswtb_golden():
+    return np.load(os.path.join(GOLDEN, "fswtb_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def staged_golden():
     return np.load(os.path.join(GOLDEN, "staged_golden.npz"), allow_pickle=False)
 

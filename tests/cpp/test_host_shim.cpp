@@ -232,6 +232,31 @@ int main()
         }
         printf( "host shim: %u full-matrix tracebacks equal to the oracle\n", J );
     }
+    // ... and of the linear-gap Smith-Waterman aligner with deletion != insertion (end-to-end): nvbio_full_sw_traceback behind the same class
+    {
+        const uint32_t STRIDE = 48;
+        const aln::SimpleSmithWatermanScheme sws( 2, -3, -5, -2 );
+        const int32_t swv[4] = { 2, -3, -5, -2 };
+        device_vector<nvbio_uint2> d_src( J ); device_vector<uint16_t> d_cig( (size_t)J * STRIDE ); device_vector<uint32_t> d_len( J );
+        typedef aln::SmithWatermanAligner<aln::SEMI_GLOBAL,aln::SimpleSmithWatermanScheme> aligner_t;
+        typedef aln::FlatTracebackStream<aligner_t> stream_t;
+        aln::BatchedAlignmentTraceback<64,stream_t> tb;
+        tb.enact( stream_t( aln::make_smith_waterman_aligner<aln::SEMI_GLOBAL>( sws ), batch, d_scores.data(), d_src.data(), d_sinks.data(),
+                            d_cig.data(), STRIDE, d_len.data() ), M, M + 31 );
+        check_hip( hipDeviceSynchronize(), "sync" );
+        std::vector<int32_t> sc = d_scores.to_host(); std::vector<nvbio_uint2> sk = d_sinks.to_host(), so = d_src.to_host();
+        std::vector<uint16_t> cg = d_cig.to_host(); std::vector<uint32_t> ln = d_len.to_host();
+        uint32_t gapped = 0;
+        for (uint32_t j = 0; j < J; ++j)
+        {
+            int32_t ws; uint32_t wsrc[2], wsnk[2], wl; uint16_t wc[STRIDE];
+            orc_full_sw_traceback( 2, swv, &pats[j*M], M, &text[wb[j]], we[j] - wb[j], -(1 << 30), &ws, wsrc, wsnk, wc, STRIDE, &wl );
+            REQUIRE( sc[j] == ws && sk[j].x == wsnk[0] && sk[j].y == wsnk[1] && so[j].x == wsrc[0] && so[j].y == wsrc[1] && ln[j] == wl );
+            for (uint32_t k = 0; k < wl && k < STRIDE; ++k) REQUIRE( cg[(size_t)j*STRIDE + k] == wc[k] );
+            gapped += wl > 1;
+        }
+        printf( "host shim: %u full-matrix Smith-Waterman tracebacks equal to the oracle (%u with more than one CIGAR run)\n", J, gapped );
+    }
     // error behaviour: an unsupported band throws with the C-ABI status
     bool threw = false;
     try { aln::batch_banded_alignment_score<9>( aln::make_gotoh_aligner<aln::LOCAL>( scheme ), batch, d_scores.data(), d_sinks.data() ); }

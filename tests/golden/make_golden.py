@@ -595,7 +595,61 @@ def make_swtb(R):
     print("swtb_golden.npz: %d cases, %d traced, %d cigar elements" % (len(cases), int(out[:, 0].sum()), int(co[-1])))
 
 
+def fswtb_cases(seed=321):
+    """(type, scheme index, min_score, pattern, text) for the FULL-matrix traceback of the linear-gap Smith-Waterman aligner: patterns up
+    to 200 symbols (past one 64-column checkpoint and several 16-column stripes) somewhere inside texts up to 400, substitutions, indels
+    of 1-4 symbols, unrelated pairs, a 2-letter alphabet (ties everywhere), N's, texts shorter than the pattern, min_score limits that
+    stop the stripe sweep early"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(2000):
+        typ = int(rng.integers(0, 3))
+        M = int(rng.integers(1, 200)); N = int(rng.integers(M, 400)) if rng.random() < 0.9 else int(rng.integers(1, M + 1))
+        A = 2 if rng.random() < 0.2 else 4
+        txt = rng.integers(0, A, N).astype(np.uint8)
+        if N >= M and rng.random() < 0.8:
+            s0 = int(rng.integers(0, N - M + 1))
+            pat = txt[s0:s0 + M].copy()
+            mut = rng.random(M) < (0.03 if rng.random() < 0.6 else 0.25)
+            pat[mut] = rng.integers(0, A, int(mut.sum()))
+            if rng.random() < 0.5 and M > 12:
+                p_ = int(rng.integers(3, M - 3)); g = int(rng.integers(1, 5))
+                pat = (np.concatenate([pat[:p_], pat[p_ + g:], rng.integers(0, A, g).astype(np.uint8)]) if rng.random() < 0.5
+                       else np.concatenate([pat[:p_], rng.integers(0, A, g).astype(np.uint8), pat[p_:M - g]]))
+        else:
+            pat = rng.integers(0, A, M).astype(np.uint8)
+        if rng.random() < 0.1:
+            pat[rng.integers(0, M)] = 4
+        ms = oracle.SCORE_MIN if rng.random() < 0.7 else -int(rng.integers(0, 60))
+        cases.append((typ, int(rng.integers(0, len(SWTB_SCHEMES))), ms, pat, txt))
+    return cases
+
+
+def make_fswtb(R):
+    cases = fswtb_cases()
+    po = np.zeros(len(cases) + 1, dtype=np.uint32); to = np.zeros(len(cases) + 1, dtype=np.uint32)
+    out = np.zeros((len(cases), 6), dtype=np.int64); co = np.zeros(len(cases) + 1, dtype=np.uint32)
+    cigs = []
+    for k, (typ, si, ms, pat, txt) in enumerate(cases):
+        r, sc, src, snk, ops, clips = R.full_sw_traceback(typ, SWTB_SCHEMES[si], pat, txt, ms)
+        cig = oracle.cigar_from_ops(ops, clips[0], clips[1]) if r else np.zeros(0, np.uint16)
+        out[k] = (1 if r else 0, sc, src[0], src[1], snk[0], snk[1])
+        cigs.append(cig); co[k + 1] = co[k] + len(cig)
+        po[k + 1] = po[k] + len(pat); to[k + 1] = to[k] + len(txt)
+    np.savez_compressed(os.path.join(HERE, "fswtb_golden.npz"), typ=np.array([c[0] for c in cases], dtype=np.int32),
+                        scheme=np.array([c[1] for c in cases], dtype=np.int32), min_score=np.array([c[2] for c in cases], dtype=np.int64),
+                        schemes=np.array(SWTB_SCHEMES, dtype=np.int32), pats=np.concatenate([c[3] for c in cases]),
+                        txts=np.concatenate([c[4] for c in cases]), pat_off=po, txt_off=to, out=out, cig_off=co,
+                        cigars=np.concatenate(cigs).astype(np.uint16))
+    print("fswtb_golden.npz: %d cases, %d traced, %d cigar elements" % (len(cases), int(out[:, 0].sum()), int(co[-1])))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                            # python make_golden.py fswtb swtb ...: only these
+        R = oracle.Reference()
+        for name in sys.argv[1:]:
+            globals()["make_" + name](R)
+        sys.exit(0)
     if not oracle.Reference.available():
         oracle.build()
     R = oracle.Reference()
@@ -612,3 +666,4 @@ if __name__ == "__main__":
     make_myers(R)
     make_staged(R)
     make_swtb(R)
+    make_fswtb(R)

@@ -250,6 +250,43 @@ def test_full_traceback_golden(amd, dp_golden, ftb_golden, tb_mode):
     assert checked == n * 6 and traced > 1500
 
 
+def test_full_sw_traceback_golden(amd, fswtb_golden):
+    """nvbio_full_sw_traceback (the linear-gap Smith-Waterman / edit-distance aligners through BatchedAlignmentTraceback) against the
+    reference's own outputs (alignment_traceback<256,1024,64> over SmithWatermanAligner): scores, sources, sinks, CIGARs; unequal
+    deletion / insertion costs; LOCAL walks that stop at SINK cells; min_score limits; scores and sinks computed here and handed over"""
+    g = fswtb_golden
+    max_p = int(np.diff(g["pat_off"]).max()); max_t = int(np.diff(g["txt_off"]).max())
+    STRIDE = 128
+    seen = traced = 0
+    for typ in range(3):
+        for si in range(len(g["schemes"])):
+            sel = np.nonzero((g["typ"] == typ) & (g["scheme"] == si))[0].astype(np.uint32)
+            if len(sel) == 0:
+                continue
+            batch = amd.AlignmentBatch(g["pats"], 8, g["pat_off"], g["txts"], 8, g["txt_off"][sel], g["txt_off"][sel + 1], read_id=sel)
+            al = amd.make_smith_waterman_aligner(typ, amd.SimpleSmithWatermanScheme(*[int(v) for v in g["schemes"][si]]))
+            ms = g["min_score"][sel].astype(np.int32)
+            tb = amd.BatchedAlignmentTraceback(al)
+            outs = [tb.enact(batch, max_p, max_t, min_scores=ms, cigar_stride=STRIDE)]
+            # ... and with the scoring pass run by the caller (pattern blocking, as the traceback's own)
+            s0, k0 = amd.BatchedAlignmentScore(al, text_blocking=False).enact(batch, max_p, max_t, min_scores=ms)
+            outs.append(tb.enact(batch, max_p, max_t, min_scores=ms, cigar_stride=STRIDE, scores=s0, sinks=k0))
+            for sc, src, snk, cig, ln in outs:
+                sc, src, snk, ln = _i64(sc), amd.u32(src).astype(np.int64), amd.u32(snk).astype(np.int64), _i64(ln)
+                cig = cig.cpu().numpy().view(np.uint16)
+                for k, i in enumerate(sel):
+                    want = g["out"][i]
+                    assert sc[k] == want[1], (i, typ, si)
+                    if want[0]:
+                        lo, hi = int(g["cig_off"][i]), int(g["cig_off"][i + 1])
+                        assert tuple(src[k]) == (want[2], want[3]) and tuple(snk[k]) == (want[4], want[5]), (i, typ, si)
+                        assert ln[k] == hi - lo and np.array_equal(cig[k, :min(hi - lo, STRIDE)], g["cigars"][lo:lo + min(hi - lo, STRIDE)]), (i, typ, si)
+                    else:
+                        assert ln[k] == 0, (i, typ, si)
+            seen += len(sel); traced += int(g["out"][sel, 0].sum())
+    assert seen == len(g["typ"]) and traced > 1900
+
+
 @pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
 def test_full_traceback_opposite_mate_shape(amd, orc, typ, tb_mode):
     """4-bit reads (reversed / complemented, qualities) in 2-bit genome windows of 150-500 symbols, chunked scratch,

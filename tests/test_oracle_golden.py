@@ -578,3 +578,20 @@ def test_banded_sw_traceback_golden(orc, swtb_golden):
             assert src == (want[2], want[3]) and snk == (want[4], want[5]), k
             assert np.array_equal(cig, g["cigars"][g["cig_off"][k]:g["cig_off"][k + 1]]), k
     assert int(g["out"][:, 0].sum()) > 2000
+
+
+def test_full_sw_traceback_golden(orc, fswtb_golden):
+    """full-matrix traceback of the linear-gap Smith-Waterman aligner (alignment_inl.h:355-455 over sw/sw_inl.h:306-392,1476-1694; unequal
+    deletion / insertion costs, the edit-distance scheme, SINK cells of LOCAL walks, the stripe early exit) against the reference's own
+    outputs: 2,000 cases"""
+    g = fswtb_golden
+    for k in range(len(g["typ"])):
+        pat = g["pats"][g["pat_off"][k]:g["pat_off"][k + 1]]; txt = g["txts"][g["txt_off"][k]:g["txt_off"][k + 1]]
+        ok, sc, src, snk, cig = orc.full_sw_traceback(int(g["typ"][k]), g["schemes"][g["scheme"][k]], pat, txt, int(g["min_score"][k]))
+        want = g["out"][k]
+        assert ok == want[0] and sc == want[1], k
+        if ok:
+            assert src == (want[2], want[3]) and snk == (want[4], want[5]), k
+            assert np.array_equal(cig, g["cigars"][g["cig_off"][k]:g["cig_off"][k + 1]]), k
+    assert 1900 < int(g["out"][:, 0].sum()) < 2000
+
