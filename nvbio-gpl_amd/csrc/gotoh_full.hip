@@ -15,6 +15,7 @@
 // job-interleaved in HBM (element i of job t at [i * jobs + t]) so that the 64 lanes of a wave
 // read and write 256 contiguous bytes per row.
 #include "gotoh_common.h"
+#include <type_traits>
 #include "bitplanes.h"
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
@@ -382,27 +383,57 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
         {
             uint32_t lead_prev[4] = { 0, 0, 0, 0 }, tail_prev[4] = { 0, 0, 0, 0 };
             bool gapped = false;
+            // A pattern gap at an end of the read also lets the rest of it lie on a diagonal that is not wholly inside the window:
+            // e symbols of the read inserted before the window's first symbol (diagonal -e) or after its last one (diagonal
+            // N - M + e), e <= gmax.  Those 2 gmax diagonals take part like the others, their rows without a text symbol counting as
+            // mismatches: the ones before the window here, seeding lead / tail of "the diagonals before d", the ones after it at the end
+            // of the loop below.
+            #pragma unroll
+            for (int e = 4; e >= 1; --e)
+                if (e <= gmax)
+                {
+                    uint32_t last = 0;
+                    #pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                    {
+                        const uint32_t l = __builtin_amdgcn_alignbit( tl[k], k ? tl[k - 1] : 0u, 32u - (uint32_t)e );      // window symbol r - e at bit r
+                        const uint32_t h = __builtin_amdgcn_alignbit( th[k], k ? th[k - 1] : 0u, 32u - (uint32_t)e );
+                        uint32_t mm = (((pl[k] ^ l) | (ph[k] ^ h)) & pm[k]) | pn[k];
+                        if (k == 0) mm |= ((1u << e) - 1u) & pm[0];                      // rows 0 .. e-1 have no text symbol
+                        if (mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
+                    }
+                    const uint32_t tail = M - 1u - last;                                 // (row 0 always counts: `last` is defined)
+                    if (tail + (uint32_t)gmax >= M) gapped = true;                       // rows g .. M-1 match for some e <= g <= gmax
+                    #pragma unroll
+                    for (int k = 3; k > 0; --k) { lead_prev[k] = lead_prev[k - 1]; tail_prev[k] = tail_prev[k - 1]; }
+                    lead_prev[0] = 0u; tail_prev[0] = tail;
+                }
+            const uint32_t last_e = last_d + (uint32_t)gmax;                             // ... through the diagonals that end past the window
             #pragma unroll
             for (int wo = 0; wo < 17; ++wo)
             {
-                if ((uint32_t)wo * 32u > last_d || gapped) break;
+                if ((uint32_t)wo * 32u > last_e || gapped) break;
                 uint32_t ql[7], qh[7];
                 #pragma unroll
                 for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 18) ? tl[wo + k] : 0u; qh[k] = (wo + k < 18) ? th[wo + k] : 0u; }
-                const uint32_t d_end = ((uint32_t)wo * 32u + 31u < last_d) ? (uint32_t)wo * 32u + 31u : last_d;
+                const uint32_t d_end = ((uint32_t)wo * 32u + 31u < last_e) ? (uint32_t)wo * 32u + 31u : last_e;
                 for (uint32_t d = (uint32_t)wo * 32u; d <= d_end && !gapped; ++d)
                 {
+                    // rows fm .. M-1 of a diagonal past last_d have no text symbol: mismatches
+                    const uint32_t fm = d > last_d ? (d - last_d < M ? M - (d - last_d) : 0u) : M;
                     uint32_t first = M, last = 0xFFFFFFFFu;
                     #pragma unroll
                     for (int k = 5; k >= 0; --k)
                     {
-                        const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                        const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
+                        const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
                         if (mm) first = 32u * k + (uint32_t)__builtin_ctz( mm );
                     }
                     #pragma unroll
                     for (int k = 0; k < 6; ++k)
                     {
-                        const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+                        const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
+                        const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
                         if (mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
                     }
                     const uint32_t lead = first;
@@ -412,11 +443,9 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
                         if (g <= gmax)
                         {
                             if (lead + (uint32_t)g >= M || tail + (uint32_t)g >= M) gapped = true;      // pattern gap at an end of the read
-                            if (d >= (uint32_t)g)
-                            {
-                                if (lead_prev[g - 1] + tail >= M) gapped = true;
-                                if (lead + tail_prev[g - 1] + (uint32_t)g >= M) gapped = true;
-                            }
+                            // (diagonal d - g exists for every g <= gmax: the ones before the window were seeded above)
+                            if (lead_prev[g - 1] + tail >= M) gapped = true;
+                            if (lead + tail_prev[g - 1] + (uint32_t)g >= M) gapped = true;
                         }
                     #pragma unroll
                     for (int k = 3; k > 0; --k) { lead_prev[k] = lead_prev[k - 1]; tail_prev[k] = tail_prev[k - 1]; }
@@ -610,6 +639,237 @@ full_gotoh_pb_pk_kernel(const BatchDev b, const SchemeDev sc, const uint32_t M, 
         for (int j = 1; j <= STRIPE; ++j) if ((uint32_t)j == jm) v = H[j];
         if (alive[0]) sink[0].report( v.x, N, M );
         if (alive[1]) sink[1].report( v.y, N, M );
+    }
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (valid[u]) { scores[job[u]] = sink[u].score; sinks[job[u]] = make_uint2( sink[u].x, sink[u].y ); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same for the end-to-end case with a zero match bonus (SEMI_GLOBAL, match = 0: nvBowtie's opposite-mate scoring), swept in
+// stripes of SIXTEEN pattern columns: half the passes over the text, half the boundary-column traffic and half the per-row set-up per
+// cell.  The reference tests its early exit after every 8 columns (gotoh_inl.h:676-680): the running maximum of column 8 of the stripe
+// is kept beside that of column 16 and both tests are made at the stripe's end, in order -- nothing is reported before the last stripe,
+// so a job that the first test would have stopped simply loses what the last stripe reported.  With match = 0 the diagonal term is
+// one v_pk_mad_u16 on the mismatch flag; `Hg = H + GO` is kept beside `H` (it feeds F of the next row and E of the next column), and
+// the row is ordered by hand so that no packed operation is consumed by the instruction behind it (see banded_gotoh_band31_pk_kernel):
+// 10 issue slots per cell, against 13 + 3 idle ones, and 30 per row instead of 160 per 8 cells around them.
+// ---------------------------------------------------------------------------------------------
+// a packed pair from its 32-bit image (never element by element: see the note on the register arrays below)
+__device__ __forceinline__ v2s pkw(const int a, const int b) { return pk_bits( ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16) ); }
+
+template <int RBITS>
+__global__ void __launch_bounds__(128)
+full_gotoh_pb_pk16_kernel(const BatchDev b, const SchemeDev sc, const uint32_t M, const uint32_t N, const uint32_t pair_begin, const uint32_t pairs,
+                          const int32_t* __restrict__ min_scores, uint2* __restrict__ column, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
+                          const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
+{
+    constexpr int W = 16;
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // pair slot inside this launch
+    if (t >= pairs) return;
+    const uint32_t n_jobs = *job_count;
+    const uint32_t slot0 = 2u * (pair_begin + t);
+    if (slot0 >= n_jobs) return;
+
+    uint32_t job[2], first[2], tb[2]; bool rev[2], comp[2], valid[2]; int32_t min_score[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        valid[u] = slot0 + u < n_jobs;
+        job[u]   = job_list[valid[u] ? slot0 + u : slot0];
+        const uint32_t rid = b.read_id ? b.read_id[job[u]] : job[u];
+        first[u] = b.read_offsets[rid];
+        const uint32_t fl = b.flags ? b.flags[job[u]] : 0u;
+        rev[u]  = (fl & NVBIO_READ_REVERSE) != 0;
+        comp[u] = (fl & NVBIO_READ_COMPLEMENT) != 0;
+        tb[u]   = b.win_begin[job[u]];
+        min_score[u] = min_scores ? min_scores[job[u]] : NVBIO_SCORE_MIN;
+    }
+    SymbolReader<RBITS> prd0( b.reads ), prd1( b.reads );
+    const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
+
+    const int32_t G_o = sc.pat_go, G_e = sc.pat_ge;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    const v2s GO = pkw( G_o, G_o ), GE = pkw( G_e, G_e );
+    const v2s INF = pkw( infimum, infimum );
+
+    uint2* col = column + t;                                    // element i at col[i * pairs]: (cell of job 0, cell of job 1)
+    {
+        const uint32_t c = pack_cell( 0, infimum );             // GotohScoringContext::init (gotoh_inl.h:56-74), SEMI_GLOBAL
+        for (uint32_t i = 0; i < N; ++i) col[(size_t)i * pairs] = make_uint2( c, c );
+    }
+
+    Sink sink[2]; sink[0].init(); sink[1].init();
+    bool alive[2] = { true, true };
+    const uint32_t nb8 = (M + 7u) / 8u ? (M + 7u) / 8u : 1u;    // the reference's blocks of 8 columns
+    const uint32_t n16 = (nb8 + 1u) / 2u;
+    const uint32_t jm  = ((M - 1u) & (W - 1u)) + 1u;            // the pattern's last column inside the last stripe
+
+    // the text stream of a job: 16 rows per packed word, assembled from the two words that cover them (loaded one chunk ahead)
+    uint32_t t_lo[2], t_hi[2];
+    #pragma unroll
+    for (int u = 0; u < 2; ++u) { t_lo[u] = tb[u] >> 4; t_hi[u] = (tb[u] + (N ? N - 1u : 0u)) >> 4; }
+
+    // (register arrays of packed pairs are kept as 32-bit words: as 2 x i16 vectors the compiler splits them into halves wherever one
+    // element is read, and glues them back with a v_perm_b32 per use)
+    v2s c_mm[W];
+    #pragma unroll
+    for (int j = 0; j < W; ++j) c_mm[j] = pk_bits( 0u );
+    v2s H[W + 1], Hg[W + 1], F[W + 1];
+
+    for (uint32_t k = 0; k < n16 && (alive[0] || alive[1]); ++k)
+    {
+        const uint32_t block = k * W;
+        const bool last = (k + 1u == n16);
+        // the stripe's pattern symbols as bit planes (bit j = column block + j): low bit, high bit, "is N"
+        uint32_t p0[2] = { 0, 0 }, p1[2] = { 0, 0 }, pn[2] = { 0, 0 };
+        #pragma unroll
+        for (int j = 0; j < W; ++j)
+        {
+            if (block + j < M)
+            {
+                int mm2[2];
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t idx = rev[u] ? first[u] + M - 1u - (block + j) : first[u] + block + j;
+                    uint32_t q = u ? prd1.get( idx ) : prd0.get( idx );
+                    if (comp[u] && q < 4u) q = 3u - q;
+                    const uint32_t qq = b.quals ? b.quals[idx] : 0u;
+                    mm2[u] = s_mm[qq < 63u ? qq : 63u];
+                    p0[u] |= (q & 1u) << j; p1[u] |= ((q >> 1) & 1u) << j; pn[u] |= (q > 3u ? 1u : 0u) << j;
+                }
+                c_mm[j] = pk_bits( ((uint32_t)mm2[0] & 0xFFFFu) | ((uint32_t)mm2[1] << 16) );
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j <= W; ++j)
+        {
+            const int h0 = (block + j > 0) ? G_o + G_e * (int32_t)(block + j - 1u) : 0;     // :676-681
+            const uint32_t hb = ((uint32_t)h0 & 0xFFFFu) * 0x00010001u;
+            H[j] = pk_bits( hb ); Hg[j] = pk_bits( hb ) + GO; F[j] = INF;
+        }
+        v2s max_mid = pkw( -32768, -32768 ), max_end = pkw( -32768, -32768 );
+        v2s temp_i  = H[0];
+
+        uint32_t wa[2], wb2[2];
+        auto issue_text = [&](const uint32_t i0) {
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const uint32_t w = (tb[u] + i0) >> 4;
+                wa[u]  = twords[w     < t_hi[u] ? w      : t_hi[u]];
+                wb2[u] = twords[w + 1 < t_hi[u] ? w + 1u : t_hi[u]];
+            }
+        };
+        issue_text( 0 );
+        uint2 cell_next = col[0];
+
+        // the sweep over the text, compiled twice: only the last stripe reports (the pattern's last column, picked out of the row as it
+        // is computed -- reading it back out of the register array makes the compiler split the array into halves)
+        auto sweep = [&](auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        for (uint32_t i0 = 0; i0 < N; i0 += 16u)
+        {
+            uint32_t tw[2];
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const uint32_t sh = ((tb[u] + i0) & 15u) * 2u;
+                tw[u] = sh ? ((wa[u] << sh) | (wb2[u] >> (32u - sh))) : wa[u];
+            }
+            if (i0 + 16u < N) issue_text( i0 + 16u );
+            const uint32_t r_end = (i0 + 16u < N) ? 16u : N - i0;
+            for (uint32_t tt = 0; tt < r_end; ++tt)
+            {
+                const uint32_t i = i0 + tt;
+                const uint2 cell = cell_next;
+                if (i + 1u < N) cell_next = col[(size_t)(i + 1u) * pairs];
+                // the row's mismatch flags: bit j / 16+j of NW = column block+j of job 0 / 1 does NOT match
+                uint32_t nq[2];
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t r = tw[u] >> 30; tw[u] <<= 2;
+                    nq[u] = (p0[u] ^ (0u - (r & 1u))) | (p1[u] ^ (0u - (r >> 1))) | pn[u];
+                }
+                const uint32_t NW = __builtin_amdgcn_perm( nq[1], nq[0], 0x05040100u );
+                const v2s Hc = pk_bits( __builtin_amdgcn_perm( cell.y, cell.x, 0x05040100u ) );      // (H of job 0, H of job 1) of the boundary column
+                const v2s Ec = pk_bits( __builtin_amdgcn_perm( cell.y, cell.x, 0x07060302u ) );
+                const v2s Hd0 = temp_i;
+                temp_i = Hc;
+
+                // cell 1's off-chain part, cell 2's first three operations
+                v2s hg = Hc + GO, eg = Ec + GE, E, fd, x, tj, d, f, hsel = Hc;
+                {
+                    const v2s x1 = F[1] + GE;
+                    const v2s t1 = pk_bits( NW & 0x00010001u );
+                    const v2s d1 = Hd0 + t1 * c_mm[0];
+                    const v2s f1 = pk_max( x1, Hg[1] );
+                    F[1] = f1;
+                    fd = pk_max( f1, d1 );
+                    x  = F[2] + GE;
+                    tj = pk_bits( (NW >> 1) & 0x00010001u );
+                }
+                constexpr int Z = 0;
+                __builtin_amdgcn_sched_barrier( Z );
+                #pragma unroll
+                for (int j = 1; j <= W; ++j)
+                {
+                    // the E chain of column j (E -> h -> hg) interleaved with what column j+1 and j+2 can compute without it
+                    E = pk_max( eg, hg );
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j + 1 <= W) d = H[j] + tj * c_mm[j];                 // H[j] still is the previous row's
+                    __builtin_amdgcn_sched_barrier( Z );
+                    const v2s h = pk_max( fd, E );
+                    if (LAST && (uint32_t)j == jm) hsel = h;
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j + 1 <= W) f = pk_max( x, Hg[j + 1] );
+                    __builtin_amdgcn_sched_barrier( Z );
+                    hg = h + GO;
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j + 1 <= W) eg = E + GE;
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j + 1 <= W) fd = pk_max( f, d );
+                    __builtin_amdgcn_sched_barrier( Z );
+                    if (j + 2 <= W) x = F[j + 2] + GE;
+                    if (j + 2 <= W) tj = pk_bits( (NW >> (j + 1)) & 0x00010001u );
+                    H[j] = h; Hg[j] = hg;
+                    if (j + 1 <= W) F[j + 1] = f;
+                    __builtin_amdgcn_sched_barrier( Z );
+                }
+                // the stripe's last column goes to the boundary column: (H, E) of job 0, of job 1
+                col[(size_t)i * pairs] = make_uint2( __builtin_amdgcn_perm( bits_pk( E ), bits_pk( H[W] ), 0x05040100u ),
+                                                     __builtin_amdgcn_perm( bits_pk( E ), bits_pk( H[W] ), 0x07060302u ) );
+                max_end = pk_max( max_end, H[W] );
+                max_mid = pk_max( max_mid, H[8] );
+                if (LAST)
+                {
+                    const uint32_t v = bits_pk( hsel );
+                    if (alive[0]) sink[0].report( (int32_t)(int16_t)(v & 0xFFFFu), i + 1u, M );
+                    if (alive[1]) sink[1].report( (int32_t)v >> 16, i + 1u, M );
+                }
+            }
+        }
+        };
+        if (last) sweep( std::true_type() ); else sweep( std::false_type() );
+        // the reference's early exit (match = 0: nothing is still to be gained), first after column block + 8, then after block + 16
+        if (2u * k + 1u < nb8)
+        {
+            const uint32_t mb = bits_pk( max_mid );
+            if ((int32_t)(int16_t)(mb & 0xFFFFu) < min_score[0]) { if (alive[0] && last) sink[0].init(); alive[0] = false; }
+            if (((int32_t)mb >> 16)              < min_score[1]) { if (alive[1] && last) sink[1].init(); alive[1] = false; }
+        }
+        if (!last)
+        {
+            const uint32_t eb = bits_pk( max_end );
+            if ((int32_t)(int16_t)(eb & 0xFFFFu) < min_score[0]) alive[0] = false;
+            if (((int32_t)eb >> 16)              < min_score[1]) alive[1] = false;
+        }
     }
     #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -817,14 +1077,20 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
             const dim3 grid( (pairs + 127u) / 128u ), block( 128 );
 #define NVB_PK(TYPE_, RB) hipLaunchKernelGGL( (full_gotoh_pb_pk_kernel<TYPE_,RB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)pb, pairs, \
                                               min_scores_dev, (uint2*)column, scores_dev, (uint2*)sinks_dev, (const uint32_t*)list_a, (const uint32_t*)count_a )
+#define NVB_PK16(RB) hipLaunchKernelGGL( (full_gotoh_pb_pk16_kernel<RB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, (uint32_t)pb, pairs, \
+                                         min_scores_dev, (uint2*)column, scores_dev, (uint2*)sinks_dev, (const uint32_t*)list_a, (const uint32_t*)count_a )
+            const bool wide16 = type == NVBIO_SEMI_GLOBAL && sc.match == 0 && !(b.algo & NVBIO_ALN_PK_STRIPE8);      // the end-to-end kernel, 16 columns per stripe
             if (batch->read_bits == 4)
             {
-                if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 4 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 4 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 4 );
+                if (wide16) NVB_PK16( 4 );
+                else if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 4 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 4 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 4 );
             }
             else
             {
-                if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 2 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 2 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 2 );
+                if (wide16) NVB_PK16( 2 );
+                else if (type == NVBIO_GLOBAL) NVB_PK( NVBIO_GLOBAL, 2 ); else if (type == NVBIO_LOCAL) NVB_PK( NVBIO_LOCAL, 2 ); else NVB_PK( NVBIO_SEMI_GLOBAL, 2 );
             }
+#undef NVB_PK16
 #undef NVB_PK
             if (hipGetLastError() != hipSuccess) { set_error( "packed full Gotoh launch failed" ); st = NVBIO_ERR_HIP; }
         }

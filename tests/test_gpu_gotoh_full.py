@@ -216,8 +216,46 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
     assert settled > 2000                                           # plenty of jobs the shortcut can settle
 
 
-@pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL", "GLOBAL"])
-def test_packed_pattern_blocking_kernel(amd, orc, typ, monkeypatch):
+def test_shortcut_sees_alignments_hanging_over_the_window_ends(amd, orc):
+    """end-to-end full-matrix scoring: the window holds a copy of the read with two substitutions (best diagonal: -12), while at one of
+    its ENDS all but the read's first / last symbol match -- one inserted symbol, -8, on a diagonal that is not wholly inside the
+    window.  The shortcut's second chance must hand these to the DP (it used to look at whole diagonals only); both blockings, with the
+    hang at either end, patterns of 20-150 symbols"""
+    rng = np.random.default_rng(97)
+    R, W = 800, 320
+    G = R * 400
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = rng.integers(20, 151, R)
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    wb = (np.arange(R) * 400 + 20).astype(np.uint32); we = (wb + W).astype(np.uint32)
+    reads = []
+    for j in range(R):
+        M = int(lens[j])
+        if j % 2:                                                   # the read's last symbol hangs over the window's end
+            r = np.concatenate([text[we[j] - (M - 1):we[j]], [(text[we[j]] + 1) % 4]]).astype(np.uint8)
+        else:                                                       # ... its first symbol over the window's beginning
+            r = np.concatenate([[(text[wb[j] - 1] + 1) % 4], text[wb[j]:wb[j] + M - 1]]).astype(np.uint8)
+        if j % 7:                                                   # a copy with two substitutions near the window's other end
+            c = r.copy(); pos = rng.choice(M, 2, replace=False); c[pos] = (c[pos] + 1) % 4
+            at = int(wb[j]) + 5 if j % 2 else int(we[j]) - M - 5
+            text[at:at + M] = c
+        reads.append(r)
+    flat = np.concatenate(reads)
+    sv = (0, 6, 6, -8, -3, -8, -3)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we)
+    gapped = 0
+    for blocking in (0, 1):
+        sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), text_blocking=bool(blocking)).enact(batch, 150, W)
+        got_s, got_k = sc.cpu().numpy(), amd.u32(sk)
+        for j in range(R):
+            ok, s_, k_ = orc.full_gotoh(oracle.SEMI_GLOBAL, blocking, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]], None, oracle.SCORE_MIN)
+            assert got_s[j] == s_ and tuple(got_k[j]) == k_, (blocking, j, lens[j])
+            gapped += int(s_ == -8)
+    assert gapped > 1200                                            # the hanging alignment wins nearly everywhere
+
+
+@pytest.mark.parametrize("typ,M", [("LOCAL", 150), ("SEMI_GLOBAL", 150), ("GLOBAL", 150), ("SEMI_GLOBAL", 140), ("SEMI_GLOBAL", 9), ("SEMI_GLOBAL", 24)])
+def test_packed_pattern_blocking_kernel(amd, orc, typ, M, monkeypatch):
     """pattern blocking on a batch of one dominant shape (150 x 400, the opposite-mate case): those jobs run two per
     lane in 16-bit registers, odd-shaped ones through the int32 kernel; odd job counts, reversed / complemented
     reads, qualities, N's, per-job min_score (early exit of one job of a pair only), with and without the
@@ -227,8 +265,10 @@ def test_packed_pattern_blocking_kernel(amd, orc, typ, monkeypatch):
     rng = np.random.default_rng(41)
     G = 200000
     text = rng.integers(0, 4, G, dtype=np.uint8)
-    R, M, W = 701, 150, 400
-    lens = np.full(R, M); lens[5::50] = rng.integers(60, 150, len(lens[5::50]))
+    # (M = 140, 9, 24: the end-to-end kernel sweeps 16 columns at a time and the reference tests its early exit every 8: a real 8-column
+    # boundary inside the last stripe, a pattern of two blocks of 8 in one stripe, a last stripe that is half empty)
+    R, W = 701, 400
+    lens = np.full(R, M); lens[5::50] = rng.integers(min(60, M - 1), M, len(lens[5::50]))
     roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
     starts = rng.integers(0, G - 500, R)
     wlen = np.full(R, W); wlen[7::40] = rng.integers(150, 400, len(wlen[7::40]))
@@ -239,7 +279,7 @@ def test_packed_pattern_blocking_kernel(amd, orc, typ, monkeypatch):
         k = int(rng.integers(0, 6))
         if k:
             pos = rng.integers(0, lens[j], k); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
-        if j % 5 == 0:
+        if j % 5 == 0 and lens[j] > 12:
             c = int(rng.integers(5, lens[j] - 5)); g = int(rng.integers(1, 5))
             r = np.concatenate([r[:c], r[c + g:], rng.integers(0, 4, g, dtype=np.uint8)]) if j % 2 else \
                 np.concatenate([r[:c], rng.integers(0, 4, g, dtype=np.uint8), r[c:lens[j] - g]])
