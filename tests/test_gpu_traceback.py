@@ -212,6 +212,39 @@ def test_traceback_argument_errors(amd, orc):
     assert amd.cigar_string(out[3][0].cpu().numpy(), 1) == "30M"
 
 
+def test_full_traceback_edge_cases(amd, orc):
+    """full-matrix tracebacks (Gotoh and Smith-Waterman aligners): an empty batch is a no-op; a text shorter than the pattern is traced
+    (the full matrix has no band: the read's overhang becomes insertions / clips); a job beyond max_pattern_len / max_text_len is
+    skipped and flagged; scores that could leave the reference's int16 checkpoints are refused"""
+    rng = np.random.default_rng(5)
+    txt = rng.integers(0, 4, 600, dtype=np.uint8)
+    pats = np.concatenate([txt[100:140], txt[300:360], txt[10:30]]).astype(np.uint8)
+    roffs = np.array([0, 40, 100, 120], dtype=np.uint32)
+    wb = np.array([90, 290, 15], dtype=np.uint32); we = np.array([160, 380, 25], dtype=np.uint32)       # job 2: 10 text symbols for 20
+    for al, ofn in ((amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, amd.SimpleGotohScheme(0, -6, -8, -3)),
+                     lambda p, t: orc.full_gotoh_traceback(oracle.SEMI_GLOBAL, oracle.Scheme(0, 6, 6, -8, -3, -8, -3), p, t)),
+                    (amd.make_smith_waterman_aligner(oracle.SEMI_GLOBAL, amd.SimpleSmithWatermanScheme(0, -3, -5, -2)),
+                     lambda p, t: orc.full_sw_traceback(oracle.SEMI_GLOBAL, (0, -3, -5, -2), p, t))):
+        tb = amd.BatchedAlignmentTraceback(al)
+        # empty batch
+        e = amd.AlignmentBatch(pats, 8, roffs, txt, 8, wb[:0], we[:0], read_id=np.zeros(0, np.uint32))
+        out = tb.enact(e, 60, 90)
+        assert out[0].numel() == 0 and out[4].numel() == 0
+        batch = amd.AlignmentBatch(pats, 8, roffs, txt, 8, wb, we)
+        sc, src, snk, cig, ln = tb.enact(batch, 60, 90, cigar_stride=32)
+        for j in range(3):
+            p_, t_ = pats[roffs[j]:roffs[j + 1]], txt[wb[j]:we[j]]
+            ok, s_, so_, sk_, c_ = ofn(p_, t_)
+            assert int(sc[j]) == s_ and tuple(amd.u32(src)[j]) == so_ and tuple(amd.u32(snk)[j]) == sk_, j
+            assert int(ln[j]) == len(c_) and np.array_equal(cig[j].cpu().numpy().view(np.uint16)[:len(c_)], c_), j
+        assert int(sc[0]) == 0 and amd.cigar_string(cig[0].cpu().numpy(), int(ln[0])) == "40M"
+        # a job beyond the declared bounds is skipped and flagged, the others are traced
+        sc, src, snk, cig, ln = tb.enact(batch, 40, 90, cigar_stride=32)
+        assert amd.u32(ln)[1] == 0xFFFFFFFF and amd.u32(ln)[0] == 1 and int(sc[0]) == 0
+    with pytest.raises(amd.NvbioError):                            # scores could overflow the int16 checkpoints
+        amd.BatchedAlignmentTraceback(amd.make_smith_waterman_aligner(oracle.LOCAL, amd.SimpleSmithWatermanScheme(300, -300, -300, -300))).enact(batch, 60, 90)
+
+
 def test_full_traceback_golden(amd, dp_golden, ftb_golden, tb_mode):
     """full-matrix traceback through the C-ABI vs the reference's alignment_traceback (ftb_golden.npz): every pair,
     3 types, with and without min_score, shortcut on and off"""
