@@ -577,6 +577,8 @@ enum
                                               instead of 2 (256 VGPRs, nothing spills: the default since the row loop issues without
                                               idle slots and no longer gains from a third wave)                                  */
     NVBIO_ALN_NO_SECOND_CHANCE      = 128, /* two-mismatch jobs go to the DP (A/B: what the check costs inside the first pass)           */
+    NVBIO_ALN_NO_NARROW_SCORE       = 512, /* end-to-end full-matrix scoring: every job the shortcut cannot settle through the DP over the whole window
+                                              (no band-31 attempt around the best diagonal with its run test)                    */
     NVBIO_ALN_PK_STRIPE8            = 256, /* packed full-matrix scoring of end-to-end jobs (match = 0): the general kernel, 8 pattern columns per
                                               stripe, instead of the end-to-end one that sweeps 16 (A/B)                          */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs

@@ -1081,6 +1081,20 @@ static nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc
     return NVBIO_ERR_INVALID;
 }
 
+// the packed band-31 end-to-end kernel over a job list, for the full-matrix scorer's narrow route (gotoh_full.hip): 4- or 2-bit reads in a
+// 2-bit text, SEMI_GLOBAL; `max_jobs` bounds the list's length (which stays on the device)
+bool banded31_packed_ok(const SchemeDev& sc, const uint32_t max_read_len)
+{
+    return plain_gotoh( sc ) && packed_ok( NVBIO_SEMI_GLOBAL, sc, max_read_len );
+}
+void banded31_packed_launch(const BatchDev& b, const SchemeDev& sc, const uint32_t read_bits, const uint32_t max_jobs, int32_t* scores, uint2* sinks,
+                            const uint32_t* job_list, const uint32_t* job_count, hipStream_t s)
+{
+    const uint32_t pairs = (max_jobs + 1u) / 2u;
+    if (read_bits == 4) launch_pk_kernel<NVBIO_SEMI_GLOBAL,4>( b, sc, pairs, scores, sinks, job_list, job_count, s );
+    else                launch_pk_kernel<NVBIO_SEMI_GLOBAL,2>( b, sc, pairs, scores, sinks, job_list, job_count, s );
+}
+
 nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
 {
     NVB_REQUIRE( in != nullptr, "batch is NULL" );

@@ -55,6 +55,9 @@ inline bool plain_gotoh(const SchemeDev& sc)
 }
 
 nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b);      // gotoh_banded.hip
+bool banded31_packed_ok(const SchemeDev& sc, const uint32_t max_read_len);  // gotoh_banded.hip
+void banded31_packed_launch(const BatchDev& b, const SchemeDev& sc, const uint32_t read_bits, const uint32_t max_jobs, int32_t* scores, uint2* sinks,
+                            const uint32_t* job_list, const uint32_t* job_count, hipStream_t s);
 
 // QualCost (nvBowtie/bowtie2/cuda/scoring.h:84-88) negated (:280-281); IEEE float ops, no contraction
 __device__ __forceinline__ int32_t mismatch_score(const SchemeDev& sc, const uint32_t q)

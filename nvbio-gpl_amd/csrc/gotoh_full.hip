@@ -267,24 +267,14 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 // Planes live in registers: 17 + 17 words of text, 6 x 3 of pattern; the text window slides one bit per
 // diagonal (v_alignbit), 32 diagonals per statically indexed outer step.
 // ---------------------------------------------------------------------------------------------
+// bit planes of a job of the full-matrix shortcuts: pattern rows 0..M-1 (pl / ph = low / high bit, pn = "is N", pm = rows that exist),
+// window symbols 0..N-1 (tl / th, 544 bits; bits at and past N are whatever follows the window)
 template <int RBITS>
-__global__ void __launch_bounds__(256)
-ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext, const bool second_chance,
-                         const int32_t* __restrict__ min_scores, const bool text_blocking,
-                         int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp)
+__device__ __forceinline__ void full_planes(const BatchDev& b, const uint32_t first, const uint32_t M, const bool rev, const bool comp,
+                                            const uint32_t tb, const uint32_t N,
+                                            uint32_t (&pl)[6], uint32_t (&ph)[6], uint32_t (&pn)[6], uint32_t (&pm)[6],
+                                            uint32_t (&tl)[18], uint32_t (&th)[18])
 {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= b.n) return;
-    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
-    const uint32_t first = b.read_offsets[rid];
-    const uint32_t M     = b.read_offsets[rid + 1] - first;
-    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
-    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
-    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
-    const uint32_t tb    = b.win_begin[job];
-    const uint32_t N     = b.win_end[job] - tb;
-    if (M == 0u || M > 161u || N < M || N > 528u) { need_dp[job] = 1; return; }
-
     // ---- pattern planes (bitplanes.h): bit i = row i ----
     uint64_t rlo[3], rhi[3], rn[3];
     {
@@ -292,7 +282,6 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
         load_read_words<RBITS>( b.reads, first, M, rw );
         read_planes192<RBITS>( rw, first, M, rev, comp, rlo, rhi, rn );
     }
-    uint32_t pl[6], ph[6], pn[6], pm[6];
     #pragma unroll
     for (int k = 0; k < 3; ++k)
     {
@@ -305,7 +294,6 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     }
 
     // ---- text planes: 544 bits, bit k = window symbol k (34 packed words cover 528 symbols at any offset) ----
-    uint32_t tl[18], th[18];
     {
         const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
         const uint32_t toff = tb & 15u;
@@ -335,6 +323,29 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
         }
         tl[17] = 0; th[17] = 0;
     }
+
+}
+
+template <int RBITS>
+__global__ void __launch_bounds__(256)
+ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext, const bool second_chance,
+                         const int32_t* __restrict__ min_scores, const bool text_blocking,
+                         int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp, const bool stash = false)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    if (M == 0u || M > 161u || N < M || N > 528u) { need_dp[job] = 1; return; }
+
+    uint32_t pl[6], ph[6], pn[6], pm[6], tl[18], th[18];
+    full_planes<RBITS>( b, first, M, rev, comp, tb, N, pl, ph, pn, pm, tl, th );
 
     const uint32_t last_d = N - M;                               // diagonals 0..N-M end inside the window
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
@@ -466,7 +477,163 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
     {
         scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); need_dp[job] = 0;
     }
-    else need_dp[job] = 1;
+    else
+    {
+        need_dp[job] = 1;
+        if (stash) { scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); }      // for the narrow route (narrow_jobs_kernel)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The narrow route of end-to-end full-matrix scoring (pattern blocking, match = 0, one mismatch penalty P, gap of g symbols =
+// open + (g-1) ext < 0): most jobs the shortcut cannot settle hold ONE good alignment next to the best diagonal d* (an indel, or a few
+// mismatches more than the shortcut takes), and the matrix has 350 diagonals of which the DP would fill every cell.  Instead:
+//   1. the band-31 kernel (two jobs per lane, gotoh_banded.hip) scores the 31 diagonals around d*: S_b, a lower bound of the optimum S*
+//      (every path inside the band is a path of the matrix, with the same score and the same end);
+//   2. an alignment that scores >= S_b holds at most n = |S_b| / min(P, |open|) events (mismatches, gaps) and at most
+//      g = (|S_b| - |open|) / |ext| + 1 gap symbols: its rows that are neither split it into at most n + 1 runs of exact matches on one
+//      diagonal each, the longest of at least (M - n - g) / (n + 1) rows, and it stays within g diagonals of that run's diagonal;
+//   3. so if that bound is >= 16 and the only diagonals of the window (those that hang over its ends by up to g symbols included)
+//      with a run of 16 exact matches lie within 15 - g of the band's centre, every alignment that scores >= S_b lies inside the band:
+//      S* = S_b, and the band's last maximum is the matrix's (both sinks keep the last of equal scores, text ends ascending).
+// A job that fails any of it -- S_b below min_score, a long run elsewhere, a bound below 16 -- takes the DP as before.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+narrow_jobs_kernel(const BatchDev b, const uint8_t* __restrict__ need_dp, const uint2* __restrict__ stashed,
+                   uint32_t* __restrict__ wb2, uint32_t* __restrict__ we2, uint8_t* __restrict__ route)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const uint32_t rid = b.read_id ? b.read_id[job] : job;
+    const uint32_t M   = b.read_offsets[rid + 1] - b.read_offsets[rid];
+    const uint32_t tb  = b.win_begin[job];
+    const uint32_t N   = b.win_end[job] - tb;
+    const bool ok = need_dp[job] == 1 && M >= 1u && M <= 161u && N <= 528u && N >= M + 30u;      // (what the shortcut kernel looked at, and room for a band)
+    uint32_t c = 15u;
+    if (ok)
+    {
+        const uint32_t d = stashed[job].x - M;                   // the best diagonal
+        const uint32_t hi = N - M - 15u;
+        c = d < 15u ? 15u : (d > hi ? hi : d);
+    }
+    wb2[job] = tb + c - 15u; we2[job] = tb + c + 15u + M;       // (a window of M + 30 symbols also where it is not used)
+    route[job] = ok ? 1 : 0;
+}
+
+template <int RBITS>
+__global__ void __launch_bounds__(256)
+narrow_check_kernel(const BatchDev b, const int32_t P, const int32_t gap_open, const int32_t gap_ext, const int32_t* __restrict__ min_scores,
+                    const uint32_t* __restrict__ wb2, const int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp,
+                    const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= *job_count) return;
+    const uint32_t job   = job_list[slot];
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    const int32_t  L     = scores[job];                          // the band's score
+    const int32_t  min_score = min_scores ? min_scores[job] : NVBIO_SCORE_MIN;
+    // the bounds of step 2
+    const int32_t a    = -L;
+    const int32_t unit = P < -gap_open ? P : -gap_open;
+    const int32_t n_ev = unit > 0 ? a / unit : 1 << 20;
+    const int32_t g    = a < -gap_open ? 0 : (gap_ext < 0 ? (a + gap_open) / (-gap_ext) + 1 : 1 << 20);
+    bool ok = L <= 0 && L >= min_score && g <= 15 && n_ev + g < (int32_t)M && ((int32_t)M - n_ev - g) / (n_ev + 1) >= 16;
+    if (!__any( ok )) return;                                    // (need_dp stays 1)
+
+    uint32_t pl[6], ph[6], pn[6], pm[6], tl[18], th[18];
+    full_planes<RBITS>( b, first, M, rev, comp, tb, N, pl, ph, pn, pm, tl, th );
+
+    const uint32_t c  = wb2[job] - tb + 15u;                     // the band's centre diagonal
+    const uint32_t hw = ok ? 15u - (uint32_t)g : 0u;
+    const uint32_t z_lo = c - hw, z_hi = c + hw;                 // runs on these diagonals keep an alignment inside the band
+    const uint32_t last_d = N - M;
+    bool far = false;
+    // a run of 16 matching rows in the 192-bit mismatch vector mm (rows >= M and rows without a text symbol are set)
+    auto run16 = [&](const uint32_t (&mm)[6]) -> bool {
+        uint32_t z[7];
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) z[k] = ~mm[k] & pm[k];
+        z[6] = 0;
+        #pragma unroll
+        for (int sh = 1; sh <= 4; sh <<= 1)
+        {
+            #pragma unroll
+            for (int k = 0; k < 6; ++k) z[k] &= __builtin_amdgcn_alignbit( z[k + 1], z[k], (uint32_t)sh );
+        }
+        uint32_t nz = z[0] | z[1] | z[2] | z[3] | z[4] | z[5];  // runs of 8
+        if (!__any( nz != 0u )) return false;
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) z[k] &= __builtin_amdgcn_alignbit( z[k + 1], z[k], 8u );
+        nz = z[0] | z[1] | z[2] | z[3] | z[4] | z[5];
+        return nz != 0u;
+    };
+    // diagonals -15 .. -1: window symbol r - e under row r, rows 0 .. e-1 without a text symbol (all of them lie outside the zone)
+    #pragma unroll
+    for (int e = 15; e >= 1; --e)
+    {
+        uint32_t mm[6];
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            const uint32_t l = __builtin_amdgcn_alignbit( tl[k], k ? tl[k - 1] : 0u, 32u - (uint32_t)e );
+            const uint32_t h = __builtin_amdgcn_alignbit( th[k], k ? th[k - 1] : 0u, 32u - (uint32_t)e );
+            mm[k] = (((pl[k] ^ l) | (ph[k] ^ h)) & pm[k]) | pn[k];
+        }
+        mm[0] |= (1u << e) - 1u;
+        if (run16( mm ) && e <= g) far = true;
+    }
+    // diagonals 0 .. N - M + g: those past N - M end beyond the window, their last rows have no text symbol
+    const uint32_t last_e = last_d + (ok ? (uint32_t)g : 0u);
+    #pragma unroll 1
+    for (int wo = 0; wo < 17; ++wo)
+    {
+        if (!__any( (uint32_t)wo * 32u <= last_e && !far && ok )) break;
+        uint32_t ql[7], qh[7];
+        #pragma unroll
+        for (int k = 0; k < 7; ++k) { ql[k] = 0u; qh[k] = 0u; }
+        #pragma unroll
+        for (int w = 0; w < 17; ++w)                             // (tl / th are register arrays: no dynamic index)
+            if (w == wo)
+            {
+                #pragma unroll
+                for (int k = 0; k < 7; ++k) { ql[k] = (w + k < 18) ? tl[w + k] : 0u; qh[k] = (w + k < 18) ? th[w + k] : 0u; }
+            }
+        for (uint32_t dd = 0; dd < 32u; ++dd)
+        {
+            const uint32_t d = (uint32_t)wo * 32u + dd;
+            if (!__any( d <= last_e && !far && ok )) break;
+            const uint32_t fm = d > last_d ? (d - last_d < M ? M - (d - last_d) : 0u) : M;      // rows fm .. M-1 have no text symbol
+            uint32_t mm[6];
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
+                mm[k] = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
+            }
+            const bool outside = d < z_lo || d > z_hi;
+            if (run16( mm ) && outside && d <= last_e) far = true;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
+                qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
+            }
+            ql[6] >>= 1; qh[6] >>= 1;
+        }
+    }
+    if (ok && !far)
+    {
+        // the band's sink in the matrix's coordinates: x = text symbols up to the alignment's end
+        sinks[job] = make_uint2( (wb2[job] - tb) + sinks[job].x, M );
+        need_dp[job] = 0;
+    }
 }
 
 
@@ -999,7 +1166,10 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, 3u * flags_bytes + 2u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        // (the narrow route: one more flag array, its job list, the band windows; see narrow_jobs_kernel)
+        const bool narrow = shortcut && !text_blocking && !(b.algo & (NVBIO_ALN_NO_NARROW_SCORE | NVBIO_ALN_NO_PACKED_DP)) && max_pattern_len <= 161u &&
+                            banded31_packed_ok( sc, max_pattern_len ) && sc.pat_ge < 0;
+        if (hipMallocAsync( &aux, 4u * flags_bytes + 5u * list_bytes + 512u + sel_bytes, s ) != hipSuccess)
         {
             set_error( "full Gotoh: out of device memory for the job lists" );
             return NVBIO_ERR_NOMEM;
@@ -1011,16 +1181,34 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         job_list  = (uint32_t*)((uint8_t*)list_a + list_bytes);
         count_a   = (uint32_t*)((uint8_t*)job_list + list_bytes);
         job_count = count_a + 1;
-        void* sel_temp = (uint8_t*)count_a + 256u;
+        uint32_t* count_n  = count_a + 2;
+        uint8_t*  route    = (uint8_t*)count_a + 256u;
+        uint32_t* list_n   = (uint32_t*)(route + flags_bytes);
+        uint32_t* wb2      = (uint32_t*)((uint8_t*)list_n + list_bytes);
+        uint32_t* we2      = (uint32_t*)((uint8_t*)wb2 + list_bytes);
+        void* sel_temp = (uint8_t*)we2 + list_bytes + 256u;
         const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
         if (shortcut)
         {
             const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
             const bool second_chance = (sc.pat_go == sc.txt_go && sc.pat_ge == sc.txt_ge);
-            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
-            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp );
+            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow );
+            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow );
         }
         hipError_t e = hipSuccess;
+        if (narrow)
+        {
+            // the unsettled jobs with room for a band around their best diagonal: band-31 score, then the run test (narrow_check_kernel)
+            hipLaunchKernelGGL( narrow_jobs_kernel, grid, block, 0, s, b, (const uint8_t*)need_dp, (const uint2*)sinks_dev, wb2, we2, route );
+            e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, route, list_n, count_n, (int)b.n, s );
+            if (e == hipSuccess)
+            {
+                BatchDev b2 = b; b2.win_begin = wb2; b2.win_end = we2; b2.max_read_len = max_pattern_len;
+                banded31_packed_launch( b2, sc, batch->read_bits, b.n, scores_dev, (uint2*)sinks_dev, list_n, count_n, s );
+                if (batch->read_bits == 4) hipLaunchKernelGGL( (narrow_check_kernel<4>), grid, block, 0, s, b, P, sc.pat_go, sc.pat_ge, min_scores_dev, (const uint32_t*)wb2, (const int32_t*)scores_dev, (uint2*)sinks_dev, need_dp, (const uint32_t*)list_n, (const uint32_t*)count_n );
+                else                       hipLaunchKernelGGL( (narrow_check_kernel<2>), grid, block, 0, s, b, P, sc.pat_go, sc.pat_ge, min_scores_dev, (const uint32_t*)wb2, (const int32_t*)scores_dev, (uint2*)sinks_dev, need_dp, (const uint32_t*)list_n, (const uint32_t*)count_n );
+            }
+        }
         if (packed)
         {
             hipLaunchKernelGGL( classify_shape_kernel, grid, block, 0, s, b, max_pattern_len, max_text_len, shortcut ? (const uint8_t*)need_dp : (const uint8_t*)nullptr,

@@ -216,6 +216,65 @@ def test_end_to_end_full_dp_with_ungapped_shortcut(amd, orc, shortcut, monkeypat
     assert settled > 2000                                           # plenty of jobs the shortcut can settle
 
 
+@pytest.mark.parametrize("narrow", [True, False])
+def test_narrow_route_and_the_other_locus(amd, orc, narrow, monkeypatch):
+    """end-to-end full-matrix scoring, pattern blocking: the jobs the shortcut cannot settle are scored in a band of 31 diagonals around
+    their best diagonal and keep that score only where no other diagonal of the window holds a long exact run (narrow_check_kernel).
+    Here the window holds the read twice: locus A with an indel of 1-3 symbols and 0-2 substitutions, locus B -- 40-250 symbols away,
+    sometimes only 5-20 -- as a copy with 2-5 substitutions, so that the best DIAGONAL is B's while the best ALIGNMENT is either's;
+    plus reads with 3-6 substitutions and no second locus, and unrelated reads with a per-job min_score.  Scores and sinks equal the
+    reference algorithm's with and without the route (NVBIO_ALN_NO_NARROW_SCORE)."""
+    monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_FORCE_PACKED_DP | (0 if narrow else amd.ALN_NO_NARROW_SCORE))
+    rng = np.random.default_rng(211)
+    R, W = 1500, 500
+    G = R * 560
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = np.full(R, 150); lens[3::11] = rng.integers(60, 150, len(lens[3::11]))
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    wb = (np.arange(R) * 560 + 30).astype(np.uint32); we = (wb + W).astype(np.uint32)
+    we[5::13] = wb[5::13] + rng.integers(200, 500, len(we[5::13]))
+    reads = []
+    for j in range(R):
+        M = int(lens[j]); N = int(we[j] - wb[j])
+        a = int(wb[j]) + int(rng.integers(0, N - M - 4))
+        src = text[a:a + M + 4]
+        kind = j % 4
+        if kind == 3:
+            r = rng.integers(0, 4, M).astype(np.uint8)             # unrelated
+        else:
+            r = src[:M].copy()
+            if kind in (0, 1):                                      # an indel at locus A
+                cpos = int(rng.integers(5, M - 5)); g = int(rng.integers(1, 4))
+                r = np.concatenate([src[:cpos], src[cpos + g:]])[:M] if rng.random() < 0.5 else \
+                    np.concatenate([src[:cpos], rng.integers(0, 4, g, dtype=np.uint8), src[cpos:]])[:M]
+                k = int(rng.integers(0, 3))
+            else:
+                k = int(rng.integers(3, 7))                         # substitutions only, more than the shortcut takes
+            pos = rng.choice(M, k, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+            if kind == 0:                                           # ... and a second locus B inside the window
+                sep = int(rng.integers(5, 21)) if rng.random() < 0.3 else int(rng.integers(40, 251))
+                bpos = a + sep if a + sep + M <= int(we[j]) else a - sep
+                if bpos >= int(wb[j]) and bpos + M <= int(we[j]):
+                    c = r.copy(); kk = int(rng.integers(2, 6)); pos = rng.choice(M, kk, replace=False); c[pos] = (c[pos] + 1 + rng.integers(0, 3, kk)) % 4
+                    text[bpos:bpos + M] = c
+                    r2 = text[a:a + M + 4]                          # (B may have overwritten part of A: the oracle decides what is best)
+        reads.append(r.astype(np.uint8))
+    flat = np.concatenate(reads)
+    sv = (0, 6, 6, -8, -3, -8, -3)
+    ms = rng.integers(-70, -10, R).astype(np.int32); ms[::3] = oracle.SCORE_MIN
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we)
+    gapped = deep = 0
+    for min_scores in (None, ms):
+        sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), text_blocking=False).enact(batch, 150, W, min_scores=min_scores)
+        got_s, got_k = sc.cpu().numpy(), amd.u32(sk)
+        for j in range(R):
+            ok, s_, k_ = orc.full_gotoh(oracle.SEMI_GLOBAL, 0, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]], None,
+                                       int(min_scores[j]) if min_scores is not None else oracle.SCORE_MIN)
+            assert got_s[j] == s_ and tuple(got_k[j]) == k_, (narrow, min_scores is not None, j, j % 4, lens[j])
+            gapped += int(-40 < s_ < -7 and s_ % 6 != 0); deep += int(s_ <= -18)
+    assert gapped > 800 and deep > 400
+
+
 def test_shortcut_sees_alignments_hanging_over_the_window_ends(amd, orc):
     """end-to-end full-matrix scoring: the window holds a copy of the read with two substitutions (best diagonal: -12), while at one of
     its ENDS all but the read's first / last symbol match -- one inserted symbol, -8, on a diagonal that is not wholly inside the
