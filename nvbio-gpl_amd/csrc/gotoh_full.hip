@@ -326,14 +326,20 @@ __device__ __forceinline__ void full_planes(const BatchDev& b, const uint32_t fi
 
 }
 
-template <int RBITS>
+// MODE 0: the pass over every job: best diagonal, settled or not; a job the second chance could still settle is flagged need_dp = 3 with its
+//   best diagonal stashed in scores / sinks (inside this pass every wave paid for the second chance's own 350-diagonal scan whenever one of
+//   its lanes asked for it, i.e. always: 15.8 -> 9 ms per 10 M opposite-mate windows with it moved out).
+// MODE 1: the pass over the dense list of those jobs (job_list / job_count on the device): the second chance; each ends as 0 or 1.
+template <int RBITS, int MODE = 0>
 __global__ void __launch_bounds__(256)
 ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext, const bool second_chance,
                          const int32_t* __restrict__ min_scores, const bool text_blocking,
-                         int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp, const bool stash = false)
+                         int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp, const bool stash = false,
+                         const uint32_t* __restrict__ job_list = nullptr, const uint32_t* __restrict__ job_count = nullptr)
 {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= b.n) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (MODE == 0 ? slot >= b.n : slot >= *job_count) return;
+    const uint32_t job = MODE == 0 ? slot : job_list[slot];
     const uint32_t rid   = b.read_id ? b.read_id[job] : job;
     const uint32_t first = b.read_offsets[rid];
     const uint32_t M     = b.read_offsets[rid + 1] - first;
@@ -349,9 +355,16 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
 
     const uint32_t last_d = N - M;                               // diagonals 0..N-M end inside the window
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
+    if (MODE == 1)
+    {
+        // the first pass left this job's best diagonal in scores / sinks
+        best_cnt = P > 0 ? (uint32_t)(-scores[job] / P) : 0u;
+        best_d   = sinks[job].x - M;
+    }
     #pragma unroll
     for (int wo = 0; wo < 17; ++wo)                              // 32 diagonals per step; d <= N - M <= 527
     {
+        if (MODE == 1) break;
         if ((uint32_t)wo * 32u > last_d) break;
         uint32_t ql[7], qh[7];
         #pragma unroll
@@ -390,6 +403,11 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
         // rows and columns charge one or the other depending on the blocking.)
         int32_t gmax = 0;
         while (gmax < 5 && (int64_t)gap_open + (int64_t)gmax * gap_ext >= U) ++gmax;
+        if (MODE == 0 && gmax >= 1 && gmax <= 4)
+        {
+            need_dp[job] = 3; scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M );      // for the second-chance launch
+            return;
+        }
         if (gmax >= 1 && gmax <= 4)
         {
             uint32_t lead_prev[4] = { 0, 0, 0, 0 }, tail_prev[4] = { 0, 0, 0, 0 };
@@ -498,6 +516,8 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
 //      S* = S_b, and the band's last maximum is the matrix's (both sinks keep the last of equal scores, text ends ascending).
 // A job that fails any of it -- S_b below min_score, a long run elsewhere, a bound below 16 -- takes the DP as before.
 // ---------------------------------------------------------------------------------------------
+struct FlagIs3 { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 3u ? 1u : 0u; } };
+
 __global__ void __launch_bounds__(256)
 narrow_jobs_kernel(const BatchDev b, const uint8_t* __restrict__ need_dp, const uint2* __restrict__ stashed,
                    uint32_t* __restrict__ wb2, uint32_t* __restrict__ we2, uint8_t* __restrict__ route)
@@ -1192,8 +1212,22 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         {
             const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
             const bool second_chance = (sc.pat_go == sc.txt_go && sc.pat_ge == sc.txt_ge);
-            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow );
-            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow );
+            if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4,0>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
+                                                           (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+            else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2,0>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
+                                                           (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+            if (second_chance)
+            {
+                // the jobs the second chance can still settle (need_dp == 3), compacted, through their own launch: every job ends as 0 or 1
+                uint32_t* list_s = list_n; uint32_t* count_s = count_n + 1;                    // (the narrow route's list is built after this)
+                hipcub::TransformInputIterator<uint8_t, FlagIs3, const uint8_t*> is3( need_dp, FlagIs3() );
+                const hipError_t e3 = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is3, list_s, count_s, (int)b.n, s );
+                if (e3 != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e3 ) ); return NVBIO_ERR_HIP; }
+                if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4,1>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
+                                                               (const uint32_t*)list_s, (const uint32_t*)count_s );
+                else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2,1>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
+                                                               (const uint32_t*)list_s, (const uint32_t*)count_s );
+            }
         }
         hipError_t e = hipSuccess;
         if (narrow)
