@@ -275,6 +275,58 @@ def test_narrow_route_and_the_other_locus(amd, orc, narrow, monkeypatch):
     assert gapped > 800 and deep > 400
 
 
+@pytest.mark.parametrize("narrow", [True, False])
+def test_full_e2e_scoring_on_low_complexity_text(amd, orc, narrow, monkeypatch):
+    """end-to-end full-matrix scoring where equal scores and long exact runs are everywhere: tandem repeats of period 1-7 with a few
+    mutations, two-letter stretches, reads that are themselves periodic (so that many diagonals and many gapped alignments tie and the
+    sink is decided by "the last of equal scores"), with 0-5 substitutions and an occasional indel; both blockings; with and without
+    the narrow route.  Scores AND sinks equal the reference algorithm's."""
+    monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_FORCE_PACKED_DP | (0 if narrow else amd.ALN_NO_NARROW_SCORE))
+    rng = np.random.default_rng(313)
+    R, W = 1200, 420
+    G = R * 480
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = np.full(R, 100); lens[2::9] = rng.integers(40, 151, len(lens[2::9]))
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    wb = (np.arange(R) * 480 + 20).astype(np.uint32); we = (wb + W).astype(np.uint32)
+    reads = []
+    for j in range(R):
+        M = int(lens[j])
+        lo, hi = int(wb[j]), int(we[j])
+        kind = j % 3
+        if kind == 0:                                               # a tandem repeat fills most of the window
+            unit = rng.integers(0, 4, int(rng.integers(1, 8))).astype(np.uint8)
+            a0 = lo + int(rng.integers(0, 60)); L = int(rng.integers(M + 20, hi - a0))
+            rep = np.resize(unit, L).copy()
+            mut = rng.random(L) < 0.02; rep[mut] = rng.integers(0, 4, int(mut.sum()))
+            text[a0:a0 + L] = rep
+        elif kind == 1:                                             # a two-letter stretch
+            a0 = lo + int(rng.integers(0, 100)); L = int(rng.integers(M, hi - a0))
+            text[a0:a0 + L] = rng.integers(0, 2, L) * int(rng.integers(1, 4))
+        a = lo + int(rng.integers(0, W - M - 4))
+        src = text[a:a + M + 4]
+        r = src[:M].copy()
+        if rng.random() < 0.3:
+            cpos = int(rng.integers(3, M - 3)); g = int(rng.integers(1, 4))
+            r = np.concatenate([src[:cpos], src[cpos + g:]])[:M] if rng.random() < 0.5 else np.concatenate([src[:cpos], src[cpos - g:cpos], src[cpos:]])[:M]
+        k = int(rng.integers(0, 6))
+        if k:
+            pos = rng.choice(M, k, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        reads.append(r.astype(np.uint8))
+    flat = np.concatenate(reads)
+    sv = (0, 6, 6, -8, -3, -8, -3)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we)
+    unsettled = 0
+    for blocking in (0, 1):
+        sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), text_blocking=bool(blocking)).enact(batch, 150, W)
+        got_s, got_k = sc.cpu().numpy(), amd.u32(sk)
+        for j in range(R):
+            ok, s_, k_ = orc.full_gotoh(oracle.SEMI_GLOBAL, blocking, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]], None, oracle.SCORE_MIN)
+            assert got_s[j] == s_ and tuple(got_k[j]) == k_, (narrow, blocking, j, j % 3, lens[j])
+            unsettled += int(s_ <= -8)
+    assert unsettled > 600
+
+
 def test_shortcut_sees_alignments_hanging_over_the_window_ends(amd, orc):
     """end-to-end full-matrix scoring: the window holds a copy of the read with two substitutions (best diagonal: -12), while at one of
     its ENDS all but the read's first / last symbol match -- one inserted symbol, -8, on a diagonal that is not wholly inside the
