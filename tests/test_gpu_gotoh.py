@@ -314,6 +314,52 @@ def test_end_to_end_shortcut_edge_cases(amd, orc):
     assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2 | 128])
+def test_end_to_end_banded_scoring_on_low_complexity_text(amd, orc, flags, monkeypatch):
+    """band-31 end-to-end scoring where equal scores are everywhere: tandem repeats of period 1-7 with a few mutations, two-letter
+    stretches, periodic reads, 0-5 substitutions and an occasional indel -- many diagonals and many single- and double-gap alignments
+    tie, which is what the shortcut's second and third chance have to get right (a tie goes to the DP) and what decides the sink.
+    Default route, DP for every job (NVBIO_ALN_NO_UNGAPPED_SCORE) and first pass + DP only: scores and sinks equal the reference
+    algorithm's."""
+    monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", flags)
+    rng = np.random.default_rng(515)
+    R, M = 4000, 150
+    G = R * 300
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    reads, wbs = [], []
+    for j in range(R):
+        base = j * 300 + 40
+        kind = j % 3
+        if kind == 0:
+            unit = rng.integers(0, 4, int(rng.integers(1, 8))).astype(np.uint8)
+            L = int(rng.integers(60, 230)); a0 = base - 30 + int(rng.integers(0, 60))
+            rep = np.resize(unit, L).copy(); mut = rng.random(L) < 0.02; rep[mut] = rng.integers(0, 4, int(mut.sum()))
+            text[a0:a0 + L] = rep
+        elif kind == 1:
+            L = int(rng.integers(40, 200)); a0 = base - 20 + int(rng.integers(0, 60))
+            text[a0:a0 + L] = rng.integers(0, 2, L) * int(rng.integers(1, 4))
+        src = text[base:base + M + 4]
+        r = src[:M].copy()
+        if rng.random() < 0.3:
+            cpos = int(rng.integers(3, M - 3)); g = int(rng.integers(1, 4))
+            r = np.concatenate([src[:cpos], src[cpos + g:]])[:M] if rng.random() < 0.5 else np.concatenate([src[:cpos], src[cpos - g:cpos], src[cpos:]])[:M]
+        k = int(rng.integers(0, 6))
+        if k:
+            pos = rng.choice(M, k, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        reads.append(r.astype(np.uint8)); wbs.append(base - 15 + int(rng.integers(-4, 5)))
+    flat = np.concatenate(reads)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    wb = np.array(wbs, dtype=np.uint32); we = (wb + 31 + M).astype(np.uint32)
+    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 3, 3, -4, -2, -4, -2)):
+        wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we)
+        batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M)
+        sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+        bad = np.nonzero(sc.cpu().numpy() != wsc)[0]
+        assert len(bad) == 0, (sv, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]])
+        assert np.array_equal(amd.u32(sk), wsk), sv
+    assert (wsc <= -4).mean() > 0.5
+
+
 @pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])
 def test_jobs_longer_than_the_declared_bound_are_rejected(amd, orc, typ):
     """nvbio_alignment_batch::max_read_len is what lets the library pick 16-bit kernels: a job whose pattern is longer than a
