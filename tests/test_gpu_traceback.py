@@ -159,6 +159,72 @@ def test_traceback_packed_batch_vs_oracle(amd, orc, typ, tb_mode):
     assert checked > 5000
 
 
+def _low_complexity_jobs(rng, R, M, span):
+    """windows of `span` symbols full of tandem repeats (period 1-7, 2 % mutated), two-letter stretches and plain random text; reads
+    taken from inside them with 0-4 substitutions and sometimes an indel of 1-3 symbols: co-optimal alignments everywhere"""
+    G = R * (span + 60)
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    reads, loci = [], []
+    for j in range(R):
+        base = j * (span + 60) + 30
+        kind = j % 3
+        if kind == 0:
+            unit = rng.integers(0, 4, int(rng.integers(1, 8))).astype(np.uint8)
+            L = int(rng.integers(M // 2, span)); a0 = base + int(rng.integers(0, span - L + 1))
+            rep = np.resize(unit, L).copy(); mut = rng.random(L) < 0.02; rep[mut] = rng.integers(0, 4, int(mut.sum()))
+            text[a0:a0 + L] = rep
+        elif kind == 1:
+            L = int(rng.integers(M // 3, span)); a0 = base + int(rng.integers(0, span - L + 1))
+            text[a0:a0 + L] = rng.integers(0, 2, L) * int(rng.integers(1, 4))
+        a = base + int(rng.integers(0, span - M - 4))
+        src = text[a:a + M + 4]
+        r = src[:M].copy()
+        if rng.random() < 0.4:
+            cpos = int(rng.integers(3, M - 3)); g = int(rng.integers(1, 4))
+            r = np.concatenate([src[:cpos], src[cpos + g:]])[:M] if rng.random() < 0.5 else np.concatenate([src[:cpos], src[cpos - g:cpos], src[cpos:]])[:M]
+        k = int(rng.integers(0, 5))
+        if k:
+            pos = rng.choice(M, k, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        reads.append(r.astype(np.uint8)); loci.append(a)
+    return text, reads, np.array(loci, dtype=np.int64)
+
+
+def test_traceback_on_low_complexity_text(amd, orc, tb_mode):
+    """banded and full-matrix end-to-end tracebacks where co-optimal alignments abound (tandem repeats, two-letter stretches): the
+    narrow-band / restricted-row routes rest on every co-optimal path lying inside the region they compute, so that the reference's
+    tie rules meet the same values -- scores, sources, sinks and CIGARs equal the reference algorithm's in every mode"""
+    rng = np.random.default_rng(717)
+    sv = (0, 6, 6, -8, -3, -8, -3)
+    stride = 40
+    # banded: a window of M + 31 around the locus
+    R, M = 3000, 150
+    text, reads, loci = _low_complexity_jobs(rng, R, M, 220)
+    flat = np.concatenate(reads); roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    wb = (loci - 15 + rng.integers(-4, 5, R)).astype(np.uint32); we = (wb + 31 + M).astype(np.uint32)
+    want = orc.banded_gotoh_traceback_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we, stride)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M)
+    sc, src, snk, cig, ln = amd.BatchedBandedAlignmentTraceback(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv))).enact(batch, cigar_stride=stride)
+    assert np.array_equal(sc.cpu().numpy(), want[0]) and np.array_equal(amd.u32(src), want[1]) and np.array_equal(amd.u32(snk), want[2])
+    assert np.array_equal(amd.u32(ln), want[4]) and np.array_equal(cig.cpu().numpy().view(np.uint16), want[3])
+    assert (want[4] > 2).mean() > 0.2
+    # full matrix: the opposite-mate shape, 150 in 400
+    R, M, W = 1200, 150, 400
+    text, reads, loci = _low_complexity_jobs(rng, R, M, W)
+    flat = np.concatenate(reads); roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    wb = (np.arange(R) * (W + 60) + 30).astype(np.uint32); we = (wb + W).astype(np.uint32)
+    batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we)
+    sc, src, snk, cig, ln = amd.BatchedAlignmentTraceback(amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv))).enact(batch, M, W, cigar_stride=stride)
+    sc, src, snk, ln = sc.cpu().numpy(), amd.u32(src), amd.u32(snk), amd.u32(ln)
+    cig = cig.cpu().numpy().view(np.uint16)
+    gapped = 0
+    for j in range(R):
+        ok, s_, so_, sk_, c_ = orc.full_gotoh_traceback(oracle.SEMI_GLOBAL, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]])
+        assert sc[j] == s_ and tuple(src[j]) == so_ and tuple(snk[j]) == sk_, j
+        assert ln[j] == len(c_) and np.array_equal(cig[j, :min(len(c_), stride)], c_[:stride]), j
+        gapped += len(c_) > 2
+    assert gapped > 200
+
+
 def test_sw_traceback_golden(amd, swtb_golden, tb_mode):
     """nvbio_banded_sw_traceback (the linear-gap Smith-Waterman / edit-distance aligners through BatchedBandedAlignmentTraceback) against
     the reference's own outputs: scores, sources, sinks, CIGARs; unequal deletion / insertion costs; LOCAL walks that run to row 0"""
