@@ -579,6 +579,8 @@ enum
     NVBIO_ALN_NO_SECOND_CHANCE      = 128, /* two-mismatch jobs go to the DP (A/B: what the check costs inside the first pass)           */
     NVBIO_ALN_NO_NARROW_SCORE       = 512, /* end-to-end full-matrix scoring: every job the shortcut cannot settle through the DP over the whole window
                                               (no band-31 attempt around the best diagonal with its run test)                    */
+    NVBIO_ALN_NO_BAND_ROUTE         = 1024, /* full-matrix end-to-end traceback: the jobs whose paths stay within 7 diagonals of their sink keep the
+                                              row-restricted full-matrix kernel instead of the band-15 traceback kernel           */
     NVBIO_ALN_PK_STRIPE8            = 256, /* packed full-matrix scoring of end-to-end jobs (match = 0): the general kernel, 8 pattern columns per
                                               stripe, instead of the end-to-end one that sweeps 16 (A/B)                          */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs

@@ -55,6 +55,10 @@ inline bool plain_gotoh(const SchemeDev& sc)
 }
 
 nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b);      // gotoh_banded.hip
+nvbio_status banded15_full_ties_traceback(const BatchDev& b, const SchemeDev& sc, const uint32_t rbits, const uint32_t tbits, const uint32_t max_jobs,
+                                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, const uint64_t dirs_bytes,
+                                          int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, const uint32_t stride, uint32_t* lens,
+                                          hipStream_t s);                   // gotoh_traceback.hip
 bool banded31_packed_ok(const SchemeDev& sc, const uint32_t max_read_len);  // gotoh_banded.hip
 void banded31_packed_launch(const BatchDev& b, const SchemeDev& sc, const uint32_t read_bits, const uint32_t max_jobs, int32_t* scores, uint2* sinks,
                             const uint32_t* job_list, const uint32_t* job_count, hipStream_t s);

@@ -432,6 +432,47 @@ finish_alignment_kernel(const BatchDev b, const uint2* __restrict__ sources, con
     if (mds_lens) mds_lens[job] = mds_len;
 }
 
+// ---- the band route: restricted jobs through the banded traceback kernel ---------------------------------------------------
+// A job whose optimal paths stay within G <= 7 diagonals of its sink's (need_dp = 2 + G, see full_gotoh_traceback_kernel) is a band-15
+// problem: the banded traceback kernel (gotoh_traceback.hip) takes it over a window of M + 14 symbols around that diagonal, with the full
+// matrix's rule for ties between the two gap moves.  The argument is the one of the restricted rows: every cell on an optimal path gets
+// its exact value inside the band, every alternative a direction rule compares it with can only come out lower, never tie.  Needs the
+// band inside the window (sink diagonal between 7 and N - M - 7); the others keep the restricted full-matrix kernel.
+__global__ void __launch_bounds__(256)
+tb_band_route_kernel(const BatchDev b, uint8_t* __restrict__ need_dp, const uint2* __restrict__ sinks,
+                     uint32_t* __restrict__ wb2, uint32_t* __restrict__ we2, uint8_t* __restrict__ route)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= b.n) return;
+    const JobInfo J = load_job( b, job );
+    const uint32_t code = need_dp[job];
+    const uint2 sink = sinks[job];
+    bool ok = code >= 2u && code - 2u <= 7u && sink.y == J.M && sink.x >= sink.y && J.N >= J.M + 14u;
+    uint32_t delta = 7u;
+    if (ok)
+    {
+        delta = sink.x - sink.y;
+        ok = delta >= 7u && delta + 7u <= J.N - J.M;
+    }
+    if (!ok) delta = 7u;
+    wb2[job] = J.tb + delta - 7u; we2[job] = J.tb + delta + 7u + J.M;
+    route[job] = ok ? 1 : 0;
+    if (ok) need_dp[job] = 0;                                    // not for the full-matrix kernel's list
+}
+
+// sources and sinks of the routed jobs back in the window's coordinates
+__global__ void __launch_bounds__(256)
+tb_band_fixup_kernel(const BatchDev b, const uint32_t* __restrict__ wb2, const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count,
+                     uint2* __restrict__ sources, uint2* __restrict__ sinks)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= *job_count) return;
+    const uint32_t job = job_list[slot];
+    const uint32_t off = wb2[job] - b.win_begin[job];
+    if (sources[job].x != 0xFFFFFFFFu) sources[job].x += off;
+    if (sinks[job].x   != 0xFFFFFFFFu) sinks[job].x   += off;
+}
+
 } // anonymous namespace
 } // namespace nvbio_amd
 
@@ -515,10 +556,12 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
                                         nullptr, 0, stream ) );
     const bool shortcut = !(b.algo & NVBIO_ALN_NO_UNGAPPED_TRACEBACK) && !sw;
     uint32_t *job_list = nullptr, *job_count = nullptr; void* aux = nullptr; uint8_t* need_dp = nullptr;
+    uint32_t *band_list = nullptr, *band_count = nullptr, *band_wb = nullptr, *band_we = nullptr; uint8_t* band_route = nullptr;
     // the row-restricted DP applies to nvBowtie's end-to-end mode (see full_gotoh_traceback_kernel)
     const int32_t go_min = -(sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go), ge_min = -(sc.pat_ge > sc.txt_ge ? sc.pat_ge : sc.txt_ge);
     const bool narrow = type == NVBIO_SEMI_GLOBAL && sc.match == 0 && sc.mm_min >= 0 && sc.mm_max >= 0 && plain_gotoh( sc ) &&
                         ge_min > 0 && go_min >= ge_min && !(b.algo & NVBIO_ALN_NO_NARROW_TRACEBACK);
+    const bool band_ok = narrow && shortcut && !(b.algo & NVBIO_ALN_NO_BAND_ROUTE);
     if (shortcut)
     {
         if (!(flags & NVBIO_TRACEBACK_SINKS_GIVEN))
@@ -529,7 +572,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, flags_bytes + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (hipMallocAsync( &aux, 2u * flags_bytes + 4u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             set_error( "full traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
@@ -537,7 +580,12 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         need_dp   = (uint8_t*)aux;
         job_list  = (uint32_t*)((uint8_t*)aux + flags_bytes);
         job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + list_bytes);
-        void* sel_temp = (uint8_t*)aux + flags_bytes + list_bytes + 256u;
+        band_count = job_count + 1;
+        band_route = (uint8_t*)job_count + 256u;
+        band_list  = (uint32_t*)(band_route + flags_bytes);
+        band_wb    = (uint32_t*)((uint8_t*)band_list + list_bytes);
+        band_we    = (uint32_t*)((uint8_t*)band_wb + list_bytes);
+        void* sel_temp = (uint8_t*)band_we + list_bytes;
         const dim3 grid( (b.n + 255u) / 256u ), block( 256 );
 #define NVB_UNG(TYPE_, RB, TB) hipLaunchKernelGGL( (ungapped_full_traceback_kernel<TYPE_,RB,TB>), grid, block, 0, s, b, sc, max_pattern_len, max_text_len, \
                                                    (const int32_t*)scores_dev, (const uint2*)sinks_dev, (uint2*)sources_dev, cigars_dev, cigar_stride, cigar_lens_dev, need_dp, \
@@ -549,7 +597,14 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         if (type == NVBIO_GLOBAL) { NVB_UNG_BITS( NVBIO_GLOBAL ); } else if (type == NVBIO_LOCAL) { NVB_UNG_BITS( NVBIO_LOCAL ); } else { NVB_UNG_BITS( NVBIO_SEMI_GLOBAL ); }
 #undef NVB_UNG_BITS
 #undef NVB_UNG
-        const hipError_t e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
+        hipError_t e = hipSuccess;
+        if (band_ok)
+        {
+            // the restricted jobs that fit a band of 15 leave the full-matrix list (see tb_band_route_kernel); launched below
+            hipLaunchKernelGGL( tb_band_route_kernel, grid, block, 0, s, b, need_dp, (const uint2*)sinks_dev, band_wb, band_we, band_route );
+            e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, band_route, band_list, band_count, (int)b.n, s );
+        }
+        if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
@@ -582,6 +637,15 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         scratch = (uint8_t*)owned;
     }
     nvbio_status st = NVBIO_OK;
+    if (band_ok)
+    {
+        BatchDev b2 = b; b2.win_begin = band_wb; b2.win_end = band_we; b2.max_read_len = max_pattern_len;
+        st = banded15_full_ties_traceback( b2, sc, rb, tbits, b.n, band_list, band_count, (uint32_t*)scratch, cap_jobs * per_job,
+                                           scores_dev, (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s );
+        if (st == NVBIO_OK)
+            hipLaunchKernelGGL( tb_band_fixup_kernel, dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, (const uint32_t*)band_wb, (const uint32_t*)band_list,
+                                (const uint32_t*)band_count, (uint2*)sources_dev, (uint2*)sinks_dev );
+    }
     for (uint64_t begin = 0; begin < b.n && st == NVBIO_OK; begin += cap_jobs)
     {
         const uint32_t jobs = (uint32_t)((b.n - begin) < cap_jobs ? (b.n - begin) : cap_jobs);

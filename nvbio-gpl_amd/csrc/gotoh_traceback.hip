@@ -36,7 +36,7 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
                               uint32_t* __restrict__ dirs,
                               int32_t* __restrict__ scores, uint2* __restrict__ sources, uint2* __restrict__ sinks,
                               uint16_t* __restrict__ cigars, const uint32_t cigar_stride, uint32_t* __restrict__ cigar_lens,
-                              const uint8_t* __restrict__ band_off = nullptr)
+                              const uint8_t* __restrict__ band_off = nullptr, const uint32_t full_ties = 0u)
 {
     constexpr int WORDS = (BAND + 7) / 8;                        // 32-bit words of direction nibbles per row
 
@@ -155,6 +155,10 @@ banded_gotoh_traceback_kernel(const BatchDev b, const SchemeDev sc, const uint32
                 {
                     h = max3( f, E, d );                                                                      // :534-557
                     hdir = f > E ? (f > d ? D_INS : D_SUB) : (E > d ? D_DEL : D_SUB);
+                    // full_ties (a band cut out of a FULL matrix, gotoh_full_traceback.hip): where the two gap moves tie above the
+                    // diagonal one, the full-matrix reference asks for the deletion first and so ends on the insertion
+                    // (gotoh_inl.h:529-531), the banded one the other way round
+                    if (full_ties && f == E && f > d) hdir = D_INS;
                 }
                 if (TYPE == NVBIO_LOCAL)
                 {
@@ -457,10 +461,10 @@ nvbio_status launch_ungapped_type(int type, const BatchDev& b, const SchemeDev& 
 template <int BAND, int TYPE>
 nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
-                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr)
+                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr, const uint32_t full_ties = 0u)
 {
     const dim3 grid( (jobs + 127u) / 128u ), block( 128 );
-#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, band_off )
+#define NVB_GO(RB, TB) hipLaunchKernelGGL( (banded_gotoh_traceback_kernel<BAND,TYPE,RB,TB>), grid, block, 0, s, b, sc, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, band_off, full_ties )
     if      (rbits == 4 && tbits == 2) NVB_GO(4, 2);
     else if (rbits == 2 && tbits == 2) NVB_GO(2, 2);
     else if (rbits == 8 && tbits == 2) NVB_GO(8, 2);
@@ -476,13 +480,13 @@ nvbio_status launch_bits(const BatchDev& b, const SchemeDev& sc, uint32_t rbits,
 template <int BAND>
 nvbio_status launch_type(int type, const BatchDev& b, const SchemeDev& sc, uint32_t rbits, uint32_t tbits, uint32_t job_begin, uint32_t jobs,
                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, uint32_t stride,
-                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr)
+                         uint32_t* lens, hipStream_t s, const uint8_t* band_off = nullptr, const uint32_t full_ties = 0u)
 {
     switch (type)
     {
-    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
-    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
-    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off );
+    case NVBIO_GLOBAL:      return launch_bits<BAND,NVBIO_GLOBAL>     ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off, full_ties );
+    case NVBIO_LOCAL:       return launch_bits<BAND,NVBIO_LOCAL>      ( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off, full_ties );
+    case NVBIO_SEMI_GLOBAL: return launch_bits<BAND,NVBIO_SEMI_GLOBAL>( b, sc, rbits, tbits, job_begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s, band_off, full_ties );
     }
     set_error( "invalid alignment type %d", type );
     return NVBIO_ERR_INVALID;
@@ -492,6 +496,26 @@ inline uint64_t row_bytes(const uint32_t band) { return (uint64_t)((band + 7u) /
 template <int CODE> struct IsCode { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == (uint8_t)CODE ? 1u : 0u; } };
 
 } // anonymous namespace
+
+// The band-15 end-to-end traceback over a job list with the FULL matrix's tie rule: for the full-matrix traceback's jobs whose optimal
+// paths are known to stay within 7 diagonals of their sink (gotoh_full_traceback.hip hands over a batch whose windows are those bands).
+// `max_jobs` bounds the list's length, which stays on the device; the scratch is used in as many launches as it takes.
+nvbio_status banded15_full_ties_traceback(const BatchDev& b, const SchemeDev& sc, const uint32_t rbits, const uint32_t tbits, const uint32_t max_jobs,
+                                          const uint32_t* job_list, const uint32_t* job_count, uint32_t* dirs, const uint64_t dirs_bytes,
+                                          int32_t* scores, uint2* sources, uint2* sinks, uint16_t* cigars, const uint32_t stride, uint32_t* lens, hipStream_t s)
+{
+    const uint64_t per_job = (uint64_t)b.max_read_len * row_bytes( 15 );
+    const uint64_t cap = dirs_bytes / (per_job ? per_job : 1u);
+    if (cap < 64u) { set_error( "full traceback: scratch too small for the band-15 route" ); return NVBIO_ERR_INVALID; }
+    nvbio_status st = NVBIO_OK;
+    for (uint64_t begin = 0; begin < max_jobs && st == NVBIO_OK; begin += cap)
+    {
+        const uint32_t jobs = (uint32_t)((max_jobs - begin) < cap ? (max_jobs - begin) : cap);
+        st = launch_type<15>( NVBIO_SEMI_GLOBAL, b, sc, rbits, tbits, (uint32_t)begin, jobs, job_list, job_count, dirs, scores, sources, sinks, cigars, stride, lens, s,
+                              nullptr, 1u );
+    }
+    return st;
+}
 } // namespace nvbio_amd
 
 using namespace nvbio_amd;

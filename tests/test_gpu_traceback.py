@@ -16,7 +16,7 @@ def _i64(t):
     return t.cpu().numpy().astype(np.int64)
 
 
-@pytest.fixture(params=["shortcut", "dp-only", "no-narrow"])
+@pytest.fixture(params=["shortcut", "dp-only", "no-narrow", "no-band-route"])
 def tb_mode(request, monkeypatch, amd):
     """the default route (ungapped shortcut; band-15 DP for the end-to-end jobs whose optimal paths stay within 7 diagonals of the
     sink), the plain DP-for-every-job path, and the shortcut with every DP over the whole band must all equal the reference"""
@@ -24,6 +24,8 @@ def tb_mode(request, monkeypatch, amd):
         monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_UNGAPPED_TRACEBACK)
     if request.param == "no-narrow":
         monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_NARROW_TRACEBACK)
+    if request.param == "no-band-route":                            # full-matrix traceback: restricted rows instead of the band-15 kernel
+        monkeypatch.setattr(amd, "DEFAULT_ALGO_FLAGS", amd.ALN_NO_BAND_ROUTE)
     return request.param
 
 
