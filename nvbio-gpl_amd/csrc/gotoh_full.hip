@@ -595,8 +595,8 @@ narrow_check_kernel(const BatchDev b, const int32_t P, const int32_t gap_open, c
         return nz != 0u;
     };
     // diagonals -15 .. -1: window symbol r - e under row r, rows 0 .. e-1 without a text symbol (all of them lie outside the zone)
-    #pragma unroll
-    for (int e = 15; e >= 1; --e)
+    #pragma unroll 1
+    for (int e = 15; e >= 1; --e)                                // (a loop, not 15 copies: unrolled, the kernel needed all 256 VGPRs)
     {
         uint32_t mm[6];
         #pragma unroll
@@ -611,20 +611,14 @@ narrow_check_kernel(const BatchDev b, const int32_t P, const int32_t gap_open, c
     }
     // diagonals 0 .. N - M + g: those past N - M end beyond the window, their last rows have no text symbol
     const uint32_t last_e = last_d + (ok ? (uint32_t)g : 0u);
-    #pragma unroll 1
-    for (int wo = 0; wo < 17; ++wo)
+    #pragma unroll
+    for (int wo = 0; wo < 17; ++wo)                              // (statically indexed: tl / th are register arrays)
     {
         if (!__any( (uint32_t)wo * 32u <= last_e && !far && ok )) break;
         uint32_t ql[7], qh[7];
         #pragma unroll
-        for (int k = 0; k < 7; ++k) { ql[k] = 0u; qh[k] = 0u; }
-        #pragma unroll
-        for (int w = 0; w < 17; ++w)                             // (tl / th are register arrays: no dynamic index)
-            if (w == wo)
-            {
-                #pragma unroll
-                for (int k = 0; k < 7; ++k) { ql[k] = (w + k < 18) ? tl[w + k] : 0u; qh[k] = (w + k < 18) ? th[w + k] : 0u; }
-            }
+        for (int k = 0; k < 7; ++k) { ql[k] = (wo + k < 18) ? tl[wo + k] : 0u; qh[k] = (wo + k < 18) ? th[wo + k] : 0u; }
+        #pragma unroll 1
         for (uint32_t dd = 0; dd < 32u; ++dd)
         {
             const uint32_t d = (uint32_t)wo * 32u + dd;
