@@ -22,6 +22,7 @@ def main():
     import __graft_entry__ as ge
     amd = ge.load_package()
     pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    amd.DEFAULT_ALGO_FLAGS = int(os.environ.get("PE_ALGO_FLAGS", "0"))           # A/B: NVBIO_ALN_* switches of the DP calls (results never change)
     dev = "cuda:0"
     P = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 3_000_000_000
@@ -90,7 +91,7 @@ def main():
                       "mean_cigar_runs": [float((out["cigar_lens1"].to(torch.int64) & 0xFFFFFFFF).float().mean()),
                                           float((out["cigar_lens2"].to(torch.int64) & 0xFFFFFFFF).float().mean())],
                       "opposite_mate_effective_gcups": cells / (opp_ms * 1e-3) / 1e9 if opp_ms else None,
-                      "stage_ms": stage}), flush=True)
+                      "algo_flags": amd.DEFAULT_ALGO_FLAGS, "stage_ms": stage}), flush=True)
 
 
 if __name__ == "__main__":
