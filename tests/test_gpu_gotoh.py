@@ -314,7 +314,7 @@ def test_end_to_end_shortcut_edge_cases(amd, orc):
     assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2 | 128])
+@pytest.mark.parametrize("flags", [0, 1, 2 | 128, 1 | 32])       # 32: the packed kernel's 3-waves-per-SIMD build
 def test_end_to_end_banded_scoring_on_low_complexity_text(amd, orc, flags, monkeypatch):
     """band-31 end-to-end scoring where equal scores are everywhere: tandem repeats of period 1-7 with a few mutations, two-letter
     stretches, periodic reads, 0-5 substitutions and an occasional indel -- many diagonals and many single- and double-gap alignments
