@@ -450,21 +450,26 @@ ungapped_full_e2e_kernel(const BatchDev b, const int32_t P, const int32_t G, con
                 {
                     // rows fm .. M-1 of a diagonal past last_d have no text symbol: mismatches
                     const uint32_t fm = d > last_d ? (d - last_d < M ? M - (d - last_d) : 0u) : M;
+                    // first / last mismatching row, searched from the two ends and only as far as needed: on a diagonal that is not (nearly)
+                    // the read's own, word 0 and the top word already hold mismatches, and a word is evaluated by the wave only while some
+                    // lane is still looking -- 2-3 word evaluations per diagonal instead of 12 (the values are the same)
                     uint32_t first = M, last = 0xFFFFFFFFu;
                     #pragma unroll
-                    for (int k = 5; k >= 0; --k)
-                    {
-                        const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
-                        const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
-                        if (mm) first = 32u * k + (uint32_t)__builtin_ctz( mm );
-                    }
-                    #pragma unroll
                     for (int k = 0; k < 6; ++k)
-                    {
-                        const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
-                        const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
-                        if (mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
-                    }
+                        if (__any( first == M ))
+                        {
+                            const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
+                            const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
+                            if (first == M && mm) first = 32u * k + (uint32_t)__builtin_ctz( mm );
+                        }
+                    #pragma unroll
+                    for (int k = 5; k >= 0; --k)
+                        if (__any( last == 0xFFFFFFFFu ))
+                        {
+                            const uint32_t force = fm >= 32u * k + 32u ? 0u : (fm <= 32u * k ? 0xFFFFFFFFu : (0xFFFFFFFFu << (fm - 32u * k)));
+                            const uint32_t mm = ((((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) | force) & pm[k]) | pn[k];
+                            if (last == 0xFFFFFFFFu && mm) last = 32u * k + 31u - (uint32_t)__builtin_clz( mm );
+                        }
                     const uint32_t lead = first;
                     const uint32_t tail = (last == 0xFFFFFFFFu) ? M : M - 1u - last;
                     #pragma unroll
