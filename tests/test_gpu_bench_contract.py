@@ -40,6 +40,9 @@ def test_bench_json_contract(extra):
     assert r["gathered_sectors_per_launch"] > 0 and 0.5 < r["sectors_per_seed"] < 40.0       # about 1.07 on the 3 Gbp / k = 17 workload; rank steps dominate on this toy index
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]          # counter traffic comes from a named profile, never from thin air
     assert "i16" in d["dtype"] and d["extend"]["gcups"] > 0 and d["extend"]["effective_gcups"] >= d["extend"]["gcups"] * 0.5
+    # the DP kernel's own bound: instruction issue (a fraction of it, from the row loop's instruction count)
+    ib = d["extend"]["dp_issue_bound"]
+    assert ib["instructions_per_row"] > 300 and ib["cells_per_wave_row"] == 64 * 2 * 31 and 0.0 < ib["frac"] <= 1.0
     assert d["traceback"]["cigars_truncated"] == 0
     assert d["left_out_of_the_step"]["build"]["index_and_tables_s"] > 0
     c = d["cpu_baseline"]
