@@ -797,6 +797,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
         for (int k = 0; k < 7; ++k) { ql[k] = ql0[k]; qh[k] = qh0[k]; }
         uint32_t lead0_p[4] = { 0, 0, 0, 0 }, lead1_p[4] = { 0, 0, 0, 0 }, tail0_p[4] = { 0, 0, 0, 0 }, tail1_p[4] = { 0, 0, 0, 0 };   // d-1 .. d-4
         bool gapped = false;
+        uint32_t mwp[6] = { 0, 0, 0, 0, 0, 0 };
         for (uint32_t d = 0; d <= 31u && !gapped; ++d)
         {
             const bool have = d < 31u;                                                  // d = 31 only closes class C for b = 30
@@ -866,10 +867,8 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
                                 {
                                     const uint32_t hi_m = (a1 >= 32) ? 0xFFFFFFFFu : ((1u << a1) - 1u);
                                     const uint32_t lo_m = (1u << a0) - 1u;                                       // a0 < a1 <= 32 -> a0 <= 31
-                                    // word k of the middle diagonal d-1, from the untouched planes
-                                    const uint32_t tl = __builtin_amdgcn_alignbit( ql0[k + 1], ql0[k], d - 1u ), th = __builtin_amdgcn_alignbit( qh0[k + 1], qh0[k], d - 1u );
-                                    const uint32_t mw = (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k];
-                                    any = any || ((mw & hi_m & ~lo_m) != 0u);
+                                    // word k of the middle diagonal d-1: kept from the previous iteration
+                                    any = any || ((mwp[k] & hi_m & ~lo_m) != 0u);
                                 }
                             }
                         }
@@ -879,6 +878,11 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
             #pragma unroll
             for (int k = 3; k > 0; --k) { lead0_p[k] = lead0_p[k - 1]; lead1_p[k] = lead1_p[k - 1]; tail0_p[k] = tail0_p[k - 1]; tail1_p[k] = tail1_p[k - 1]; }
             lead0_p[0] = lead0; lead1_p[0] = lead1; tail0_p[0] = tail0; tail1_p[0] = tail1;
+            if (two11 && have)                                   // this diagonal's mismatch words: the middle diagonal of the next iteration
+            {
+                #pragma unroll
+                for (int k = 0; k < 6; ++k) mwp[k] = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
+            }
             #pragma unroll
             for (int k = 0; k < 6; ++k)
             {
