@@ -857,7 +857,26 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
                         // diagonal); only otherwise look at the words
                         const int32_t bf = (int32_t)lead0_p[0], bl = (int32_t)M - 1 - (int32_t)tail0_p[0];
                         bool any = (bf >= lo && bf < hi) || (tail0_p[0] < M && bl >= lo && bl < hi);
-                        if (!any)
+                        bool full = !any;
+                        if (__any( !any ))
+                        {
+                            // next: the 32 rows from lo on (two of b's words, picked by lo's word index) -- on an unrelated diagonal they hold a
+                            // mismatch, which settles it; only an interval that is longer AND clean so far walks all the words
+                            const uint32_t wi = (uint32_t)lo >> 5;
+                            uint32_t w_lo = mwp[0], w_hi = mwp[1];
+                            #pragma unroll
+                            for (int k = 1; k < 6; ++k)
+                            {
+                                const uint32_t next = k < 5 ? mwp[k < 5 ? k + 1 : 5] : 0u;
+                                w_lo = wi == (uint32_t)k ? mwp[k] : w_lo;
+                                w_hi = wi == (uint32_t)k ? next   : w_hi;
+                            }
+                            uint32_t rows32 = __builtin_amdgcn_alignbit( w_hi, w_lo, (uint32_t)lo & 31u );      // b's mismatches in rows lo .. lo + 31
+                            const int32_t span = hi - lo;                                                        // > 0 here
+                            if (span < 32) rows32 &= (1u << span) - 1u;
+                            if (!any && wi < 6u) { if (rows32) { any = true; full = false; } else if (span <= 32) full = false; }
+                        }
+                        if (full)
                         {
                             #pragma unroll
                             for (int k = 0; k < 6; ++k)
