@@ -674,9 +674,10 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     }
     else
     {
-        for (uint32_t d = 0; d < 31u; ++d)
+        #pragma unroll
+        for (uint32_t d = 0; d < 31u; ++d)                           // (unrolled, no early exit: a window is rarely clipped)
         {
-            if (!(d == 0u || d < m)) break;                          // reportable columns are a prefix of 0..30
+            const bool on = (d == 0u || d < m);                      // reportable columns are a prefix of 0..30
             uint32_t cnt = 0;
             #pragma unroll
             for (int k = 0; k < 6; ++k)
@@ -684,7 +685,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
                 const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
                 cnt += (uint32_t)__popc( mm );
             }
-            if (cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
+            if (on && cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
             #pragma unroll
             for (int k = 0; k < 6; ++k)
             {
