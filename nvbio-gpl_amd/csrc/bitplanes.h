@@ -76,6 +76,8 @@ __device__ __forceinline__ void read_planes192(const ReadWords<RBITS>& rw, const
     #pragma unroll
     for (int j = 0; j < ReadWords<RBITS>::N; ++j)
     {
+        // (the array covers 161 symbols at any offset; a wave of 150-symbol reads skips the words past their ends)
+        if (!__any( (uint32_t)j * RPW < roff + M )) continue;
         const uint32_t w = __brev( rw.w[j] );
         uint32_t lo, hi, nn;
         if (RBITS == 4)
