@@ -179,6 +179,13 @@ typedef struct
      *   [ base(r) + j*seed_interval, + fixed_len ),  base(r) = offsets_dev ? offsets_dev[r] : r*stride   */
     uint32_t        seeds_per_string;
     uint32_t        seed_interval;
+    /* ragged seed sets (reads of different lengths, each seeded at its own interval: nvBowtie computes both per read,
+     * mapping_inl.h:507-529, `read_len = range.y - range.x`, `seed_freq( read_len )`): seed_intervals_dev[r] = the seed interval of
+     * string r (n / seeds_per_string entries), or NULL.  With it offsets_dev holds n_strings + 1 entries (string r =
+     * [offsets[r], offsets[r+1]) ), seeds_per_string is the LARGEST number of seeds of a string -- the stride of seed ids, seed id =
+     * r * seeds_per_string + j -- and seed j of string r exists iff j * interval_r + fixed_len <= its length; a seed id without a seed
+     * matches nothing (the empty range (1, 0)).  seed_interval is ignored. */
+    const uint32_t* seed_intervals_dev;
 } nvbio_string_set;
 
 enum
@@ -324,7 +331,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
  *                                       reads: a tile's forward keys in seed order, then its reverse-strand keys in seed order
  *   residual_*_dev[0 .. counts_dev[1])                              forward-strand searches that ended on several rows (range, seed id)
  *   residual_*_dev[residual_capacity .. + counts_dev[2])            the same for the reverse strand
- * keys_dev: nvbio_fm_match_seed_diagonals_both_keys_capacity() entries (128 per tile of 64 / seeds_per_string reads: with
+ * keys_dev: nvbio_fm_match_seed_diagonals_both_keys_capacity() entries (256 per tile of 64 / seeds_per_string reads: with
  * NVBIO_FM_INLINE_HITS a seed can leave several keys, a tile at most 64 per strand -- slightly more than 2 * seeds->n when 64 is not a
  * multiple of seeds_per_string); residual arrays: 2 * residual_capacity entries, residual_capacity >= seeds->n.  counts_dev: 4 uint32
  * (6, 8-byte aligned, with NVBIO_FM_COUNT_SECTORS: the distinct 64-byte sectors gathered from the index as a uint64 at counts_dev + 4).
@@ -333,6 +340,12 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
  * ALL their diagonal keys in keys_dev (behind its tile's one-row keys, no duplicate removal) instead of a residual entry -- what
  * FMIndexFilter's scan + locate would add for it, without the trip; only larger ranges reach the residual lists. */
 #define NVBIO_FM_INLINE_HITS(h) (((uint32_t)(h) & 15u) << 8)
+/* NVBIO_FM_DEFER_HEAVY: the searches the table cannot answer (a k-mer with more than 8 occurrences; more hits on a strand than
+ * NVBIO_FM_INLINE_HITS) do not run inside the pass -- where every wave that holds one such window waits for its ten dependent gathers --
+ * but are collected and run as a dense launch of their own behind it: same keys and residual entries (their keys follow the others in
+ * keys_dev, without the adjacent-duplicate removal).  For repeat-rich references; on a unique-ish one it costs three short launches.
+ * Ragged reads (seeds->seed_intervals_dev): read_len is ignored, every read's length comes from its offsets. */
+#define NVBIO_FM_DEFER_HEAVY 64u
 nvbio_status nvbio_fm_match_seed_diagonals_both_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes);
 nvbio_status nvbio_fm_match_seed_diagonals_both_keys_capacity(const nvbio_string_set* seeds, uint64_t* n_keys);
 nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
@@ -392,6 +405,31 @@ nvbio_status nvbio_sort_unique_keys(int device, uint64_t* keys_dev, uint64_t n, 
 nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, uint32_t read_len,
                                         uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
                                         uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream);
+
+/* Ragged read batches (reads of different lengths: io::SequenceData's sequence_index; nvBowtie takes every read's length from its
+ * range, mapping_inl.h:507-529, score_inl.h:100-106): the same operators with read_offsets_dev (n_reads + 1 symbol offsets) in place
+ * of one read_len -- and, where a threshold depends on the read's length (MinScoreFunc, scoring.h:117-129), min_scores_dev[r] =
+ * scheme.min_score( length of read r ) computed by the caller. */
+nvbio_status nvbio_diagonals_to_windows_ragged(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, const uint32_t* read_offsets_dev,
+                                               uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                               uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream);
+nvbio_status nvbio_fm_filter_locate_diagonals_ragged(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                                     const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                                     uint32_t seeds_per_read, uint32_t seed_len, const uint32_t* read_offsets_dev,
+                                                     const uint32_t* seed_intervals_dev, uint32_t strand, const uint32_t* query_ids_dev,
+                                                     uint64_t* keys_dev, void* stream);
+nvbio_status nvbio_traceback_best_batch_ragged(int device, const uint64_t* best_dev, const int64_t* best_wb_dev, uint32_t n_reads,
+                                               const uint32_t* read_offsets_dev, uint32_t band, uint32_t genome_len, const int32_t* min_scores_dev,
+                                               uint8_t* flags_dev, uint32_t* win_begin_dev, uint32_t* win_end_dev, int32_t* scores_dev,
+                                               nvbio_uint2* sinks_dev, void* stream);
+/* distinct_dist = (length of the candidate's read) / 2, worst_score = min_scores_dev[read] - 1 */
+nvbio_status nvbio_second_candidate_reduce_ragged(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                  const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev,
+                                                  const uint32_t* read_offsets_dev, const int32_t* min_scores_dev, uint64_t* second_dev, void* stream);
+/* perfect_score = match x (length of the read), min_score = min_scores_dev[read], monotone = (match == 0) */
+nvbio_status nvbio_mapq_ragged(int device, const uint64_t* best_dev, const uint64_t* second_dev, uint32_t n_reads, int32_t version, int32_t match,
+                               const uint32_t* read_offsets_dev, const int32_t* min_scores_dev, int32_t* second_scores_dev, uint8_t* mapq_dev,
+                               void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * nvBowtie's scoring stream, as data: what a specialisation of aln::BatchedBandedAlignmentScore for
@@ -583,6 +621,12 @@ enum
                                               row-restricted full-matrix kernel instead of the band-15 traceback kernel           */
     NVBIO_ALN_PK_STRIPE8            = 256, /* packed full-matrix scoring of end-to-end jobs (match = 0): the general kernel, 8 pattern columns per
                                               stripe, instead of the end-to-end one that sweeps 16 (A/B)                          */
+    NVBIO_ALN_RAGGED_READS          = 4096, /* a HINT, the only flag that is not an A/B switch: the batch's reads differ in length.  The packed band-31
+                                              end-to-end kernel -- two alignments per lane -- then runs a build that takes a lane's two alignments
+                                              in one pass whatever their lengths (the shorter one starts late); without the hint such a lane takes
+                                              two passes.  Results are identical either way.                                        */
+    NVBIO_ALN_NO_QUALITY_SHORTCUT   = 2048, /* band-31 end-to-end scoring of reads WITH base qualities under a quality-dependent mismatch penalty
+                                              (nvBowtie's default ramp): every job through the DP, as before round 3 (A/B)          */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs
                                               whose optimal paths provably stay within 7 diagonals of the sink)                  */
 };

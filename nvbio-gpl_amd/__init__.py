@@ -27,13 +27,14 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvbio_amd.h")
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 SCORE_MIN = -(1 << 30)
-FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS, FM_NO_PIPELINE = 1, 2, 4, 8, 16, 32
+FM_SCAN_FORWARD, FM_COMPLEMENT, FM_NO_KMER_TABLE, FM_NO_VERIFY, FM_COUNT_SECTORS, FM_NO_PIPELINE, FM_DEFER_HEAVY = 1, 2, 4, 8, 16, 32, 64
 FM_TABLE_NO_DIRECT, FM_TABLE_NO_CONTEXT, FM_TABLE_NO_GROUPS, FM_TABLE_CANONICAL, FM_TABLE_CANONICAL_WIDE = 1, 2, 4, 8, 16      # nvbio_fm_build_options::table_flags
 READ_REVERSE, READ_COMPLEMENT = 1, 2
 TRACEBACK_SINKS_GIVEN = 1
 # nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)
 ALN_NO_UNGAPPED_SCORE, ALN_NO_THIRD_CHANCE, ALN_NO_PACKED_DP, ALN_FORCE_PACKED_DP, ALN_NO_UNGAPPED_TRACEBACK, ALN_PK_THREE_WAVES = 1, 2, 4, 8, 16, 32
 ALN_NO_NARROW_TRACEBACK, ALN_NO_SECOND_CHANCE, ALN_PK_STRIPE8, ALN_NO_NARROW_SCORE, ALN_NO_BAND_ROUTE = 64, 128, 256, 512, 1024
+ALN_NO_QUALITY_SHORTCUT, ALN_RAGGED_READS = 2048, 4096
 DEFAULT_ALGO_FLAGS = 0          # what an AlignmentBatch is created with unless told otherwise (tests set it for a whole run)
 BACKTRACK_REFERENCE_QUIRKS = 1
 
@@ -62,7 +63,8 @@ class _StringSet(ctypes.Structure):
     _fields_ = [("symbols_dev", ctypes.c_void_p), ("symbol_bits", ctypes.c_uint32),
                 ("offsets_dev", ctypes.c_void_p), ("offsets_are_ranges", ctypes.c_uint32),
                 ("fixed_len", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("n", ctypes.c_uint32),
-                ("seeds_per_string", ctypes.c_uint32), ("seed_interval", ctypes.c_uint32)]
+                ("seeds_per_string", ctypes.c_uint32), ("seed_interval", ctypes.c_uint32),
+                ("seed_intervals_dev", ctypes.c_void_p)]
 
 
 class _Scheme(ctypes.Structure):
@@ -193,7 +195,7 @@ class PackedStringSet:
     """
 
     def __init__(self, symbols, bits, n, offsets=None, ranges=False, fixed_len=0, stride=None, device="cuda:0",
-                 seeds_per_string=0, seed_interval=0):
+                 seeds_per_string=0, seed_interval=0, seed_intervals=None):
         torch = _torch()
         self.bits, self.n = int(bits), int(n)
         self.symbols = _dev_tensor(symbols, torch.uint8 if bits == 8 else torch.int32, device)
@@ -203,10 +205,13 @@ class PackedStringSet:
         self.device = device
         # seed enumeration: n = n_strings * seeds_per_string queries [base(r) + j*seed_interval, + fixed_len)
         self.seeds_per_string, self.seed_interval = int(seeds_per_string), int(seed_interval)
+        # ragged seed sets: one seed interval per string (int32 [n_strings]); offsets then hold n_strings + 1 entries and
+        # seeds_per_string is the largest seed count of a string (the stride of seed ids)
+        self.seed_intervals = _dev_tensor(seed_intervals, torch.int32, device)
 
     def c_struct(self):
         return _StringSet(_ptr(self.symbols), self.bits, _ptr(self.offsets), 1 if self.ranges else 0,
-                          self.fixed_len, self.stride, self.n, self.seeds_per_string, self.seed_interval)
+                          self.fixed_len, self.stride, self.n, self.seeds_per_string, self.seed_interval, _ptr(self.seed_intervals))
 
 
 # ---- FM-index ----------------------------------------------------------------------------------
@@ -388,7 +393,7 @@ class FMIndex:
     def canonical(self):
         return self.canonical_kmer != 0
 
-    def match_seed_diagonals_both(self, seeds, read_len, buffers=None, flags=0, grid_blocks=0, inline_hits=0):
+    def match_seed_diagonals_both(self, seeds, read_len, buffers=None, flags=0, grid_blocks=0, inline_hits=0, defer_heavy=False):
         """the seed pass of BOTH strands in one launch over the canonical table (nvbio_fm_match_seed_diagonals_both) -> the buffers dict:
         "keys" int64 (the first counts[0]: both strands, tile by tile), "ranges" int32 [2 n, 2] / "ids" int32 [2 n]: residual seeds on
         several rows, forward strand in [0, counts[1]), reverse strand in [n, n + counts[2]); "counts" int32 [6] on the device.
@@ -411,7 +416,7 @@ class FMIndex:
             buffers["temp"] = torch.empty(nb.value, dtype=torch.uint8, device=self.device)
         assert grid_blocks % 64 == 0 and grid_blocks < (1 << 22)
         _check(lib().nvbio_fm_match_seed_diagonals_both(
-            self._h, ctypes.byref(qs), ctypes.c_uint32(flags | ((int(inline_hits) & 15) << 8) | ((grid_blocks // 64) << 16)),
+            self._h, ctypes.byref(qs), ctypes.c_uint32(flags | (FM_DEFER_HEAVY if defer_heavy else 0) | ((int(inline_hits) & 15) << 8) | ((grid_blocks // 64) << 16)),
             ctypes.c_uint32(read_len),
             _ptr(buffers["keys"]), _ptr(buffers["ranges"]), _ptr(buffers["ids"]), ctypes.c_uint32(n), _ptr(buffers["counts"]),
             _ptr(buffers["temp"]), ctypes.c_uint64(buffers["temp"].numel()), _stream_ptr(self.device)))
@@ -515,12 +520,19 @@ class FMIndexFilter:
                                             ctypes.c_uint64(end), _ptr(hits), _stream_ptr(self._index.device)))
         return hits
 
-    def locate_diagonals(self, begin, end, seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids=None):
+    def locate_diagonals(self, begin, end, seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids=None, read_offsets=None,
+                         seed_intervals=None):
         """locate() and hits_to_diagonals() in one pass (nvbio_fm_filter_locate_diagonals): int64 keys
         read << 34 | strand << 33 | diagonal + 1024 of hit indices [begin, end); query_ids: the seed id of every range when
         the ranges are a compacted subset (FMIndex.match_seed_diagonals' residual list)"""
         torch = _torch()
         keys = torch.empty(end - begin, dtype=torch.int64, device=self._index.device)
+        if read_offsets is not None:                 # ragged reads: every read's length and seed interval
+            _check(lib().nvbio_fm_filter_locate_diagonals_ragged(
+                self._index._h, _ptr(self._ranges), _ptr(self._slots), _ptr(self._direct), ctypes.c_uint32(self._n_queries),
+                ctypes.c_uint64(begin), ctypes.c_uint64(end), ctypes.c_uint32(seeds_per_read), ctypes.c_uint32(seed_len), _ptr(read_offsets),
+                _ptr(seed_intervals), ctypes.c_uint32(strand), _ptr(query_ids), _ptr(keys), _stream_ptr(self._index.device)))
+            return keys
         _check(lib().nvbio_fm_filter_locate_diagonals(
             self._index._h, _ptr(self._ranges), _ptr(self._slots), _ptr(self._direct), ctypes.c_uint32(self._n_queries),
             ctypes.c_uint64(begin), ctypes.c_uint64(end), ctypes.c_uint32(seeds_per_read), ctypes.c_uint32(seed_interval),
@@ -874,7 +886,7 @@ def best_candidate_windows(keys, scores, sinks, win_begin, best, best_wb, best_l
                                               _stream_ptr(keys.device)))
 
 
-def traceback_best_batch(best, best_wb, read_len, band, genome_len, min_score):
+def traceback_best_batch(best, best_wb, read_len, band, genome_len, min_score, read_offsets=None, min_scores=None):
     """nvbio_traceback_best_batch: the per-read arrays of the traceback batch of every read's best alignment ->
     (flags uint8, win_begin int32, win_end int32, scores int32, sinks int32 [R, 2]); unaligned reads get the empty window"""
     torch = _torch()
@@ -882,6 +894,11 @@ def traceback_best_batch(best, best_wb, read_len, band, genome_len, min_score):
     flags = torch.empty(n, dtype=torch.uint8, device=dev)
     wb = torch.empty(n, dtype=torch.int32, device=dev); we = torch.empty(n, dtype=torch.int32, device=dev)
     scores = torch.empty(n, dtype=torch.int32, device=dev); sinks = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    if read_offsets is not None:                     # ragged reads (read_len / min_score are ignored)
+        _check(lib().nvbio_traceback_best_batch_ragged(FMIndex._dev_index(dev), _ptr(best), _ptr(best_wb), ctypes.c_uint32(n), _ptr(read_offsets),
+                                                       ctypes.c_uint32(band), ctypes.c_uint32(genome_len), _ptr(min_scores), _ptr(flags),
+                                                       _ptr(wb), _ptr(we), _ptr(scores), _ptr(sinks), _stream_ptr(dev)))
+        return flags, wb, we, scores, sinks
     _check(lib().nvbio_traceback_best_batch(FMIndex._dev_index(dev), _ptr(best), _ptr(best_wb), ctypes.c_uint32(n), ctypes.c_uint32(read_len),
                                             ctypes.c_uint32(band), ctypes.c_uint32(genome_len), ctypes.c_int32(min_score), _ptr(flags),
                                             _ptr(wb), _ptr(we), _ptr(scores), _ptr(sinks), _stream_ptr(dev)))
@@ -911,22 +928,32 @@ class _MapqParams(ctypes.Structure):
                 ("min_score", ctypes.c_int32)]
 
 
-def second_candidate_reduce(keys, scores, sinks, wb, best, distinct_dist, worst_score, second):
+def second_candidate_reduce(keys, scores, sinks, wb, best, distinct_dist, worst_score, second, read_offsets=None, min_scores=None):
     """nvBowtie's second-best alignment per read (score_reduce, reduce_inl.h:65-140; see nvbio_second_candidate_reduce):
     best must already hold the final per-read maxima over ALL candidates; second is zero-initialised by the caller"""
+    if read_offsets is not None:                     # ragged reads: distinct_dist = read_len / 2 and worst_score = min_score - 1 per read
+        _check(lib().nvbio_second_candidate_reduce_ragged(FMIndex._dev_index(keys.device), _ptr(keys), _ptr(scores), _ptr(sinks), _ptr(wb),
+                                                          ctypes.c_uint64(keys.shape[0]), _ptr(best), _ptr(read_offsets), _ptr(min_scores),
+                                                          _ptr(second), _stream_ptr(keys.device)))
+        return second
     _check(lib().nvbio_second_candidate_reduce(FMIndex._dev_index(keys.device), _ptr(keys), _ptr(scores), _ptr(sinks), _ptr(wb),
                                                ctypes.c_uint64(keys.shape[0]), _ptr(best), ctypes.c_uint32(distinct_dist),
                                                ctypes.c_int32(worst_score), _ptr(second), _stream_ptr(keys.device)))
     return second
 
 
-def mapq(best, second, perfect_score, min_score, monotone, version=2):
+def mapq(best, second, perfect_score, min_score, monotone, version=2, read_offsets=None, min_scores=None, match=0):
     """Bowtie2's mapping quality per read from the best / second-best selection keys (BowtieMapq2 / BowtieMapq3,
     nvBowtie/bowtie2/cuda/mapq.h) -> (mapq uint8 [R], second_score int32 [R])"""
     torch = _torch()
     R = best.shape[0]
     q = torch.empty(R, dtype=torch.uint8, device=best.device)
     ss = torch.empty(R, dtype=torch.int32, device=best.device)
+    if read_offsets is not None:                     # ragged reads: perfect score = match x length, min score per read
+        _check(lib().nvbio_mapq_ragged(FMIndex._dev_index(best.device), _ptr(best), _ptr(second) if second is not None else None,
+                                       ctypes.c_uint32(R), ctypes.c_int32(int(version)), ctypes.c_int32(int(match)), _ptr(read_offsets),
+                                       _ptr(min_scores), _ptr(ss), _ptr(q), _stream_ptr(best.device)))
+        return q, ss
     prm = _MapqParams(int(version), 1 if monotone else 0, int(perfect_score), int(min_score))
     _check(lib().nvbio_mapq(FMIndex._dev_index(best.device), _ptr(best), _ptr(second) if second is not None else None,
                             ctypes.c_uint32(R), ctypes.byref(prm), _ptr(ss), _ptr(q), _stream_ptr(best.device)))
@@ -948,7 +975,7 @@ def opposite_mate_windows(g_pos, anchor_rc, anchor_len, opposite_gapped_len, anc
     return wb, we, flags, valid
 
 
-def diagonals_to_windows(keys, band, read_len, genome_len):
+def diagonals_to_windows(keys, band, read_len, genome_len, read_offsets=None):
     """genome_infixes + nvBowtie's window rule: (read_id, flags, win_begin, win_end) of every candidate key"""
     torch = _torch()
     n, dev = keys.numel(), keys.device
@@ -956,6 +983,11 @@ def diagonals_to_windows(keys, band, read_len, genome_len):
     fl = torch.empty(n, dtype=torch.uint8, device=dev)
     wb = torch.empty(n, dtype=torch.int32, device=dev)
     we = torch.empty(n, dtype=torch.int32, device=dev)
+    if read_offsets is not None:                     # ragged reads: window end = begin + band + the read's own length
+        _check(lib().nvbio_diagonals_to_windows_ragged(FMIndex._dev_index(dev), _ptr(keys), ctypes.c_uint64(n), ctypes.c_uint32(band),
+                                                       _ptr(read_offsets), ctypes.c_uint32(genome_len), _ptr(rid), _ptr(fl),
+                                                       _ptr(wb), _ptr(we), _stream_ptr(dev)))
+        return rid, fl, wb, we
     _check(lib().nvbio_diagonals_to_windows(FMIndex._dev_index(dev), _ptr(keys), ctypes.c_uint64(n), ctypes.c_uint32(band),
                                             ctypes.c_uint32(read_len), ctypes.c_uint32(genome_len), _ptr(rid), _ptr(fl),
                                             _ptr(wb), _ptr(we), _stream_ptr(dev)))

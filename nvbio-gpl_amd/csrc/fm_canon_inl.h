@@ -227,27 +227,42 @@ static nvbio_status build_canonical_table(FMIndexImpl* idx, const uint32_t k, co
 // the seed pass of both strands: one wave per tile of whole reads, software-pipelined over the tiles a wave owns as
 // fm_seed_pipe_kernel (words of tile t+2 | table entry of tile t+1 | resolution of tile t).  A tile has 128 key slots: the keys of the
 // forward strand (at most 64), those of the reverse strand right behind them; tile_counts[tile] = both.  Seeds whose k-mer has more than
-// 8 occurrences, or with several hits on a strand (a repeat longer than the seed), take the ordinary search of that strand
-// (plain table + rank steps + finish on the text) inside the kernel; what ends on several rows goes to that strand's residual
+// 8 occurrences, or with several hits on a strand (a repeat longer than the seed), need the ordinary search of that strand
+// (plain table + rank steps + finish on the text): what ends on several rows goes to that strand's residual
 // list: ranges / ids [0, cap) forward, [cap, 2 cap) reverse; counts[1], counts[2].
+// DEFER = false: that search runs inside this kernel, in the lane that needs it (every wave that holds one such lane pays its ten
+//   dependent gathers: fine on a unique-ish genome where one window in 10^5 needs it, 2.6x the kernel's time when 5 % do).
+// DEFER = true (NVBIO_FM_DEFER_HEAVY): the lane only records (seed id | strand << 31) in its tile's 128 deferred slots
+//   (tile_defer / defer_counts, compacted like the keys); fm_seed_heavy_kernel then runs those searches as a dense launch of their own.
+// Ragged reads (q.intervals): read r has its own length (offsets[r+1] - offsets[r]) and seed interval; lane (read, j) holds a seed iff
+//   j x interval + len fits the read; q.spr is the largest seed count of a read (the stride of seed ids).
 // ---------------------------------------------------------------------------------------------
 // WIDE: 16-byte entries (NVBIO_FM_TABLE_CANONICAL_WIDE): a k-mer with TWO occurrences has both rows in its entry, groups start at three
-template <int BITS, bool COUNT, bool WIDE>
+template <int BITS, bool COUNT, bool WIDE, bool DEFER>
 __global__ void __launch_bounds__(256)
 fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, const uint32_t read_len, const uint32_t inline_max,
                     uint64_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_counts, uint2* __restrict__ res_ranges,
-                    uint32_t* __restrict__ res_ids, const uint32_t res_cap, unsigned int* __restrict__ counts, unsigned long long* __restrict__ sectors_out)
+                    uint32_t* __restrict__ res_ids, const uint32_t res_cap, unsigned int* __restrict__ counts, unsigned long long* __restrict__ sectors_out,
+                    uint32_t* __restrict__ tile_defer, uint32_t* __restrict__ defer_counts)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t k = f.ckmer, len = q.fixed_len, r = len - k;
     const uint32_t lr = lane / q.spr, j = lane - lr * q.spr;
     const bool lane_ok = lr < tl.rpt;
+    const bool ragged = q.intervals != nullptr;
     const uint32_t rmask = (1u << (2u * r)) - 1u;                            // r <= 7
     const uint32_t fshift = 2u * (CTAB_FLANK - r);
     DevIndex fplain = f; fplain.dtab = nullptr; fplain.dkmer = 0;            // the fallback searches use the plain table only
 
-    auto seed_begin = [&](const uint32_t rid) -> uint32_t { return (q.offsets ? q.offsets[rid] : rid * q.stride) + j * q.interval; };
+    // the seed of this lane in read rid: where it begins in the symbol stream, its offset in the read, the read's length; false: no such seed
+    auto seed_geom = [&](const uint32_t rid, uint32_t& begin, uint32_t& p_fw, uint32_t& rlen) -> bool {
+        const uint32_t base = q.offsets ? q.offsets[rid] : rid * q.stride;
+        p_fw  = j * (ragged ? q.intervals[rid] : q.interval);
+        rlen  = ragged ? q.offsets[rid + 1] - base : read_len;
+        begin = base + p_fw;
+        return !ragged || p_fw + len <= rlen;
+    };
     auto entry_of = [&](const uint64_t V, uint32_t& qo) -> uint4 {
         const uint64_t key = V >> (2u * r);
         qo = (uint32_t)(key >> k) & 1u;
@@ -264,24 +279,34 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
 
     uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= tl.n_tiles) return;
-    SeedWords W = { 0, 0, 0, 0, 0 }; uint32_t w_begin = 0; bool w_valid = false;
-    uint64_t V = 0; uint4 e = make_uint4( 1u, 0u, 0u, 0u ); bool e_valid = false; uint32_t qo = 0;
+    // stage 1 -> 2 (the tile after the current one): packed words, where they begin, the seed's offset in its read, the read's length
+    SeedWords W = { 0, 0, 0, 0, 0 }; uint32_t w_begin = 0, w_pfw = 0, w_rlen = 0; bool w_valid = false;
+    // stage 2 -> 3 (the current tile): seed bits, table entry, orientation
+    uint64_t V = 0; uint4 e = make_uint4( 1u, 0u, 0u, 0u ); bool e_valid = false; uint32_t qo = 0, c_pfw = 0, c_rlen = 0; bool c_seed = false;
     {
         const uint32_t rid = tile * tl.rpt + lr;
         if (lane_ok && rid < tl.reads)
         {
-            const uint32_t b0 = seed_begin( rid );
-            const SeedWords W0 = load_seed_words<BITS>( q.symbols, b0, len );
-            e_valid = seed_bits_from_words<BITS>( W0, b0, len, false, false, V );
-            if (e_valid) e = entry_of( V, qo );
+            uint32_t b0;
+            c_seed = seed_geom( rid, b0, c_pfw, c_rlen );
+            if (c_seed)
+            {
+                const SeedWords W0 = load_seed_words<BITS>( q.symbols, b0, len );
+                e_valid = seed_bits_from_words<BITS>( W0, b0, len, false, false, V );
+                if (e_valid) e = entry_of( V, qo );
+            }
         }
         const uint32_t t1 = tile + n_waves, rid1 = t1 * tl.rpt + lr;
-        if (t1 < tl.n_tiles && lane_ok && rid1 < tl.reads) { w_begin = seed_begin( rid1 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); w_valid = true; }
+        if (t1 < tl.n_tiles && lane_ok && rid1 < tl.reads)
+        {
+            w_valid = seed_geom( rid1, w_begin, w_pfw, w_rlen );
+            if (w_valid) W = load_seed_words<BITS>( q.symbols, w_begin, len );
+        }
     }
     for (; tile < tl.n_tiles; tile += n_waves)
     {
         const uint32_t rid = tile * tl.rpt + lr;
-        const bool valid = lane_ok && rid < tl.reads;
+        const bool valid = lane_ok && rid < tl.reads && c_seed;
         // ---- stage 3a: the kind of entry; the group of a k-mer with 2..8 occurrences is requested ----
         const bool is_one   = e_valid && e.y >= DTAB_MARK && e.x < DTAB_MARK;
         const bool is_group = e_valid && e.y >= DTAB_MARK && e.x >= DTAB_MARK;
@@ -296,6 +321,7 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
         }
         // ---- stage 2 for the next tile ----
         uint64_t Vn = 0; uint4 en = make_uint4( 1u, 0u, 0u, 0u ); bool en_valid = false; uint32_t qon = 0;
+        const uint32_t n_pfw = w_pfw, n_rlen = w_rlen; const bool n_seed = w_valid;
         if (w_valid)
         {
             en_valid = seed_bits_from_words<BITS>( W, w_begin, len, false, false, Vn );
@@ -305,7 +331,8 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
         {
             const uint32_t t2 = tile + 2u * n_waves, rid2 = t2 * tl.rpt + lr;
             w_valid = t2 < tl.n_tiles && lane_ok && rid2 < tl.reads;
-            if (w_valid) { w_begin = seed_begin( rid2 ); W = load_seed_words<BITS>( q.symbols, w_begin, len ); }
+            if (w_valid) w_valid = seed_geom( rid2, w_begin, w_pfw, w_rlen );
+            if (w_valid) W = load_seed_words<BITS>( q.symbols, w_begin, len );
         }
         // ---- stage 3b: resolve the current tile ----
         const uint32_t rest = (uint32_t)V & rmask;                           // the seed's first r symbols, reversed (scan order)
@@ -340,13 +367,14 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
         uint32_t sectors = e_valid ? (is_group ? 2u : 1u) : 0u;
         const uint32_t i = rid * q.spr + j;
         uint32_t tile_fill = 0;                                              // keys of this tile written so far: the reverse strand's follow the forward strand's
+        uint32_t defer_fill = 0;                                             // deferred searches of this tile recorded so far (DEFER)
         #pragma unroll
         for (int s = 0; s < 2; ++s)
         {
             // what this strand leaves: cnt keys (positions pos[s][0 .. cnt)), or the range (rx, ry) of several rows for the residual list
-            uint32_t cnt = (valid && !is_heavy && hits[s] <= inline_max) ? hits[s] : 0u;
+            uint32_t cnt = (valid && e_valid && !is_heavy && hits[s] <= inline_max) ? hits[s] : 0u;
             uint32_t rx = 1u, ry = 0u;
-            bool searched = false;
+            bool searched = false, deferred = false;
             const uint32_t sflags = s ? (NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT) : 0u;
             auto plain_search = [&]() -> bool {                              // the ordinary search of this strand: range (rx, ry) or a position
                 uint32_t nblk, sec = 0; bool single = false;
@@ -354,10 +382,11 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
                 sectors += sec; searched = true;
                 return single;
             };
-            if (valid && (is_heavy || hits[s] > inline_max))
+            if (valid && e_valid && (is_heavy || hits[s] > inline_max))
             {
                 cnt = 0u;
-                if (plain_search()) { pos[s][0] = rx; cnt = 1u; }
+                if (DEFER) deferred = true;
+                else if (plain_search()) { pos[s][0] = rx; cnt = 1u; }
                 else if (rx <= ry && ry - rx < inline_max)                   // 1 .. inline_max rows: their positions from the suffix array
                 {
                     cnt = ry - rx + 1u;
@@ -374,19 +403,20 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
             for (uint32_t t = 0; t < CTAB_INLINE; ++t) total += (uint32_t)__popcll( __ballot( cnt >= 2u && t < cnt ) );
             if (total > 64u && cnt >= 2u)
             {
-                if (!searched) (void)plain_search();
+                if (DEFER) { deferred = true; rx = 1u; ry = 0u; }
+                else if (!searched) (void)plain_search();
                 cnt = 0u;
             }
             uint64_t* slots = tile_keys + (uint64_t)tile * 128u + tile_fill;
             uint32_t n_out = 0; uint64_t last = ~0ull;
             const uint32_t x1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? rx : 1u), y1 = cnt == 1u ? pos[s][0] : (cnt == 0u ? ry : 0u);
-            emit_seed_results( q, len, read_len, (uint32_t)s, lane, valid, cnt == 1u, x1, y1, rid, j, i, slots, n_out, last,
+            emit_seed_results( c_pfw, len, c_rlen, (uint32_t)s, lane, valid, cnt == 1u, x1, y1, rid, i, slots, n_out, last,
                                res_ranges + (s ? res_cap : 0u), res_ids + (s ? res_cap : 0u), counts + s );
             // seeds with 2 .. inline_max hits on this strand: their keys behind the tile's one-hit keys, no duplicate removal
             if (__ballot( cnt >= 2u ))
             {
-                uint32_t pq = j * q.interval;
-                if (s) pq = read_len - pq - len;
+                uint32_t pq = c_pfw;
+                if (s) pq = c_rlen - pq - len;
                 #pragma unroll
                 for (uint32_t t = 0; t < CTAB_INLINE; ++t)
                 {
@@ -398,8 +428,17 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
                 }
             }
             tile_fill += n_out;
+            if (DEFER)
+            {
+                const uint64_t md = __ballot( deferred );
+                if (md)
+                {
+                    if (deferred) tile_defer[(uint64_t)tile * 128u + defer_fill + (uint32_t)__popcll( md & ((1ull << lane) - 1ull) )] = i | ((uint32_t)s << 31);
+                    defer_fill += (uint32_t)__popcll( md );
+                }
+            }
         }
-        if (lane == 0) tile_counts[tile] = tile_fill;
+        if (lane == 0) { tile_counts[tile] = tile_fill; if (DEFER) defer_counts[tile] = defer_fill; }
         if (COUNT)
         {
             uint32_t tot = valid ? sectors : 0u;
@@ -407,6 +446,98 @@ fm_seed_both_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
             for (int d = 32; d > 0; d >>= 1) tot += (uint32_t)__shfl_xor( (int)tot, d );
             if (lane == 0 && tot) atomicAdd( sectors_out, (unsigned long long)tot );
         }
-        V = Vn; e = en; e_valid = en_valid; qo = qon;
+        V = Vn; e = en; e_valid = en_valid; qo = qon; c_pfw = n_pfw; c_rlen = n_rlen; c_seed = n_seed;
+    }
+}
+
+// The deferred searches of fm_seed_both_kernel<.., DEFER = true> as a dense launch: entry t of `list` (n = *n_list) is
+// (seed id | strand << 31); the ordinary search of that strand (plain table + rank steps + finish on the text) ends on
+//   one text occurrence       -> its diagonal key, appended behind the compacted keys (keys_out + counts[0], counts[0] advanced)
+//   several rows (a repeat)   -> that strand's residual list (counts[1 + strand]), as the in-line search would
+//   nothing                   -> nothing.
+// Every lane runs four searches, then the workgroup appends what they left with ONE returning atomic per output list (a wave-level
+// append per list would put 2 x 10^5 atomics on two neighbouring words for 9 M searches: at ~11 ns each, longer than the searches).
+constexpr uint32_t HEAVY_PER_LANE = 4u;
+template <int BITS>
+__global__ void __launch_bounds__(256)
+fm_seed_heavy_kernel(const DevIndex f, const StringSetDev q, const uint32_t read_len, const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                     uint64_t* __restrict__ keys_out, uint2* __restrict__ res_ranges, uint32_t* __restrict__ res_ids, const uint32_t res_cap,
+                     unsigned int* __restrict__ counts)
+{
+    __shared__ uint32_t s_cnt[4][3], s_base[3];
+    const uint32_t n = *n_list;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t len = q.fixed_len;
+    const bool ragged = q.intervals != nullptr;
+    DevIndex fplain = f; fplain.dtab = nullptr; fplain.dkmer = 0;
+    const uint32_t chunk = 256u * HEAVY_PER_LANE;
+    for (uint32_t c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk)           // (block-uniform trip count: the barriers below are safe)
+    {
+        uint32_t kind[HEAVY_PER_LANE], vx[HEAVY_PER_LANE], vy[HEAVY_PER_LANE], ent[HEAVY_PER_LANE];
+        uint32_t nk = 0, nr0 = 0, nr1 = 0;                                            // this lane's keys / forward residuals / reverse residuals
+        #pragma unroll
+        for (uint32_t u = 0; u < HEAVY_PER_LANE; ++u)
+        {
+            const uint32_t t = c0 + u * 256u + threadIdx.x;
+            kind[u] = 0u; vx[u] = 1u; vy[u] = 0u; ent[u] = 0u;
+            if (t < n)
+            {
+                ent[u] = list[t];
+                const uint32_t i = ent[u] & 0x7FFFFFFFu, s = ent[u] >> 31;
+                uint32_t rx, ry, nblk; bool single;
+                match_one<BITS,false,true,true>( fplain, q, s ? (NVBIO_FM_SCAN_FORWARD | NVBIO_FM_COMPLEMENT) : 0u, f.ktab != nullptr, false, i, rx, ry, nblk, single );
+                if (!single && rx == ry) { const uint32_t sv = f.ssa[rx]; rx = ry = (sv == 0xFFFFFFFFu) ? f.length : sv; single = true; }
+                if (single)        { kind[u] = 1u; vx[u] = rx; ++nk; }
+                else if (rx < ry)  { kind[u] = 2u + s; vx[u] = rx; vy[u] = ry; if (s) ++nr1; else ++nr0; }
+            }
+        }
+        // exclusive prefix of the three counts within the wave, wave totals to LDS, one atomic per list and workgroup
+        uint32_t pk = nk, p0 = nr0, p1 = nr1;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const uint32_t a = (uint32_t)__shfl_up( (int)pk, d ), b = (uint32_t)__shfl_up( (int)p0, d ), c = (uint32_t)__shfl_up( (int)p1, d );
+            if (lane >= (uint32_t)d) { pk += a; p0 += b; p1 += c; }
+        }
+        if (lane == 63u) { s_cnt[wave][0] = pk; s_cnt[wave][1] = p0; s_cnt[wave][2] = p1; }
+        __syncthreads();
+        if (threadIdx.x < 3u)
+        {
+            const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+            s_base[threadIdx.x] = tot ? atomicAdd( &counts[threadIdx.x], tot ) : 0u;
+        }
+        __syncthreads();
+        uint32_t ok = s_base[0] + (pk - nk), o0 = s_base[1] + (p0 - nr0), o1 = s_base[2] + (p1 - nr1);
+        for (uint32_t w = 0; w < wave; ++w) { ok += s_cnt[w][0]; o0 += s_cnt[w][1]; o1 += s_cnt[w][2]; }
+        #pragma unroll
+        for (uint32_t u = 0; u < HEAVY_PER_LANE; ++u)
+        {
+            const uint32_t i = ent[u] & 0x7FFFFFFFu, s = ent[u] >> 31;
+            if (kind[u] == 1u)
+            {
+                const uint32_t rid = i / q.spr, j = i - rid * q.spr;
+                uint32_t pq = j * (ragged ? q.intervals[rid] : q.interval);
+                const uint32_t rlen = ragged ? q.offsets[rid + 1] - q.offsets[rid] : read_len;
+                if (s) pq = rlen - pq - len;
+                keys_out[ok++] = ((uint64_t)rid << 34) | ((uint64_t)s << 33) | ((uint64_t)vx[u] + 1024u - pq);
+            }
+            else if (kind[u] == 2u) { res_ranges[o0] = make_uint2( vx[u], vy[u] ); res_ids[o0] = i; ++o0; }
+            else if (kind[u] == 3u) { res_ranges[res_cap + o1] = make_uint2( vx[u], vy[u] ); res_ids[res_cap + o1] = i; ++o1; }
+        }
+        __syncthreads();                                                              // s_cnt / s_base are reused by the next chunk
+    }
+}
+
+// the deferred slots of every tile made dense (as fm_seed_compact_kernel does with the keys); counts_out[0] = their number
+__global__ void __launch_bounds__(256)
+fm_seed_defer_compact_kernel(const uint32_t* __restrict__ tile_defer, const uint32_t* __restrict__ defer_counts, const uint32_t* __restrict__ defer_offsets,
+                             const uint32_t n_tiles, uint32_t* __restrict__ list, uint32_t* __restrict__ n_out)
+{
+    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += gridDim.x * blockDim.x)
+    {
+        const uint32_t n = defer_counts[tile], off = defer_offsets[tile];
+        const uint32_t* src = tile_defer + (uint64_t)tile * 128u;
+        for (uint32_t k = 0; k < n; ++k) list[off + k] = src[k];
+        if (tile == n_tiles - 1u) n_out[0] = off + n;
     }
 }

@@ -73,15 +73,19 @@ struct StringSetDev
     uint32_t        n;
     uint32_t        spr;         // seeds per string (0: plain string set)
     uint32_t        interval;    // seed interval
+    const uint32_t* intervals;   // ragged seed sets: the seed interval of every string (offsets then hold n_strings + 1 entries)
 };
 
-__device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint32_t i, uint32_t& begin, uint32_t& len)
+// false: query i is a seed id of a ragged seed set beyond its string's last seed -- it matches nothing
+__device__ __forceinline__ bool string_bounds(const StringSetDev& q, const uint32_t i, uint32_t& begin, uint32_t& len)
 {
     if (q.spr)
     {
         const uint32_t r = i / q.spr, j = i - r * q.spr;
-        begin = (q.offsets ? q.offsets[r] : r * q.stride) + j * q.interval;
+        const uint32_t base = q.offsets ? q.offsets[r] : r * q.stride;
+        begin = base + j * (q.intervals ? q.intervals[r] : q.interval);
         len   = q.fixed_len;
+        if (q.intervals && begin + len > q.offsets[r + 1]) return false;
     }
     else if (q.offsets)
     {
@@ -89,6 +93,7 @@ __device__ __forceinline__ void string_bounds(const StringSetDev& q, const uint3
         len   = q.ranges ? q.offsets[i + 1] - begin : q.fixed_len;
     }
     else { begin = i * q.stride; len = q.fixed_len; }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,7 +271,12 @@ __device__ __forceinline__ void match_one(const DevIndex& f, const StringSetDev&
     const bool fwd  = (flags & NVBIO_FM_SCAN_FORWARD) != 0;
     const bool comp = (flags & NVBIO_FM_COMPLEMENT) != 0;
     uint32_t begin, len;
-    string_bounds( q, i, begin, len );
+    if (!string_bounds( q, i, begin, len ))
+    {
+        x_out = 1u; y_out = 0u; nblk_out = 0u; is_pos_out = false;
+        if (sectors_out) *sectors_out = 0u;
+        return;
+    }
     SymbolReader<BITS> rd( q.symbols );
 
     // symbol s in scan order
@@ -350,8 +360,9 @@ struct SeedTiles
 //   * the tile's keys, in seed order, a key equal to its predecessor dropped -- ballot + popcount, the predecessor's key
 //     through ds_bpermute: no LDS, no barrier;
 //   * the residual list, one atomic per wave that has any seed on several rows.
-__device__ __forceinline__ void emit_seed_results(const StringSetDev& q, const uint32_t len, const uint32_t read_len, const uint32_t strand, const uint32_t lane,
-                                                  const bool valid, const bool single, const uint32_t x, const uint32_t y, const uint32_t rid, const uint32_t j,
+// p_fw: the seed's offset in its read (j x the read's seed interval); read_len: that read's length
+__device__ __forceinline__ void emit_seed_results(const uint32_t p_fw, const uint32_t len, const uint32_t read_len, const uint32_t strand, const uint32_t lane,
+                                                  const bool valid, const bool single, const uint32_t x, const uint32_t y, const uint32_t rid,
                                                   const uint32_t i, uint64_t* __restrict__ tile_slots, uint32_t& n_out, uint64_t& last_key,
                                                   uint2* __restrict__ res_ranges, uint32_t* __restrict__ res_ids, unsigned int* __restrict__ counts)
 {
@@ -359,7 +370,7 @@ __device__ __forceinline__ void emit_seed_results(const StringSetDev& q, const u
     uint64_t key = 0;
     if (single)
     {
-        uint32_t p = j * q.interval;
+        uint32_t p = p_fw;
         if (strand) p = read_len - p - len;
         key = ((uint64_t)rid << 34) | ((uint64_t)(strand & 1u) << 33) | ((uint64_t)x + 1024u - p);
     }
@@ -460,7 +471,7 @@ fm_seed_tiles_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl,
                 for (int d = 32; d > 0; d >>= 1) tot += (uint32_t)__shfl_xor( (int)tot, d );
                 if (lane == 0 && tot) atomicAdd( sectors_out, (unsigned long long)tot );
             }
-            emit_seed_results( q, len, read_len, strand, lane, valid, single, x, y, rid, j, i, tile_keys + (uint64_t)tile * 64u * rounds, n_out, last_key,
+            emit_seed_results( j * q.interval, len, read_len, strand, lane, valid, single, x, y, rid, i, tile_keys + (uint64_t)tile * 64u * rounds, n_out, last_key,
                                res_ranges, res_ids, counts );
         }
         if (lane == 0) tile_counts[tile] = n_out;
@@ -568,7 +579,7 @@ fm_seed_pipe_kernel(const DevIndex f, const StringSetDev q, const SeedTiles tl, 
             }
         }
         uint32_t n_out = 0; uint64_t last_key = ~0ull;
-        emit_seed_results( q, len, read_len, strand, lane, valid, single, x, y, rid, j, rid * q.spr + j, tile_keys + (uint64_t)tile * 64u, n_out, last_key,
+        emit_seed_results( j * q.interval, len, read_len, strand, lane, valid, single, x, y, rid, rid * q.spr + j, tile_keys + (uint64_t)tile * 64u, n_out, last_key,
                            res_ranges, res_ids, counts );
         if (lane == 0) tile_counts[tile] = n_out;
         V = Vn; e = en; e_valid = en_valid;
@@ -894,7 +905,8 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t* __restrict__
 
 // seed enumeration of a hit's query id -> its diagonal key (hit_to_diagonal, examples/fmmap/fmmap.cu:92-117; see
 // nvbio_hits_to_diagonals): with KEYS the expansion writes the 8-byte key instead of the (position, query) pair
-struct DiagSpec { uint32_t spr, interval, seed_len, read_len, strand; const uint32_t* qid; };   // qid: optional seed id of every query
+// qid: optional seed id of every query; read_offsets / intervals: ragged reads (every read's length and seed interval)
+struct DiagSpec { uint32_t spr, interval, seed_len, read_len, strand; const uint32_t* qid; const uint32_t* read_offsets; const uint32_t* intervals; };
 
 template <bool KEYS>
 __global__ void __launch_bounds__(256)
@@ -940,8 +952,8 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
                         const uint32_t sid = ds.qid ? (qv & 0x7FFFFFFFu) : qv;
                         const uint32_t str = (ds.strand ^ (ds.qid ? qv >> 31 : 0u)) & 1u;
                         const uint32_t rid = sid / ds.spr;
-                        uint32_t       p   = (sid - rid * ds.spr) * ds.interval;
-                        if (str) p = ds.read_len - p - ds.seed_len;
+                        uint32_t       p   = (sid - rid * ds.spr) * (ds.intervals ? ds.intervals[rid] : ds.interval);
+                        if (str) p = (ds.read_offsets ? ds.read_offsets[rid + 1] - ds.read_offsets[rid] : ds.read_len) - p - ds.seed_len;
                         keys[h - begin] = ((uint64_t)rid << 34) | ((uint64_t)str << 33) | ((uint64_t)pos + 1024u - p);
                     }
                     else hits[h - begin] = make_uint2( pos, slot );
@@ -965,8 +977,8 @@ static nvbio_status make_set(const nvbio_string_set* s, StringSetDev* d)
     NVB_REQUIRE( !(s->offsets_are_ranges && s->offsets_dev == nullptr), "offsets_are_ranges without offsets_dev" );
     d->symbols = s->symbols_dev; d->offsets = s->offsets_dev; d->ranges = s->offsets_are_ranges;
     d->fixed_len = s->fixed_len; d->stride = s->stride; d->n = s->n;
-    d->spr = s->seeds_per_string; d->interval = s->seed_interval;
-
+    d->spr = s->seeds_per_string; d->interval = s->seed_interval; d->intervals = s->seed_intervals_dev;
+    NVB_REQUIRE( d->intervals == nullptr || (d->spr > 0 && d->offsets != nullptr), "seed_intervals_dev needs seeds_per_string > 0 and offsets_dev (n_strings + 1 entries)" );
     return NVBIO_OK;
 }
 
@@ -1592,6 +1604,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     StringSetDev q; NVB_CHECK( make_set( seeds, &q ) );
     NVB_REQUIRE( counts_dev != nullptr, "counts_dev is NULL" );
     NVB_REQUIRE( q.spr > 0, "the string set must enumerate seeds (seeds_per_string > 0)" );
+    NVB_REQUIRE( q.intervals == nullptr, "ragged seed sets (seed_intervals_dev) go through nvbio_fm_match_seed_diagonals_both" );
     NVB_REQUIRE( (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
     NVB_REQUIRE( q.fixed_len > 0, "empty seeds" );
     if (!(idx->text && idx->view.ssa_dev && idx->view.sa_int == 1))
@@ -1663,8 +1676,10 @@ int nvbio_fm_index_is_canonical(nvbio_fm_index_t index)
     return index != nullptr && ((FMIndexImpl*)index)->ctab != nullptr ? (int)((FMIndexImpl*)index)->ckmer : 0;
 }
 
-// scratch of the two-strand pass: 128 key slots and 2 counts per tile
-static nvbio_status seed_both_layout(const nvbio_string_set* seeds, SeedScratch* L)
+// scratch of the two-strand pass: 128 key slots and 2 counts per tile; with NVBIO_FM_DEFER_HEAVY also 128 deferred slots (uint32) and 2 counts per
+// tile, the dense list of deferred searches and its length
+struct SeedBothScratch { SeedScratch L; uint64_t defer_bytes, list_bytes; };
+static nvbio_status seed_both_layout(const nvbio_string_set* seeds, SeedScratch* L, SeedBothScratch* B = nullptr)
 {
     NVB_CHECK( seed_scratch_layout( seeds, L ) );
     NVB_REQUIRE( seeds->seeds_per_string <= 64u, "the two-strand seed pass takes at most 64 seeds per read" );
@@ -1675,7 +1690,11 @@ static nvbio_status seed_both_layout(const nvbio_string_set* seeds, SeedScratch*
     if (L->tl.n_tiles)
         NVB_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)L->tl.n_tiles, (hipStream_t)0 ) );
     L->scan_bytes = ((uint64_t)scan + 255u) & ~255ull;
-    L->total = L->keys_bytes + 2u * L->counts_bytes + L->scan_bytes + 256u;
+    const uint64_t defer_bytes = ((uint64_t)L->tl.n_tiles * 128u * sizeof(uint32_t) + 255u) & ~255ull;
+    const uint64_t list_bytes  = ((uint64_t)L->tl.n_tiles * 128u * sizeof(uint32_t) + 255u) & ~255ull;
+    // keys | counts | offsets | scan temp | deferred slots | deferred counts | deferred offsets | dense deferred list | its length
+    L->total = L->keys_bytes + 2u * L->counts_bytes + L->scan_bytes + defer_bytes + 2u * L->counts_bytes + list_bytes + 256u + 256u;
+    if (B) { B->L = *L; B->defer_bytes = defer_bytes; B->list_bytes = list_bytes; }
     return NVBIO_OK;
 }
 
@@ -1691,7 +1710,8 @@ nvbio_status nvbio_fm_match_seed_diagonals_both_keys_capacity(const nvbio_string
 {
     NVB_REQUIRE( n_keys != nullptr, "n_keys is NULL" );
     SeedScratch L; NVB_CHECK( seed_both_layout( seeds, &L ) );
-    *n_keys = 128ull * L.tl.n_tiles;                            // a tile of 64 / seeds_per_string reads can leave up to 64 keys per strand
+    // a tile of 64 / seeds_per_string reads can leave up to 64 keys per strand, and (NVBIO_FM_DEFER_HEAVY) one more per deferred search
+    *n_keys = 256ull * L.tl.n_tiles;
     return NVBIO_OK;
 }
 
@@ -1712,16 +1732,18 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     NVB_REQUIRE( q.spr > 0 && q.spr <= 64u, "the string set must enumerate 1..64 seeds per read (seeds_per_string)" );
     NVB_REQUIRE( seeds->symbol_bits == 2 || seeds->symbol_bits == 4, "packed seeds (2 or 4 bits per symbol)" );
     NVB_REQUIRE( q.fixed_len >= idx->ckmer && q.fixed_len - idx->ckmer <= CTAB_FLANK, "seed length outside [kmer_len, kmer_len + 7]" );
-    NVB_REQUIRE( (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( q.intervals != nullptr || (uint64_t)(q.spr - 1u) * q.interval + q.fixed_len <= read_len, "seeds do not fit the read" );
     NVB_REQUIRE( residual_capacity >= q.n, "residual_capacity must be at least the number of seeds" );
+    NVB_REQUIRE( q.n < (1u << 31), "at most 2^31 - 1 seeds per call (bit 31 of a seed id carries the strand)" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     const bool count = (flags & NVBIO_FM_COUNT_SECTORS) != 0;
+    const bool defer = (flags & NVBIO_FM_DEFER_HEAVY) != 0 && !count;
     NVB_REQUIRE( !count || ((uintptr_t)counts_dev & 7u) == 0, "counts_dev must be 8-byte aligned with NVBIO_FM_COUNT_SECTORS" );
     NVB_HIP( hipMemsetAsync( counts_dev, 0, (count ? 6 : 4) * sizeof(uint32_t), s ) );
     if (q.n == 0) return NVBIO_OK;
     NVB_REQUIRE( keys_dev && residual_ranges_dev && residual_ids_dev, "NULL device pointer" );
-    SeedScratch L; NVB_CHECK( seed_both_layout( seeds, &L ) );
+    SeedScratch L; SeedBothScratch B; NVB_CHECK( seed_both_layout( seeds, &L, &B ) );
     uint8_t* temp = (uint8_t*)temp_dev;
     bool own_temp = false;
     if (temp == nullptr)
@@ -1735,6 +1757,12 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     uint32_t* tile_counts  = (uint32_t*)(base + L.keys_bytes);
     uint32_t* tile_offsets = (uint32_t*)(base + L.keys_bytes + L.counts_bytes);
     void*     scan_temp    = base + L.keys_bytes + 2u * L.counts_bytes;
+    uint8_t*  dbase        = base + L.keys_bytes + 2u * L.counts_bytes + L.scan_bytes;
+    uint32_t* tile_defer    = (uint32_t*)dbase;
+    uint32_t* defer_counts  = (uint32_t*)(dbase + B.defer_bytes);
+    uint32_t* defer_offsets = (uint32_t*)(dbase + B.defer_bytes + L.counts_bytes);
+    uint32_t* defer_list    = (uint32_t*)(dbase + B.defer_bytes + 2u * L.counts_bytes);
+    uint32_t* defer_n       = (uint32_t*)(dbase + B.defer_bytes + 2u * L.counts_bytes + B.list_bytes);
     const DevIndex f = idx->dev();
     unsigned blocks = (L.tl.n_tiles + 3u) / 4u;
     const unsigned cap = (flags >> 16) ? (flags >> 16) * 64u : 256u * 64u;
@@ -1743,14 +1771,16 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     // flags bits 8..11: a seed with up to that many hits on a strand leaves them all as keys (0/1: only one-hit seeds do)
     uint32_t inline_max = (flags >> 8) & 15u;
     inline_max = inline_max < 1u ? 1u : (inline_max > CTAB_INLINE ? CTAB_INLINE : inline_max);
-#define NVB_LAUNCH_SB(BITS, CNT) if (idx->cwide) NVB_LAUNCH_SBW( BITS, CNT, true ); else NVB_LAUNCH_SBW( BITS, CNT, false )
-#define NVB_LAUNCH_SBW(BITS, CNT, W) hipLaunchKernelGGL( (fm_seed_both_kernel<BITS,CNT,W>), grid, block, 0, s, f, q, L.tl, read_len, inline_max, tile_keys, tile_counts, \
+#define NVB_LAUNCH_SBD(BITS, CNT, W, D) hipLaunchKernelGGL( (fm_seed_both_kernel<BITS,CNT,W,D>), grid, block, 0, s, f, q, L.tl, read_len, inline_max, tile_keys, tile_counts, \
                                     (uint2*)residual_ranges_dev, residual_ids_dev, residual_capacity, (unsigned int*)counts_dev,                         \
-                                    CNT ? (unsigned long long*)(counts_dev + 4) : (unsigned long long*)nullptr )
-    if (seeds->symbol_bits == 2) { if (count) NVB_LAUNCH_SB( 2, true ); else NVB_LAUNCH_SB( 2, false ); }
-    else                         { if (count) NVB_LAUNCH_SB( 4, true ); else NVB_LAUNCH_SB( 4, false ); }
+                                    CNT ? (unsigned long long*)(counts_dev + 4) : (unsigned long long*)nullptr, tile_defer, defer_counts )
+#define NVB_LAUNCH_SBW(BITS, W) do { if (count) NVB_LAUNCH_SBD( BITS, true, W, false ); else if (defer) NVB_LAUNCH_SBD( BITS, false, W, true ); \
+                                     else NVB_LAUNCH_SBD( BITS, false, W, false ); } while (0)
+#define NVB_LAUNCH_SB(BITS) do { if (idx->cwide) NVB_LAUNCH_SBW( BITS, true ); else NVB_LAUNCH_SBW( BITS, false ); } while (0)
+    if (seeds->symbol_bits == 2) NVB_LAUNCH_SB( 2 ); else NVB_LAUNCH_SB( 4 );
 #undef NVB_LAUNCH_SB
 #undef NVB_LAUNCH_SBW
+#undef NVB_LAUNCH_SBD
     hipError_t e = hipGetLastError();
     size_t scan_bytes = L.scan_bytes;
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)tile_counts, tile_offsets, (int)L.tl.n_tiles, s );
@@ -1759,6 +1789,26 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
         hipLaunchKernelGGL( fm_seed_compact_kernel, dim3( grid_for( 4ull * L.tl.n_tiles ) ), block, 0, s, (const uint64_t*)tile_keys, (const uint32_t*)tile_counts,
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, 128u, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
+    }
+    if (e == hipSuccess && defer)
+    {
+        // the deferred searches: their slots made dense, then a launch of their own that appends to the keys and the residual lists
+        scan_bytes = L.scan_bytes;
+        e = hipcub::DeviceScan::ExclusiveSum( scan_temp, scan_bytes, (const uint32_t*)defer_counts, defer_offsets, (int)L.tl.n_tiles, s );
+        if (e == hipSuccess)
+        {
+            hipLaunchKernelGGL( fm_seed_defer_compact_kernel, dim3( grid_for( L.tl.n_tiles ) ), block, 0, s, (const uint32_t*)tile_defer, (const uint32_t*)defer_counts,
+                                (const uint32_t*)defer_offsets, L.tl.n_tiles, defer_list, defer_n );
+            const uint64_t max_chunks = (128ull * L.tl.n_tiles + 256u * HEAVY_PER_LANE - 1u) / (256u * HEAVY_PER_LANE);
+            const dim3 hgrid( (unsigned)(max_chunks < 4096u ? (max_chunks ? max_chunks : 1u) : 4096u) );
+            if (seeds->symbol_bits == 2)
+                hipLaunchKernelGGL( (fm_seed_heavy_kernel<2>), hgrid, block, 0, s, f, q, read_len, (const uint32_t*)defer_list, (const uint32_t*)defer_n, keys_dev,
+                                    (uint2*)residual_ranges_dev, residual_ids_dev, residual_capacity, (unsigned int*)counts_dev );
+            else
+                hipLaunchKernelGGL( (fm_seed_heavy_kernel<4>), hgrid, block, 0, s, f, q, read_len, (const uint32_t*)defer_list, (const uint32_t*)defer_n, keys_dev,
+                                    (uint2*)residual_ranges_dev, residual_ids_dev, residual_capacity, (unsigned int*)counts_dev );
+            e = hipGetLastError();
+        }
     }
     if (own_temp) (void)hipFreeAsync( temp, s );
     if (e != hipSuccess) { set_error( "seed pass failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
@@ -1781,24 +1831,46 @@ nvbio_status nvbio_fm_filter_locate_direct(nvbio_fm_index_t index, const nvbio_u
     return NVBIO_OK;
 }
 
-nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
-                                              const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
-                                              uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
-                                              uint32_t strand, const uint32_t* query_ids_dev, uint64_t* keys_dev, void* stream)
+static nvbio_status filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                            const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                            uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                            uint32_t strand, const uint32_t* query_ids_dev, const uint32_t* read_offsets_dev,
+                                            const uint32_t* seed_intervals_dev, uint64_t* keys_dev, void* stream)
 {
     NVB_REQUIRE( index != nullptr, "index is NULL" );
     if (end <= begin) return NVBIO_OK;
     NVB_REQUIRE( ranges_dev && slots_dev && keys_dev, "NULL device pointer" );
     NVB_REQUIRE( seeds_per_read > 0, "seeds_per_read must be positive" );
-    NVB_REQUIRE( (uint64_t)(seeds_per_read - 1u) * seed_interval + seed_len <= read_len, "seeds do not fit the read" );
+    NVB_REQUIRE( (read_offsets_dev == nullptr) == (seed_intervals_dev == nullptr), "ragged reads need both read_offsets_dev and seed_intervals_dev" );
+    NVB_REQUIRE( read_offsets_dev != nullptr || (uint64_t)(seeds_per_read - 1u) * seed_interval + seed_len <= read_len, "seeds do not fit the read" );
     FMIndexImpl* idx = (FMIndexImpl*)index;
     NVB_REQUIRE( idx->view.ssa_dev, "index has no sampled suffix array" );
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
-    const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids_dev };
+    const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, strand, query_ids_dev, read_offsets_dev, seed_intervals_dev };
     hipLaunchKernelGGL( fm_filter_locate_kernel<true>, dim3( grid_for( (end - begin + FILTER_TILE - 1u) / FILTER_TILE * 256u ) ), dim3(256), 0, (hipStream_t)stream,
                         idx->dev(), (const uint2*)ranges_dev, slots_dev, n_queries, begin, end, (uint2*)nullptr, direct_dev, ds, keys_dev );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
+}
+
+nvbio_status nvbio_fm_filter_locate_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                              const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                              uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                              uint32_t strand, const uint32_t* query_ids_dev, uint64_t* keys_dev, void* stream)
+{
+    return filter_locate_diagonals( index, ranges_dev, slots_dev, direct_dev, n_queries, begin, end, seeds_per_read, seed_interval, seed_len, read_len,
+                                    strand, query_ids_dev, nullptr, nullptr, keys_dev, stream );
+}
+
+nvbio_status nvbio_fm_filter_locate_diagonals_ragged(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint64_t* slots_dev,
+                                                     const uint8_t* direct_dev, uint32_t n_queries, uint64_t begin, uint64_t end,
+                                                     uint32_t seeds_per_read, uint32_t seed_len, const uint32_t* read_offsets_dev,
+                                                     const uint32_t* seed_intervals_dev, uint32_t strand, const uint32_t* query_ids_dev,
+                                                     uint64_t* keys_dev, void* stream)
+{
+    NVB_REQUIRE( read_offsets_dev && seed_intervals_dev, "read_offsets_dev and seed_intervals_dev are required" );
+    return filter_locate_diagonals( index, ranges_dev, slots_dev, direct_dev, n_queries, begin, end, seeds_per_read, 0u, seed_len, 0u,
+                                    strand, query_ids_dev, read_offsets_dev, seed_intervals_dev, keys_dev, stream );
 }
 
 

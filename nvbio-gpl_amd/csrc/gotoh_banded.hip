@@ -261,7 +261,11 @@ __device__ __forceinline__ uint32_t even_bits64(uint64_t x)
 // state spill (the scratch accesses sit outside the row loop).  2 waves leave 256: nothing spills.  Which is faster is measured, not
 // assumed: 3 waves won while the row loop still had idle issue slots to fill; with the hand-ordered loop 2 waves are 4 % ahead and
 // are the default, NVBIO_ALN_PK_THREE_WAVES runs the other build.
-template <int TYPE, int RBITS, int MINW = 3, bool M0 = false>
+// RAGGED (GLOBAL / SEMI_GLOBAL; NVBIO_ALN_RAGGED_READS): a lane whose two alignments differ in length still takes ONE pass: the shorter one
+// starts late, at row pad = (rows of the longer) - (its own rows), so that both end in the same row and report from the band there.  Its
+// streams are read at row - pad (before its start it computes on whatever they hold), and in the row it starts its half of the band and of
+// the text cache is set to the initial state -- one extra wave-level branch per row while some lane of the wave is still waiting to start.
+template <int TYPE, int RBITS, int MINW = 3, bool M0 = false, bool RAGGED = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MINW, 3)))
 banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
                               const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
@@ -317,6 +321,9 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     auto read_chunk_start = [&](const int u, const uint32_t r0) -> int64_t {
         return rev[u] ? (int64_t)first[u] + (int64_t)M[u] - 1 - (int64_t)r0 - 7 : (int64_t)first[u] + r0;
     };
+    auto read_chunk_start_at = [&](const int u, const int64_t r0) -> int64_t {      // RAGGED: rows before the alignment's start are negative
+        return rev[u] ? (int64_t)first[u] + (int64_t)M[u] - 1 - r0 - 7 : (int64_t)first[u] + r0;
+    };
 
     const uint32_t qadj = (uint32_t)((uintptr_t)b.quals & 3u);      // the quality stream need not be 4-byte aligned
     const uint32_t* __restrict__ qwords = (const uint32_t*)((uintptr_t)b.quals - qadj);
@@ -342,7 +349,11 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     // (two passes, one half active each); equal lengths -- the normal case for a read batch -- take one pass.
     // LOCAL reports every cell as it goes and always takes one pass.
     const bool want0 = valid[0] && N[0] >= M[0], want1 = valid[1] && N[1] >= M[1];
-    const bool split = (TYPE != NVBIO_LOCAL) && want0 && want1 && M[0] != M[1];
+    const bool split = (TYPE != NVBIO_LOCAL) && !RAGGED && want0 && want1 && M[0] != M[1];
+    // RAGGED: rows the shorter alignment waits before it starts
+    const uint32_t rows_max = rows_all[0] > rows_all[1] ? rows_all[0] : rows_all[1];
+    uint32_t pad[2] = { 0u, 0u };
+    if (RAGGED && TYPE != NVBIO_LOCAL) { pad[0] = rows_max - rows_all[0]; pad[1] = rows_max - rows_all[1]; }
 
     for (int pass = 0; pass < (split ? 2 : 1); ++pass)
     {
@@ -354,7 +365,7 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
         // ---- text cache: two bit planes per alignment, c0 / c1 = low / high bits of the symbols.  Inside a row column j sits at bit
         // 30-j: the row's incoming symbol (column 30) is shifted in at bit 0 (one v_alignbit per plane) and every other column
         // thereby moves to the next row's position; between rows the planes hold columns 0..29 at bits 29-j ------------------------
-        uint32_t c0[2], c1[2];
+        uint32_t c0[2], c1[2], c0i[2] = { 0, 0 }, c1i[2] = { 0, 0 };
         #pragma unroll
         for (int u = 0; u < 2; ++u)
         {
@@ -370,6 +381,7 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
             // even / odd bits of c, gathered: column j at bit 31-j, moved to bit 29-j (the row's incoming symbol is shifted in at bit 0)
             c0[u] = even_bits64( c ) >> 2;
             c1[u] = even_bits64( c >> 1 ) >> 2;
+            if (RAGGED) { c0i[u] = c0[u]; c1i[u] = c1[u]; }
         }
 
         // ---- stream words for chunk 0 (loaded now, consumed at the top of the loop) ----------------------
@@ -381,7 +393,7 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                 {
-                    const int64_t qw  = (read_chunk_start( u, r0 ) + qadj) >> 2;        // byte position / 4
+                    const int64_t qw  = ((RAGGED ? read_chunk_start_at( u, (int64_t)r0 - pad[u] ) : read_chunk_start( u, r0 )) + qadj) >> 2;        // byte position / 4
                     const uint32_t lo = (first[u] + qadj) >> 2, hi = (first[u] + qadj + (M[u] ? M[u] - 1u : 0u)) >> 2;
                     qa[u] = qwords[clamp_u32( qw,     lo, hi )];
                     qb[u] = qwords[clamp_u32( qw + 1, lo, hi )];
@@ -391,12 +403,13 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
             #pragma unroll
             for (int u = 0; u < 2; ++u)
             {
-                const int64_t  rbit = read_chunk_start( u, r0 ) * RBITS;
+                const int64_t  rbit = (RAGGED ? read_chunk_start_at( u, (int64_t)r0 - pad[u] ) : read_chunk_start( u, r0 )) * RBITS;
                 const int64_t  rw   = rbit >> 5;                          // arithmetic shift: floor for negatives
                 ra[u]  = rwords[clamp_u32( rw,     r_lo[u], r_hi[u] )];
                 rb[u]  = rwords[clamp_u32( rw + 1, r_lo[u], r_hi[u] )];
-                const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);  // text symbol entering column 30 at row r0
-                const int64_t  tw   = (int64_t)(tpos >> 4);
+                // text symbol entering column 30 at row r0 (RAGGED: of the alignment's own row r0 - pad, possibly before the window)
+                const int64_t  tw   = RAGGED ? (((int64_t)tb[u] + (int64_t)r0 - pad[u] + (BAND - 1)) >> 4)
+                                             : (int64_t)(((uint64_t)tb[u] + r0 + (BAND - 1)) >> 4);
                 ta[u]  = twords[clamp_u32( tw,     t_lo[u], t_hi[u] )];
                 tbw[u] = twords[clamp_u32( tw + 1, t_lo[u], t_hi[u] )];
             }
@@ -422,21 +435,22 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                 if (has_quals)
                 {
                     // 8 quality bytes of the chunk, byte k of the chunk at bits [8k, 8k+7] (memory order)
-                    const uint32_t bs = ((uint32_t)((read_chunk_start( u, r0 ) + qadj) & 3)) * 8u;
+                    const uint32_t bs = ((uint32_t)(((RAGGED ? read_chunk_start_at( u, (int64_t)r0 - pad[u] ) : read_chunk_start( u, r0 )) + qadj) & 3)) * 8u;
                     const uint32_t lo = bs ? ((qa[u] >> bs) | (qb[u] << (32u - bs))) : qa[u];
                     const uint32_t hi = bs ? ((qb[u] >> bs) | (qc[u] << (32u - bs))) : qb[u];
                     qchunk[u] = ((uint64_t)hi << 32) | lo;
                 }
                 qsh[u] = rev[u] ? 56 : 0; qstep[u] = rev[u] ? -8 : 8;
-                const int64_t rbit = read_chunk_start( u, r0 ) * RBITS;
+                const int64_t rbit = (RAGGED ? read_chunk_start_at( u, (int64_t)r0 - pad[u] ) : read_chunk_start( u, r0 )) * RBITS;
                 rchunk[u] = funnel32( ra[u], rb[u], (uint32_t)(rbit & 31) );
                 rsh[u]    = rev[u] ? (32 - RBITS) - 7 * RBITS : (32 - RBITS);   // row 0 of the chunk: last / first symbol
                 rstep[u]  = rev[u] ? RBITS : -RBITS;
-                const uint64_t tpos = (uint64_t)tb[u] + r0 + (BAND - 1);
-                uint32_t tc = funnel32( ta[u], tbw[u], (uint32_t)(tpos & 15u) * 2u );
+                const uint32_t tsym = RAGGED ? (uint32_t)(((int64_t)tb[u] + (int64_t)r0 - pad[u] + (BAND - 1)) & 15)
+                                             : (uint32_t)(((uint64_t)tb[u] + r0 + (BAND - 1)) & 15u);
+                uint32_t tc = funnel32( ta[u], tbw[u], tsym * 2u );
                 // symbols at or past the text end enter the cache as 3 (the 255 sentinel through a 2-bit cache): symbol k of the
                 // chunk is text symbol r0 + 30 + k
-                const int64_t kk = (int64_t)N[u] - (int64_t)(BAND - 1) - (int64_t)r0;
+                const int64_t kk = RAGGED ? (int64_t)N[u] - (int64_t)(BAND - 1) - ((int64_t)r0 - pad[u]) : (int64_t)N[u] - (int64_t)(BAND - 1) - (int64_t)r0;
                 if (kk < 16) tc |= (kk <= 0) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (2u * (uint32_t)kk));
                 tchunk[u]  = tc;                                     // top bit = high bit of the next symbol
                 tchunk1[u] = tc << 1;                                // top bit = its low bit
@@ -447,6 +461,23 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
             for (uint32_t t = 0; t < r_end; ++t)
             {
                 const uint32_t i = r0 + t;
+                if (RAGGED && TYPE != NVBIO_LOCAL)
+                {
+                    // an alignment that starts in this row: its half of the band and of the text cache to the initial state
+                    const bool s0 = pad[0] != 0u && i == pad[0], s1 = pad[1] != 0u && i == pad[1];
+                    if (s0 || s1)
+                    {
+                        #pragma unroll
+                        for (int j = 0; j < BAND; ++j)
+                        {
+                            const int h0 = (TYPE == NVBIO_GLOBAL && j > 0) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;
+                            if (s0) { H[j].x = (short)h0; F[j].x = (short)-16384; Hg[j].x = (short)(h0 + sc.pat_go); }
+                            if (s1) { H[j].y = (short)h0; F[j].y = (short)-16384; Hg[j].y = (short)(h0 + sc.pat_go); }
+                        }
+                        if (s0) { c0[0] = c0i[0]; c1[0] = c1i[0]; }
+                        if (s1) { c0[1] = c0i[1]; c1[1] = c1i[1]; }
+                    }
+                }
                 // the row's pattern symbols / mismatch scores, the text symbols entering column 30, and the row's mismatch flags:
                 // nq(u) bit 30-j = column j of alignment u does NOT match (31 columns from the two planes; an N in the read matches
                 // nothing; a column-30 symbol past the text end is the 255 sentinel for this row and a 3 once it is in the cache).
@@ -472,7 +503,7 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                     tchunk[u] <<= 2; tchunk1[u] <<= 2;
                     uint32_t x = (c0[u] ^ (0u - (q & 1u))) | (c1[u] ^ (0u - ((q >> 1) & 1u)));
                     if (RBITS > 2 && q >= 4u) x = 0xFFFFFFFFu;
-                    if (i >= lim[u]) x |= 1u;                         // column 30 past the text end
+                    if (i >= (RAGGED ? lim[u] + pad[u] : lim[u])) x |= 1u;      // column 30 past the text end
                     nq[u] = x;
                 }
                 // both alignments side by side: column j >= 15 at bits 30-j / 46-j of NWa, column j < 15 at bits 14-j / 30-j of NWb
@@ -597,12 +628,25 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
 //   every wave paid for them whenever one lane needed one (the second chance, one job in four, was HALF of this kernel's 1.46 ms).
 // MODE 1 / 2: the pass over the dense list of the need_dp = 3 / 2 jobs (job_list / job_count on the device): the second / third chance,
 //   each job ends as 0 or 1.
-template <int RBITS, int MODE>
+// QUAL (MODE 0 only): the mismatch penalty depends on the row's base quality (nvBowtie's default ramp, scoring.h:73-92), P = the
+//   scheme's SMALLEST penalty (> 0).  U_d = -(sum of the penalties of diagonal d's mismatching rows) lies between -pmax c_d and
+//   -P c_d for c_d mismatches, so only diagonals with P c_d <= pmax min_d c_d can hold the maximum: those few (the read's own diagonal,
+//   its partners across an indel) are summed exactly, row by row, from the quality bytes; every other diagonal is ruled out by its
+//   count alone.  Everything after that -- which classes of gapped alignments could still reach U* -- is argued with P as the least a
+//   mismatch can cost, which only makes the classes larger (more jobs to the DP, never a wrong answer).
+template <int RBITS, int MODE, bool QUAL = false>
 __global__ void __launch_bounds__(256)
 ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
                       int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp,
-                      const uint32_t* __restrict__ job_list = nullptr, const uint32_t* __restrict__ job_count = nullptr)
+                      const uint32_t* __restrict__ job_list = nullptr, const uint32_t* __restrict__ job_count = nullptr,
+                      const SchemeDev sc = SchemeDev{})
 {
+    __shared__ int32_t s_pen[QUAL ? 64 : 1];
+    if (QUAL)
+    {
+        if (threadIdx.x < 64) s_pen[threadIdx.x] = -mismatch_score( sc, threadIdx.x );     // the DP kernels' table, negated
+        __syncthreads();
+    }
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr bool LIST = MODE != 0;
     if (LIST ? slot >= *job_count : slot >= b.n) return;
@@ -665,15 +709,16 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     for (int k = 0; k < 7; ++k) { ql0[k] = ql[k]; qh0[k] = qh[k]; }
 
     uint32_t best_cnt = 0xFFFFFFFFu, best_d = 0;
+    int64_t U = 0;
     if (LIST)
     {
-        // the first pass left this job's best diagonal in scores / sinks
-        const int32_t us = scores[job];
-        best_cnt = P > 0 ? (uint32_t)(-us / P) : 0u;
-        best_d   = sinks[job].x - M;
+        // the first pass left this job's best diagonal and its score in scores / sinks
+        U      = scores[job];
+        best_d = sinks[job].x - M;
     }
     else
     {
+        uint32_t cnt_d[QUAL ? 31 : 1];
         #pragma unroll
         for (uint32_t d = 0; d < 31u; ++d)                           // (unrolled, no early exit: a window is rarely clipped)
         {
@@ -685,6 +730,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
                 const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
                 cnt += (uint32_t)__popc( mm );
             }
+            if (QUAL) cnt_d[d] = on ? cnt : 0xFFFFFFFFu;
             if (on && cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
             #pragma unroll
             for (int k = 0; k < 6; ++k)
@@ -694,8 +740,43 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
             }
             ql[6] >>= 1; qh[6] >>= 1;
         }
+        U = -(int64_t)P * (int64_t)best_cnt;
+        if (QUAL)
+        {
+            // no class of alignments the three chances know can be settled below 3 G - P (the third chance's `beyond`): such a job
+            // needs the DP whatever its exact U*, so its qualities are not even read
+            if (U <= 3 * (int64_t)G - P) { need_dp[job] = 1; return; }
+            const uint32_t pmax  = (uint32_t)s_pen[63];
+            const uint64_t bound = (uint64_t)pmax * best_cnt;                    // a diagonal with P c_d > pmax c_min cannot hold the maximum
+            uint32_t cand = 0;
+            #pragma unroll
+            for (uint32_t d = 0; d < 31u; ++d)
+                if (cnt_d[d] != 0xFFFFFFFFu && (uint64_t)(uint32_t)P * cnt_d[d] <= bound) cand |= 1u << d;
+            uint32_t best_w = 0xFFFFFFFFu;
+            while (cand)                                                          // ascending d: `<=` keeps the larger column on ties
+            {
+                const uint32_t d = (uint32_t)__builtin_ctz( cand );
+                cand &= cand - 1u;
+                uint32_t w = 0;
+                #pragma unroll
+                for (int k = 0; k < 6; ++k)
+                {
+                    // the text planes d symbols on (d <= 30 < 32: one funnel shift per word)
+                    const uint32_t tl = __builtin_amdgcn_alignbit( ql0[k + 1], ql0[k], d ), th = __builtin_amdgcn_alignbit( qh0[k + 1], qh0[k], d );
+                    uint32_t mm = (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k];
+                    while (mm)
+                    {
+                        const uint32_t row = 32u * k + (uint32_t)__builtin_ctz( mm );
+                        mm &= mm - 1u;
+                        const uint32_t qq = b.quals[rev ? first + M - 1u - row : first + row];
+                        w += (uint32_t)s_pen[qq < 63u ? qq : 63u];
+                    }
+                }
+                if (w <= best_w) { best_w = w; best_d = d; }
+            }
+            U = -(int64_t)best_w;
+        }
     }
-    const int64_t U = -(int64_t)P * (int64_t)best_cnt;
     bool settled = U > (int64_t)G;
     auto stash = [&]() { scores[job] = (int32_t)U; sinks[job] = make_uint2( M + best_d, M ); };
     const bool second_applies = !settled && (int64_t)G - P < U && 2 * (int64_t)G < U && N >= M + 30u && !(b.algo & NVBIO_ALN_NO_SECOND_CHANCE);
@@ -922,11 +1003,14 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
 
 // host-side conditions of the shortcut: SEMI_GLOBAL, match = 0, one mismatch penalty for every quality,
 // non-positive gap terms
-static bool ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P)
+static bool ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P, bool* by_quality)
 {
     if (sc.match != 0) return false;
     if (sc.mm_min < 0 || sc.mm_max < 0) return false;
-    if (b.quals != nullptr && sc.mm_min != sc.mm_max) return false;   // the penalty would depend on the row
+    // the penalty depends on the row (nvBowtie's default: 2..6 by base quality): the first pass sums the candidates' rows exactly
+    // (QUAL); it needs a ramp that does not decrease with the quality and a smallest penalty > 0
+    *by_quality = b.quals != nullptr && sc.mm_min != sc.mm_max;
+    if (*by_quality && (sc.mm_min <= 0 || sc.mm_max < sc.mm_min || (b.algo & NVBIO_ALN_NO_QUALITY_SHORTCUT))) return false;
     if (sc.pat_go >= 0 || sc.txt_go >= 0 || sc.pat_ge > 0 || sc.txt_ge > 0) return false;
     *P = sc.mm_min;                                               // quality 0 / constant ramp: mismatch = -mm_min
     return true;
@@ -960,6 +1044,13 @@ static void launch_pk_kernel(const BatchDev& b, const SchemeDev& sc, const uint3
 {
     const dim3 grid( (pairs + 127u) / 128u ), block( 128 );
     const bool two = (b.algo & NVBIO_ALN_PK_THREE_WAVES) == 0;
+    if (TYPE == NVBIO_SEMI_GLOBAL && sc.match == 0 && (b.algo & NVBIO_ALN_RAGGED_READS))
+    {
+        // reads of different lengths (the caller says so): both alignments of a lane in one pass
+        constexpr int T = (TYPE == NVBIO_SEMI_GLOBAL) ? TYPE : NVBIO_SEMI_GLOBAL;
+        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        return;
+    }
     if (TYPE != NVBIO_LOCAL && sc.match == 0)
     {
         constexpr int T = (TYPE == NVBIO_LOCAL) ? NVBIO_SEMI_GLOBAL : TYPE;      // (never LOCAL here: keeps that instantiation out)
@@ -977,8 +1068,11 @@ template <int TYPE, int RB>
 static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* scores, uint2* sinks, hipStream_t s)
 {
     const uint32_t pairs = (b.n + 1u) / 2u;
-    int32_t P = 0;
-    if (TYPE == NVBIO_SEMI_GLOBAL && ungapped_ok( sc, b, &P ) && !(b.algo & NVBIO_ALN_NO_UNGAPPED_SCORE))
+    int32_t P = 0; bool by_quality = false;
+    // (txt_go / txt_ge never enter the banded recurrences -- both gap recurrences take the pattern-gap terms, gotoh_common.h:23-30 -- which is
+    // why the chance kernels below are handed pat_go / pat_ge only; plain_gotoh() at the call site guarantees it.  A scheme that separates
+    // the two must disable the shortcut, as gotoh_full.hip does with `second_chance`.)
+    if (TYPE == NVBIO_SEMI_GLOBAL && ungapped_ok( sc, b, &P, &by_quality ) && !(b.algo & NVBIO_ALN_NO_UNGAPPED_SCORE))
     {
         // 1. settle the jobs whose best diagonal beats every gapped alignment; 2. compact the rest; 3. DP over the list
         const int32_t G = sc.pat_go > sc.txt_go ? sc.pat_go : sc.txt_go;
@@ -997,6 +1091,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         if (part_bytes > sel_bytes) sel_bytes = part_bytes;
         if (hipMallocAsync( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             set_error( "banded score: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
@@ -1007,8 +1102,12 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         uint32_t* job_count = (uint32_t*)((uint8_t*)aux + flags_bytes + 3u * list_bytes);
         uint32_t* count_st  = job_count + 2;                                                  // [2]: second, third
         void*     sel_temp  = (uint8_t*)aux + flags_bytes + 3u * list_bytes + 256u;
-        hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,0>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
-                            (const uint32_t*)nullptr, (const uint32_t*)nullptr );
+        if (by_quality)
+            hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,0,true>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc );
+        else
+            hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,0>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc );
         hipError_t e = hipSuccess;
         {
             // the jobs a second / third chance can still settle (need_dp == 3 / 2), compacted by one three-way partition, each list through
@@ -1124,6 +1223,7 @@ nvbio_status make_batch(const nvbio_alignment_batch* in, BatchDev* b)
     NVB_REQUIRE( in != nullptr, "batch is NULL" );
     NVB_REQUIRE( in->read_bits == 2 || in->read_bits == 4 || in->read_bits == 8, "read_bits must be 2, 4 or 8" );
     NVB_REQUIRE( in->text_bits == 2 || in->text_bits == 8, "text_bits must be 2 or 8" );
+    NVB_REQUIRE( in->n < (1u << 31), "at most 2^31 - 1 jobs per batch (the job lists are compacted with 32-bit signed counts)" );
     if (in->n)
     {
         NVB_REQUIRE( in->reads_dev && in->read_offsets_dev && in->text_dev && in->win_begin_dev && in->win_end_dev,

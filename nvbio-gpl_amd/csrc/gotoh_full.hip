@@ -1190,6 +1190,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
                             banded31_packed_ok( sc, max_pattern_len ) && sc.pat_ge < 0;
         if (hipMallocAsync( &aux, 4u * flags_bytes + 5u * list_bytes + 512u + sel_bytes, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             set_error( "full Gotoh: out of device memory for the job lists" );
             return NVBIO_ERR_NOMEM;
         }
@@ -1280,6 +1281,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         if (cap_jobs < 64) cap_jobs = 64;
         if (hipMallocAsync( &owned, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             if (aux) (void)hipFreeAsync( aux, s );
             set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
@@ -1380,6 +1382,7 @@ extern "C" nvbio_status nvbio_full_gotoh_score_best2(int device, nvbio_alignment
     void* column = nullptr;
     if (hipMallocAsync( &column, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
     {
+        (void)hipGetLastError();
         set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
         return NVBIO_ERR_NOMEM;
     }

@@ -574,6 +574,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
         if (hipMallocAsync( &aux, 2u * flags_bytes + 4u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             set_error( "full traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
@@ -630,6 +631,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         cap_jobs = (cap_jobs + 63u) & ~63ull;
         if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             if (aux) (void)hipFreeAsync( aux, s );
             set_error( "full traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;

@@ -594,6 +594,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
         if (hipMallocAsync( &aux, 2u * (flags_bytes + list_bytes + 256u) + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             set_error( "banded traceback: out of device memory for the job list" );
             return NVBIO_ERR_NOMEM;
         }
@@ -655,6 +656,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         if (cap_jobs < 64) cap_jobs = 64;
         if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
+            (void)hipGetLastError();
             if (aux) (void)hipFreeAsync( aux, s );
             set_error( "banded traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;

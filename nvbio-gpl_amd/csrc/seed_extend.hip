@@ -27,9 +27,9 @@ hits_to_diagonals_kernel(const uint2* __restrict__ hits, const uint64_t n, const
 }
 
 __global__ void __launch_bounds__(256)
-diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n, const uint32_t band, const uint32_t read_len,
+diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n, const uint32_t band, const uint32_t read_len_all,
                             const uint32_t genome_len, uint32_t* __restrict__ read_id, uint8_t* __restrict__ flags,
-                            uint32_t* __restrict__ wb, uint32_t* __restrict__ we)
+                            uint32_t* __restrict__ wb, uint32_t* __restrict__ we, const uint32_t* __restrict__ read_offsets = nullptr)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     {
@@ -38,8 +38,10 @@ diagonals_to_windows_kernel(const uint64_t* __restrict__ keys, const uint64_t n,
         const uint32_t g    = d > 1024u ? (uint32_t)(d - 1024u) : 0u;          // clamp the diagonal at the genome start
         const uint32_t half = band / 2u;
         const uint32_t b    = g > half ? g - half : 0u;
+        const uint32_t rid  = (uint32_t)(k >> 34);
+        const uint32_t read_len = read_offsets ? read_offsets[rid + 1] - read_offsets[rid] : read_len_all;     // ragged reads: each its own length
         const uint64_t e    = (uint64_t)b + band + read_len;
-        read_id[i] = (uint32_t)(k >> 34);
+        read_id[i] = rid;
         flags[i]   = ((k >> 33) & 1ull) ? (uint8_t)(NVBIO_READ_REVERSE | NVBIO_READ_COMPLEMENT) : (uint8_t)0;
         wb[i]      = b;
         we[i]      = e < genome_len ? (uint32_t)e : genome_len;
@@ -104,12 +106,14 @@ best_window_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict_
 // the traceback batch of every read's best alignment: see nvbio_traceback_best_batch
 __global__ void __launch_bounds__(256)
 traceback_best_batch_kernel(const unsigned long long* __restrict__ best, const long long* __restrict__ best_wb, const uint32_t n,
-                            const uint32_t read_len, const uint32_t band, const uint32_t genome_len, const int32_t min_score,
+                            const uint32_t read_len_all, const uint32_t band, const uint32_t genome_len, const int32_t min_score_all,
                             uint8_t* __restrict__ flags, uint32_t* __restrict__ wb, uint32_t* __restrict__ we, int32_t* __restrict__ scores,
-                            uint2* __restrict__ sinks)
+                            uint2* __restrict__ sinks, const uint32_t* __restrict__ read_offsets = nullptr, const int32_t* __restrict__ min_scores = nullptr)
 {
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
     {
+        const uint32_t read_len  = read_offsets ? read_offsets[r + 1] - read_offsets[r] : read_len_all;
+        const int32_t  min_score = min_scores ? min_scores[r] : min_score_all;
         const unsigned long long k = best[r];
         const long long w = best_wb[r];
         const int64_t sv = (int64_t)(k >> 34);
@@ -146,13 +150,17 @@ __device__ __forceinline__ bool distinct_alignments(const uint64_t pos1, const u
 __global__ void __launch_bounds__(256)
 second_candidate_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ scores, const uint2* __restrict__ sinks,
                         const uint32_t* __restrict__ wb, const uint64_t n, const unsigned long long* __restrict__ best,
-                        const uint32_t dist, const int32_t worst_score, unsigned long long* __restrict__ second)
+                        const uint32_t dist_all, const int32_t worst_score_all, unsigned long long* __restrict__ second,
+                        const uint32_t* __restrict__ read_offsets = nullptr, const int32_t* __restrict__ min_scores = nullptr)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     {
         const int32_t sc = scores[i];
-        if (sc <= worst_score) continue;                          // `score > best.m_a2.score()` with a2 initialised to the threshold
         const uint64_t k   = keys[i];
+        // ragged reads: distinct_dist = read_len / 2 and the threshold min_score - 1 of the candidate's own read
+        const uint32_t dist        = read_offsets ? (read_offsets[(k >> 34) + 1] - read_offsets[k >> 34]) / 2u : dist_all;
+        const int32_t  worst_score = min_scores ? min_scores[k >> 34] - 1 : worst_score_all;
+        if (sc <= worst_score) continue;                          // `score > best.m_a2.score()` with a2 initialised to the threshold
         const int64_t  s   = (int64_t)sc + (1ll << 20);
         const uint64_t pos = ((uint64_t)wb[i] + (uint64_t)sinks[i].x) & ((1ull << 33) - 1ull);
         const uint64_t sel = ((uint64_t)(s > 0 ? s : 0) << 34) | (k & (1ull << 33)) | pos;
@@ -248,11 +256,15 @@ __device__ __forceinline__ int mapq_v2(const int32_t best_score, const bool has_
 
 __global__ void __launch_bounds__(256)
 mapq_kernel(const unsigned long long* __restrict__ best, const unsigned long long* __restrict__ second, const uint32_t n,
-            const int version, const bool monotone, const float max_score, const float min_score,
-            int32_t* __restrict__ second_score, uint8_t* __restrict__ mapq)
+            const int version, const bool monotone, const float max_score_all, const float min_score_all,
+            int32_t* __restrict__ second_score, uint8_t* __restrict__ mapq,
+            const uint32_t* __restrict__ read_offsets = nullptr, const int32_t* __restrict__ min_scores = nullptr, const int32_t match = 0)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     {
+        // ragged reads: perfect_score = match x read_len (scoring.h:274) and min_score( read_len ) of the read itself
+        const float max_score = read_offsets ? (float)(match * (int32_t)(read_offsets[i + 1] - read_offsets[i])) : max_score_all;
+        const float min_score = min_scores ? (float)min_scores[i] : min_score_all;
         const unsigned long long b = best[i], s2 = second ? second[i] : 0ull;
         const int32_t bs = b  ? (int32_t)((int64_t)(b  >> 34) - (1ll << 20)) : NVBIO_SCORE_MIN;
         const int32_t ss = s2 ? (int32_t)((int64_t)(s2 >> 34) - (1ll << 20)) : NVBIO_SCORE_MIN;
@@ -472,6 +484,19 @@ extern "C" nvbio_status nvbio_diagonals_to_windows(int device, const uint64_t* k
     return NVBIO_OK;
 }
 
+extern "C" nvbio_status nvbio_diagonals_to_windows_ragged(int device, const uint64_t* keys_dev, uint64_t n, uint32_t band, const uint32_t* read_offsets_dev,
+                                                          uint32_t genome_len, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                                          uint32_t* win_begin_dev, uint32_t* win_end_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && read_offsets_dev && read_id_dev && flags_dev && win_begin_dev && win_end_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( diagonals_to_windows_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        keys_dev, n, band, 0u, genome_len, read_id_dev, flags_dev, win_begin_dev, win_end_dev, read_offsets_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
 extern "C" nvbio_status nvbio_best_candidate_reduce(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
                                                     const uint32_t* win_begin_dev, uint64_t n, uint64_t* best_dev, void* stream)
 {
@@ -511,6 +536,21 @@ extern "C" nvbio_status nvbio_traceback_best_batch(int device, const uint64_t* b
     return NVBIO_OK;
 }
 
+extern "C" nvbio_status nvbio_traceback_best_batch_ragged(int device, const uint64_t* best_dev, const int64_t* best_wb_dev, uint32_t n_reads,
+                                                          const uint32_t* read_offsets_dev, uint32_t band, uint32_t genome_len, const int32_t* min_scores_dev,
+                                                          uint8_t* flags_dev, uint32_t* win_begin_dev, uint32_t* win_end_dev, int32_t* scores_dev,
+                                                          nvbio_uint2* sinks_dev, void* stream)
+{
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( best_dev && best_wb_dev && read_offsets_dev && min_scores_dev && flags_dev && win_begin_dev && win_end_dev && scores_dev && sinks_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( traceback_best_batch_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)best_dev,
+                        (const long long*)best_wb_dev, n_reads, 0u, band, genome_len, 0, flags_dev, win_begin_dev, win_end_dev,
+                        scores_dev, (uint2*)sinks_dev, read_offsets_dev, min_scores_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
 extern "C" nvbio_status nvbio_best_candidate_unpack(int device, const uint64_t* best_dev, uint32_t n_reads, int32_t* scores_dev,
                                                     int64_t* end_pos_dev, uint8_t* rc_dev, void* stream)
 {
@@ -533,6 +573,35 @@ extern "C" nvbio_status nvbio_second_candidate_reduce(int device, const uint64_t
     hipLaunchKernelGGL( second_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
                         keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (const unsigned long long*)best_dev,
                         distinct_dist, worst_score, (unsigned long long*)second_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_second_candidate_reduce_ragged(int device, const uint64_t* keys_dev, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                                             const uint32_t* win_begin_dev, uint64_t n, const uint64_t* best_dev,
+                                                             const uint32_t* read_offsets_dev, const int32_t* min_scores_dev, uint64_t* second_dev, void* stream)
+{
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( keys_dev && scores_dev && sinks_dev && win_begin_dev && best_dev && second_dev && read_offsets_dev && min_scores_dev, "NULL device pointer" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( second_candidate_kernel, dim3( grid_for( n ) ), dim3(256), 0, (hipStream_t)stream,
+                        keys_dev, scores_dev, (const uint2*)sinks_dev, win_begin_dev, n, (const unsigned long long*)best_dev,
+                        0u, 0, (unsigned long long*)second_dev, read_offsets_dev, min_scores_dev );
+    NVB_HIP( hipGetLastError() );
+    return NVBIO_OK;
+}
+
+extern "C" nvbio_status nvbio_mapq_ragged(int device, const uint64_t* best_dev, const uint64_t* second_dev, uint32_t n_reads, int32_t version, int32_t match,
+                                          const uint32_t* read_offsets_dev, const int32_t* min_scores_dev, int32_t* second_scores_dev, uint8_t* mapq_dev,
+                                          void* stream)
+{
+    if (n_reads == 0) return NVBIO_OK;
+    NVB_REQUIRE( best_dev && mapq_dev && read_offsets_dev && min_scores_dev, "NULL pointer" );
+    NVB_REQUIRE( version == 2 || version == 3, "mapq version must be 2 or 3" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipLaunchKernelGGL( mapq_kernel, dim3( grid_for( n_reads ) ), dim3(256), 0, (hipStream_t)stream,
+                        (const unsigned long long*)best_dev, (const unsigned long long*)second_dev, n_reads, (int)version,
+                        match == 0, 0.0f, 0.0f, second_scores_dev, mapq_dev, read_offsets_dev, min_scores_dev, match );
     NVB_HIP( hipGetLastError() );
     return NVBIO_OK;
 }

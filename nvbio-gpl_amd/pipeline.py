@@ -15,7 +15,7 @@ import math
 
 import numpy as np
 
-from . import (FM_COMPLEMENT, FM_SCAN_FORWARD, LOCAL, READ_COMPLEMENT, READ_REVERSE, SCORE_MIN, SEMI_GLOBAL, AlignmentBatch,
+from . import (ALN_RAGGED_READS, FM_COMPLEMENT, FM_SCAN_FORWARD, LOCAL, READ_COMPLEMENT, READ_REVERSE, SCORE_MIN, SEMI_GLOBAL, AlignmentBatch,
                BatchedBandedAlignmentScore, FMIndexFilter, GotohAligner, GotohScheme, PackedStringSet)
 
 
@@ -41,6 +41,8 @@ class SeedExtendParams:
         self.merge_strands = True                   # one-call seed pass: extend the candidates of both strands in ONE batch (half the
                                                     # launches, better-filled kernels) instead of strand by strand
         self.algo_flags = 0                         # nvbio_alignment_batch::algo_flags of the extension (ALN_*: A/B of the exact shortcuts)
+        self.defer_heavy = True                     # two-strand seed pass: the searches the table cannot answer (k-mers with more than 8
+                                                    # occurrences) run as a dense launch of their own behind the pass (FM_DEFER_HEAVY)
 
     @classmethod
     def end_to_end(cls, constant_quality=True, **kw):
@@ -62,12 +64,27 @@ class SeedExtendParams:
             return int(np.float32(-0.6) + np.float32(-0.6) * np.float32(read_len))
         return int(np.float32(0.0) + np.float32(10.0) * np.float32(math.log(np.float32(read_len))))
 
+    def interval_table(self, max_len):
+        """seed interval of a read of every length 0..max_len: nvBowtie's seed_freq( read_len ) = int32( 1 + 1.15 sqrtf( len ) )
+        (SimpleFunc, params.h:87-100; bowtie2_cuda_driver.cu:111-113), evaluated in float32 as the reference does"""
+        if self.seed_interval:
+            return np.full(max_len + 1, self.seed_interval, dtype=np.int32)
+        x = np.arange(max_len + 1, dtype=np.float32)
+        return np.maximum((np.float32(1.0) + np.float32(1.15) * np.sqrt(x)).astype(np.int32), 1)
+
+    def min_score_table(self, max_len):
+        """min_score_for() of every read length 0..max_len (ragged batches: the threshold is the read's own)"""
+        return np.array([self.min_score_for(max(l, 1)) for l in range(max_len + 1)], dtype=np.int32)
+
 
 class ReadBatch:
-    """io::SequenceData<DNA_N>-shaped batch in HBM: 4-bit big-endian packed symbols, uniform length."""
+    """io::SequenceData<DNA_N>-shaped batch in HBM: 4-bit big-endian packed symbols, one quality byte per symbol (optional).
+    Uniform length: read r = symbols [r * read_len, (r + 1) * read_len).  Ragged (offsets: int32 tensor [n_reads + 1], the
+    sequence_index): read r = [offsets[r], offsets[r+1]); read_len is then the LONGEST read's length."""
 
-    def __init__(self, reads4, n_reads, read_len, quals=None):
+    def __init__(self, reads4, n_reads, read_len, quals=None, offsets=None):
         self.reads4, self.n, self.read_len, self.quals = reads4, int(n_reads), int(read_len), quals
+        self.offsets = offsets
 
 
 SCORE_BIAS = 1 << 20
@@ -97,6 +114,20 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     R, M, L = reads.n, reads.read_len, params.seed_len
     S_int = params.interval_for(M)
     spr = (M - L) // S_int + 1                                   # seeds per read and strand
+    ragged = reads.offsets is not None
+    intervals = min_scores = None
+    if ragged:
+        # every read its own length, seed interval (seed_freq( read_len ), mapping_inl.h:507-529) and score threshold; the tables are
+        # evaluated on the host in float32 as the reference evaluates them, per length, and gathered per read on the device
+        cache = getattr(reads, "_ragged", None)
+        if cache is None or cache[0] is not params:
+            lens = (reads.offsets[1:] - reads.offsets[:-1]).to(torch.int64)
+            it = torch.from_numpy(params.interval_table(M)).to(dev)
+            mt = torch.from_numpy(params.min_score_table(M)).to(dev)
+            itab = params.interval_table(M)
+            spr_max = max(((l - L) // int(itab[l]) + 1) if l >= L else 0 for l in range(M + 1))
+            cache = reads._ragged = (params, it[lens].contiguous(), mt[lens].contiguous(), int(spr_max))
+        _, intervals, min_scores, spr = cache
 
     def tick(name):
         if timers is None:
@@ -112,10 +143,17 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     # 1. seeds: infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernel
     #    (uniform_seeds_functor semantics; no offset array is materialised)
-    qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
-                         seed_interval=S_int)
-
-    read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    if ragged:
+        qs = PackedStringSet(reads.reads4, 4, R * spr, offsets=reads.offsets, fixed_len=L, stride=0, device=dev, seeds_per_string=spr,
+                             seed_intervals=intervals)
+        read_off = reads.offsets
+    else:
+        qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
+                             seed_interval=S_int)
+        read_off = getattr(reads, "_read_off", None)
+        if read_off is None:
+            read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    ext_flags = (params.algo_flags or 0) | (ALN_RAGGED_READS if ragged else 0)
     aligner = GotohAligner(params.aln_type, params.scheme)
     top = torch.zeros((R,), dtype=torch.int64, device=dev)      # best selection key per read (0: no candidate)
 
@@ -123,11 +161,11 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         """candidate windows (genome_infixes, fmmap.cu:169-196; window rule of score_inl.h:100-106), the banded Gotoh of
         every one of them, and the per-read reduction of the selection keys into `top` (one atomic max per candidate)"""
         e = tick("windows" + tag)
-        rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len)
+        rid, flags, wb, we = diagonals_to_windows(keys, params.band, M, genome_len, read_offsets=read_off if ragged else None)
         tock(e)
         e = tick("extend" + tag)
         batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, read_id=rid,
-                               flags=flags, device=dev, max_read_len=M, algo_flags=params.algo_flags or None)
+                               flags=flags, device=dev, max_read_len=M, algo_flags=ext_flags or None)
         scores, sinks = BatchedBandedAlignmentScore(params.band, aligner).enact(batch)
         tock(e)
         e = tick("reduce")
@@ -150,7 +188,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
             ranges = torch.stack([ranges[:, 0], torch.where(ycap >= 2 ** 31, ycap - 2 ** 32, ycap).to(torch.int32)], dim=1).contiguous()
         flt = FMIndexFilter()
         n_hits = flt.rank_ranges(fmi, ranges.contiguous(), None)
-        rkeys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, query_ids=ids.contiguous())
+        rkeys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, query_ids=ids.contiguous(),
+                                     read_offsets=read_off if ragged else None, seed_intervals=intervals)
         rkeys = torch.unique_consecutive(rkeys)
         if rkeys.numel() > 2 * R:
             rkeys = torch.unique(rkeys)
@@ -158,6 +197,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     ck = fmi.canonical_kmer if fused else 0
     both = fused and ck and ck <= L <= ck + 7 and spr <= 64 and getattr(params, "two_strand_pass", True)
+    if ragged and not both:
+        raise ValueError("ragged read batches go through the two-strand seed pass (an index built with FM_TABLE_CANONICAL[_WIDE])")
     if both:
         # 2.-4. for BOTH strands in one kernel over the canonical table (a k-mer and its reverse complement share an entry): one table
         #    gather per seed window instead of one per window and strand
@@ -167,7 +208,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         e = tick("match_both")
         # seeds that end on 2..4 rows (short repeats) leave all their keys at once: on unique-ish genomes the residual lists stay
         # empty and the scan + locate path with its host round trips is not entered at all
-        fmi.match_seed_diagonals_both(qs, M, b, inline_hits=min(4, params.max_seed_hits or 4))
+        fmi.match_seed_diagonals_both(qs, M, b, inline_hits=min(4, params.max_seed_hits or 4), defer_heavy=params.defer_heavy)
         tock(e)
         if "host" not in b:
             b["host"] = torch.empty(4, dtype=torch.int32, pin_memory=True)
@@ -277,9 +318,11 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         second = torch.zeros((R,), dtype=torch.int64, device=dev)
         min_score = params.min_score_for(M)
         for keys, scores, sinks, wb in scored:
-            second_candidate_reduce(keys, scores, sinks, wb, top, M // 2, min_score - 1, second)
+            second_candidate_reduce(keys, scores, sinks, wb, top, M // 2, min_score - 1, second,
+                                    read_offsets=read_off if ragged else None, min_scores=min_scores)
         match = int(params.scheme.c.match)
-        q, second_score = mapq(top, second, match * M, min_score, match == 0, params.mapq_version)
+        q, second_score = mapq(top, second, match * M, min_score, match == 0, params.mapq_version,
+                               read_offsets=read_off if ragged else None, min_scores=min_scores, match=match)
         tock(e)
         if extras is not None:
             extras.update(mapq=q, second_score=second_score, second=second)
@@ -291,6 +334,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     if extras is not None:
         extras["best_keys"] = top
+        if ragged:
+            extras["min_scores"] = min_scores
     if return_windows:
         # the window begin and the locus of every read's best candidate: one pass over the candidates (those whose selection key is
         # their read's final best)
@@ -317,10 +362,15 @@ def traceback_best_all(genome2, genome_len, reads, params, best_keys, best_wb, c
         a, ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         timers.setdefault("traceback", []).append((a, ev))
         a.record()
-    flags, wb, we, scores, sinks = traceback_best_batch(best_keys, best_wb, M, params.band, genome_len, params.min_score_for(M))
-    read_off = getattr(reads, "_read_off", None)
-    if read_off is None:
-        read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    if reads.offsets is not None:
+        read_off = reads.offsets
+        flags, wb, we, scores, sinks = traceback_best_batch(best_keys, best_wb, M, params.band, genome_len, 0, read_offsets=read_off,
+                                                            min_scores=reads._ragged[2])
+    else:
+        flags, wb, we, scores, sinks = traceback_best_batch(best_keys, best_wb, M, params.band, genome_len, params.min_score_for(M))
+        read_off = getattr(reads, "_read_off", None)
+        if read_off is None:
+            read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
     batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, flags=flags, device=dev, max_read_len=M)
     known = dict(scores=scores, sinks=sinks) if params.aln_type != LOCAL else {}
     op = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme))

@@ -312,6 +312,68 @@ def test_end_to_end_shortcut_edge_cases(amd, orc):
         assert np.array_equal(amd.u32(sk), wsk), sv
     # the indel reads really are cases where a gapped alignment beats a 2-3 mismatch diagonal
     assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
+    # the same jobs with base qualities under quality-dependent mismatch penalties (nvBowtie's default ramp 2..6 and two others):
+    # the first pass sums the penalties of its candidate diagonals row by row (QUAL), the chances argue with the smallest penalty
+    _with_qualities(amd, orc, rng, flat, roffs, text, wb, we, M)
+
+
+def _quality_sets(rng, n):
+    """base qualities: uniform 0..63, Illumina's four bins, mostly-40 with low-quality tails, all equal"""
+    tails = np.full(n, 40, dtype=np.uint8); low = rng.random(n) < 0.15; tails[low] = rng.integers(0, 30, int(low.sum()))
+    return (rng.integers(0, 64, n, dtype=np.uint8), rng.choice(np.array([2, 12, 23, 37], dtype=np.uint8), n), tails,
+            np.full(n, 17, dtype=np.uint8))
+
+
+def _with_qualities(amd, orc, rng, flat, roffs, text, wb, we, M, schemes=((0, 2, 6, -8, -3, -8, -3), (0, 1, 3, -5, -1, -5, -1), (0, 3, 10, -9, -2, -9, -2))):
+    rid = np.arange(len(wb), dtype=np.uint32)
+    fl = np.zeros(len(wb), dtype=np.uint8)
+    for quals in _quality_sets(rng, len(flat)):
+        for sv in schemes:
+            wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we,
+                                                     read_id=rid, flags=fl, quals=quals)
+            for algo in (None, amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_NO_QUALITY_SHORTCUT):
+                batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, max_read_len=M, algo_flags=algo)
+                sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+                bad = np.nonzero(sc.cpu().numpy() != wsc)[0]
+                assert len(bad) == 0, (sv, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]])
+                assert np.array_equal(amd.u32(sk), wsk), (sv, algo)
+
+
+def test_end_to_end_shortcut_with_qualities_reversed_reads(amd, orc):
+    """the quality-aware first pass on reverse-complemented reads (quality bytes are taken in storage order, mirrored with the read),
+    ragged read lengths and reads with N"""
+    rng = np.random.default_rng(77)
+    G, R = 300000, 5000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = rng.integers(60, 151, R)
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(40, G - 300, R)
+    rc = rng.random(R) < 0.5
+    reads = []
+    for k in range(R):
+        r = text[starts[k]:starts[k] + lens[k]].copy()
+        nm = int(rng.integers(0, 4)); pos = rng.choice(lens[k], nm, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, nm)) % 4
+        if rng.random() < 0.1 and lens[k] > 20:
+            cpos = int(rng.integers(5, lens[k] - 5)); r = np.concatenate([r[:cpos], r[cpos + 1:], text[starts[k] + lens[k]:starts[k] + lens[k] + 1]])
+        if rc[k]:
+            r = (3 - r)[::-1]
+        if rng.random() < 0.05:
+            r = r.copy(); r[int(rng.integers(0, lens[k]))] = 4
+        reads.append(r.astype(np.uint8))
+    flat = np.concatenate(reads)
+    wb = (starts - 15 + rng.integers(-2, 3, R)).astype(np.uint32); we = (wb + lens + 31).astype(np.uint32)
+    flags = (rc * (amd.READ_REVERSE | amd.READ_COMPLEMENT)).astype(np.uint8)
+    rid = np.arange(R, dtype=np.uint32)
+    sv = (0, 2, 6, -8, -3, -8, -3)
+    for quals in _quality_sets(rng, len(flat)):
+        wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we,
+                                                 read_id=rid, flags=flags, quals=quals)
+        for algo in (None, amd.ALN_NO_UNGAPPED_SCORE):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, flags=flags, max_read_len=150, algo_flags=algo)
+            sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+            assert np.array_equal(sc.cpu().numpy(), wsc), algo
+            assert np.array_equal(amd.u32(sk), wsk), algo
+    assert (wsc > -8).mean() > 0.3                                    # a good share is settled by the first pass
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2 | 128, 1 | 32])       # 32: the packed kernel's 3-waves-per-SIMD build
@@ -358,6 +420,8 @@ def test_end_to_end_banded_scoring_on_low_complexity_text(amd, orc, flags, monke
         assert len(bad) == 0, (sv, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]])
         assert np.array_equal(amd.u32(sk), wsk), sv
     assert (wsc <= -4).mean() > 0.5
+    if flags in (0, 1):
+        _with_qualities(amd, orc, rng, flat, roffs, text, wb, we, M, schemes=((0, 2, 6, -8, -3, -8, -3), (0, 1, 2, -4, -2, -4, -2)))
 
 
 @pytest.mark.parametrize("typ", ["LOCAL", "SEMI_GLOBAL"])

@@ -249,3 +249,74 @@ def test_pipeline_second_best_and_mapq(amd, orc, mode):
     assert has[:2300].mean() > 0.8 and has[2300:-20].mean() < 0.05
     assert len(np.unique(q)) >= 6 and (q[2300:-20] >= 20).mean() > 0.95 and (q[:1500] <= 1).mean() > 0.5
     fmi.close()
+
+
+def test_pipeline_ragged_reads_with_qualities_and_a_repeat_family(amd, orc):
+    """what the benchmark's friendly batch is not: reads of different lengths (each seeded at its own interval, scored against its own
+    threshold), per-base qualities under nvBowtie's default ramp (mismatch 2..6: the quality-aware first pass), and a repeat family
+    whose k-mers the canonical table cannot answer (deferred searches, seed-hit cap).  Every read is independent, so the ragged batch
+    must give each read what the oracle's uniform composition gives a batch of that read's length."""
+    import torch
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    rng = np.random.default_rng(2026)
+    G = 1_500_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    unit = rng.integers(0, 4, 300, dtype=np.uint8)
+    for c in range(60):
+        text[20000 + 9000 * c:20300 + 9000 * c] = unit
+    hidx = orc.build_index(text)
+    genome2 = orc.pack2(text)
+    fmi = amd.FMIndex.build(genome2, G, kmer_len=15, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL_WIDE)
+    assert fmi.canonical
+    R, Mmax = 6000, 150
+    lens = rng.choice(np.array([100, 101, 117, 125, 136, 149, 150]), R)
+    starts = rng.integers(0, G - Mmax - 8, R)
+    starts[:500] = 20000 + 9000 * rng.integers(0, 60, 500) + rng.integers(0, 150, 500)       # reads inside the family
+    full = mutate_reads(rng, text, starts, Mmax)
+    rcm = rng.random(R) < 0.5
+    reads = []
+    for r in range(R):
+        x = full[r, :lens[r]]
+        x = ((3 - x[::-1]) if rcm[r] else x).copy()
+        x[rng.random(len(x)) < 0.0005] = 4
+        reads.append(x)
+    offs = np.zeros(R + 1, dtype=np.int64); offs[1:] = np.cumsum(lens)
+    flat = np.concatenate(reads).astype(np.uint8)
+    quals = rng.choice(np.array([2, 12, 23, 37, 40], dtype=np.uint8), len(flat), p=[0.05, 0.1, 0.15, 0.5, 0.2])
+    params = pipeline.SeedExtendParams.end_to_end(constant_quality=False, max_seed_hits=4)
+    params.mapq = True
+    rb = pipeline.ReadBatch(torch.from_numpy(orc.pack4(flat).view(np.int32)).cuda(), R, Mmax, quals=torch.from_numpy(quals).cuda(),
+                            offsets=torch.from_numpy(offs.astype(np.int32)).cuda())
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    scheme = oracle.Scheme(0, 2, 6, -8, -3, -8, -3)
+    results = {}
+    for defer in (True, False):
+        for algo in (0, amd.ALN_NO_UNGAPPED_SCORE):
+            params.defer_heavy, params.algo_flags = defer, algo
+            ex = {}
+            bs, bp, brc, nc = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, extras=ex)
+            results[(defer, algo)] = (bs.cpu().numpy(), bp.cpu().numpy(), brc.cpu().numpy(), ex["mapq"].cpu().numpy(), ex["second_score"].cpu().numpy())
+    base = results[(True, 0)]
+    for key, val in results.items():
+        for a, b in zip(base, val):
+            assert np.array_equal(a, b), key
+    itab = params.interval_table(Mmax)
+    checked = 0
+    for ln in np.unique(lens):
+        grp = np.nonzero(lens == ln)[0]
+        assert int(1 + 1.15 * np.sqrt(ln)) == int(itab[ln])
+        sub = np.stack([reads[r] for r in grp]).astype(np.uint8)
+        q = np.concatenate([quals[offs[r]:offs[r + 1]] for r in grp])
+        ms = params.min_score_for(int(ln))
+        want = cpu_pipeline.seed_and_extend_cpu(orc, hidx, text, G, sub, aln_type=oracle.SEMI_GLOBAL, scheme=scheme, quals=q, max_seed_hits=4,
+                                                second=dict(min_score=ms, perfect_score=0, monotone=True, version=2))
+        assert np.array_equal(base[0][grp], want[0]), ln
+        assert np.array_equal(base[1][grp], want[1]), ln
+        assert np.array_equal(base[2][grp], want[2]), ln
+        assert np.array_equal(base[3][grp], want[4]["mapq"]), ln
+        assert np.array_equal(base[4][grp], want[4]["second_score"]), ln
+        checked += len(grp)
+    assert checked == R
+    aligned = np.array([base[0][r] >= params.min_score_for(int(lens[r])) for r in range(R)])
+    assert aligned[500:].mean() > 0.97
+    fmi.close()

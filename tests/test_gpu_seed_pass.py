@@ -279,3 +279,135 @@ def test_two_strand_pass_equals_the_per_strand_operators(amd, orc, k, wide):
     plain.close()
     with pytest.raises(amd.NvbioError):
         amd.FMIndex.build(orc.pack2(text), n, kmer_len=8, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL)      # even k
+
+
+def _all_candidates(hidx, keys, res_f, res_r, spr, M, L, S, cap=None):
+    """every candidate key a run of the two-strand pass stands for: its keys plus the rows of its residual ranges (first `cap` rows)"""
+    out = [np.asarray(keys, dtype=np.int64)]
+    for strand, res in ((0, res_f), (1, res_r)):
+        for sid, (x, y) in res.items():
+            if cap is not None:
+                y = min(y, x + cap - 1)
+            rid, j = sid // spr, sid % spr
+            p = (M - j * S - L) if strand else j * S
+            out.append((np.int64(rid) << 34) | (strand << 33) | (hidx.sa[x:y + 1].astype(np.int64) + 1024 - p))
+    return np.unique(np.concatenate(out))
+
+
+@pytest.mark.parametrize("k", [5, 9, 15])
+def test_two_strand_pass_with_deferred_heavy_searches(amd, orc, k):
+    """NVBIO_FM_DEFER_HEAVY: the searches the canonical table cannot answer (k-mers with more than 8 occurrences -- all of them at k = 5 --
+    or more hits on a strand than the in-line limit) run as a dense launch behind the pass.  The candidates the call stands for
+    (keys + rows of the residual ranges) are those of the in-line form, and the keys that do not depend on a deferred search are where
+    they were: the pass's own keys, tile by tile; the deferred searches' keys follow them."""
+    rng = np.random.default_rng(1200 + k)
+    n = 300007
+    text = _text(rng, n)
+    text[160000:160300] = 3 - text[5000:5300][::-1]
+    hidx = orc.build_index(text)
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL_WIDE)
+    R, M = 3000, 150
+    reads = _reads(rng, text, R, M)
+    packed = orc.pack4(reads.reshape(-1))
+    n_deferred = 0
+    for L, S in ((k + 5, 15), (k + 7, 20)):
+        spr = (M - L) // S + 1
+        want_f, res_f = _expected(orc, hidx, reads, M, L, S, 0)
+        want_r, res_r = _expected(orc, hidx, reads, M, L, S, 1)
+        want_all = _all_candidates(hidx, np.concatenate([want_f, want_r]), res_f, res_r, spr, M, L, S)
+        for h in (0, 4):
+            for gb in (0, 64):
+                qs = amd.PackedStringSet(packed, 4, R * spr, fixed_len=L, stride=M, seeds_per_string=spr, seed_interval=S)
+                b = fmi.match_seed_diagonals_both(qs, M, grid_blocks=gb, inline_hits=h, defer_heavy=True)
+                c = [int(v) for v in b["counts"][:4].cpu().numpy()]
+                keys = b["keys"][:c[0]].cpu().numpy()
+                nq = R * spr
+                res = []
+                for lo, cnt in ((0, c[1]), (nq, c[2])):
+                    rr = amd.u32(b["ranges"][lo:lo + cnt]); ids = b["ids"][lo:lo + cnt].cpu().numpy()
+                    assert len(np.unique(ids)) == len(ids)
+                    res.append({int(i): (int(a), int(d)) for i, (a, d) in zip(ids, rr)})
+                got_all = _all_candidates(hidx, keys, res[0], res[1], spr, M, L, S)
+                assert np.array_equal(got_all, want_all), (k, L, S, h, gb)
+                # residual entries are real multi-row ranges of the oracle's searches
+                for strand, want_res in ((0, res_f), (1, res_r)):
+                    for sid, xy in res[strand].items():
+                        assert want_res[sid] == xy
+                n_deferred += c[1] + c[2]
+    assert n_deferred > 500
+    fmi.close()
+
+
+def test_two_strand_pass_over_ragged_reads(amd, orc):
+    """reads of different lengths, each seeded at its own interval (nvBowtie: seed_freq( read_len ), mapping_inl.h:507-529): the pass over
+    a ragged seed set (seed_intervals_dev) leaves, read by read, what the uniform pass leaves for a batch of that read's length; seed ids
+    beyond a read's last seed match nothing -- in the two-strand pass and in the plain match()"""
+    rng = np.random.default_rng(4242)
+    n = 300007
+    text = _text(rng, n)
+    hidx = orc.build_index(text)
+    k, L = 11, 16
+    fmi = amd.FMIndex.build(orc.pack2(text), n, kmer_len=k, sa_int=1, table_flags=amd.FM_TABLE_CANONICAL_WIDE)
+    R, Mmax = 2500, 150
+    full = _reads(rng, text, R, Mmax)
+    lens = rng.integers(60, Mmax + 1, R); lens[:40] = rng.integers(10, 25, 40)              # some reads shorter than two seeds, some than one
+    lens[40:60] = Mmax
+    offs = np.zeros(R + 1, dtype=np.int64); offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([full[r, :lens[r]] for r in range(R)])
+    itab = np.maximum((np.float32(1.0) + np.float32(1.15) * np.sqrt(np.arange(Mmax + 1, dtype=np.float32))).astype(np.int32), 1)
+    ivs = itab[lens]
+    nseeds = np.where(lens >= L, (lens - L) // ivs + 1, 0)
+    spr = int(nseeds.max())
+    qs = amd.PackedStringSet(orc.pack4(flat), 4, R * spr, offsets=offs.astype(np.uint32), fixed_len=L, stride=0, seeds_per_string=spr,
+                             seed_intervals=ivs.astype(np.uint32))
+    # expectations, length group by length group, from the uniform helper
+    exp_keys, exp_res = [[], []], [{}, {}]
+    for ln in np.unique(lens):
+        grp = np.nonzero(lens == ln)[0]
+        if ln < L:
+            continue
+        S = int(itab[ln]); g_spr = (ln - L) // S + 1
+        sub = np.stack([full[r, :ln] for r in grp])
+        for strand in (0, 1):
+            ks, rs = _expected(orc, hidx, sub, int(ln), L, S, strand)
+            lrid = ks >> 34
+            exp_keys[strand].append((grp[lrid].astype(np.int64) << 34) | (ks & ((1 << 34) - 1)))
+            for sid, xy in rs.items():
+                exp_res[strand][int(grp[sid // g_spr]) * spr + sid % g_spr] = xy
+    for defer in (False, True):
+        b = fmi.match_seed_diagonals_both(qs, Mmax, defer_heavy=defer)
+        c = [int(v) for v in b["counts"][:4].cpu().numpy()]
+        keys = b["keys"][:c[0]].cpu().numpy()
+        nq = R * spr
+        res = []
+        for lo, cnt in ((0, c[1]), (nq, c[2])):
+            rr = amd.u32(b["ranges"][lo:lo + cnt]); ids = b["ids"][lo:lo + cnt].cpu().numpy()
+            res.append({int(i): (int(a), int(d)) for i, (a, d) in zip(ids, rr)})
+        if not defer:
+            for strand in (0, 1):
+                got = np.sort(keys[((keys >> 33) & 1) == strand])
+                assert np.array_equal(got, np.sort(np.concatenate(exp_keys[strand]))), strand
+                assert res[strand] == exp_res[strand], strand
+        else:
+            # (the deferred searches' keys come without the adjacent-duplicate removal: compare what the call stands for)
+            def cands(keys, res):
+                out = [keys]
+                for strand in (0, 1):
+                    for sid, (x, y) in res[strand].items():
+                        rid, j = sid // spr, sid % spr
+                        p = (int(lens[rid]) - j * int(ivs[rid]) - L) if strand else j * int(ivs[rid])
+                        out.append((np.int64(rid) << 34) | (strand << 33) | (hidx.sa[x:y + 1].astype(np.int64) + 1024 - p))
+                return np.unique(np.concatenate(out))
+            assert np.array_equal(cands(keys, res), cands(np.concatenate(exp_keys[0] + exp_keys[1]), exp_res))
+    # the plain operator over the same ragged seed set: ranges of the seeds that exist, (1, 0) for the ids that do not
+    ranges = amd.u32(fmi.match(qs))
+    sid = np.arange(R * spr); rid, j = sid // spr, sid % spr
+    exists = j < nseeds[rid]
+    assert (ranges[~exists, 0] > ranges[~exists, 1]).all()
+    beg = offs[rid] + j * ivs[rid]
+    sel = np.nonzero(exists)[0][:4000]
+    syms = np.concatenate([flat[b:b + L] for b in beg[sel]])
+    want = orc.match_batch(hidx, syms, (np.arange(len(sel) + 1) * L).astype(np.uint32))
+    assert np.array_equal(ranges[sel], want)
+    assert exists.sum() > 10000 and (~exists).sum() > 500
+    fmi.close()
