@@ -32,10 +32,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 GPU_CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
 DP_ROW_INSTRUCTIONS = 360            # banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4,2,true>: instructions of one pass through the row loop (profiles/r02h_pk_row_loop.s)
-SECTOR = 64                      # bytes the fabric moves for one gather, whatever its width (FETCH_SIZE's unit)
+SECTOR = 64                      # the unit the kernel's accounting instantiation counts gathers in (distinct 64-byte sectors)
+LINE = 128                       # bytes the fabric MOVES for one gather: every L2 miss of gfx950 is a 128-byte read request, whatever
+                                 # the load's width, the memory's kind or the cache policy bits (TCC_EA0_RDREQ_128B = gathers, _64B = _32B = 0:
+                                 # profiles/r03_gather2_modes.jsonl, r03_gather2_pmc_128GiB.jsonl); FETCH_SIZE tallies them at 64 bytes
 TB_STRIDE = 32                   # io::Cigar elements kept per read by the traceback stage
 SEED_KERNEL_TAG = "fm_seed_pipe_kernel<4>"            # the per-strand pass (--no-canonical)
-SEED_BOTH_KERNEL_TAG = "fm_seed_both_kernel<4, false, %s>"   # the two-strand pass over the canonical table (default): % wide entries
+SEED_BOTH_KERNEL_TAG = "fm_seed_both_kernel<4, false, %s, %s>"   # the two-strand pass over the canonical table (default): % wide entries, deferred heavy searches
 
 
 def log(msg):
@@ -91,6 +94,28 @@ def plant_family(words, n, copies, device, seed, unit=300):
     return slots * 16
 
 
+def make_ragged(reads_sym, min_len, device, seed):
+    """cut every read of a [R, M] batch to a length drawn uniformly from [min_len, M] and give every base a quality from Illumina's
+    four bins plus 40 (q -> nvBowtie mismatch penalty 2 + int(min(q,40)/40 * 4): 2, 3, 4, 5, 6).  Returns (flat symbols uint8, offsets
+    int32 [R+1], qualities uint8, lengths int64)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    R, M = reads_sym.shape
+    lens = torch.randint(min_len, M + 1, (R,), device=device, generator=g, dtype=torch.int64)
+    keep = torch.arange(M, device=device)[None, :] < lens[:, None]
+    flat = reads_sym[keep]
+    offs = torch.zeros(R + 1, dtype=torch.int64, device=device)
+    offs[1:] = torch.cumsum(lens, 0)
+    bins = torch.tensor([2, 12, 23, 37, 40], dtype=torch.uint8, device=device)
+    cum = torch.tensor([0.04, 0.12, 0.25, 0.70], device=device)                     # P(q) = 0.04, 0.08, 0.13, 0.45, 0.30
+    quals = torch.empty(flat.numel(), dtype=torch.uint8, device=device)
+    for b0 in range(0, flat.numel(), 1 << 28):
+        u = torch.rand(min(1 << 28, flat.numel() - b0), device=device, generator=g)
+        quals[b0:b0 + u.numel()] = bins[torch.bucketize(u, cum)]
+    return flat.contiguous(), offs.to(torch.int32), quals, lens
+
+
 def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000, family=None):
     """150 bp reads drawn from the reference: 1 % substitutions, 0.1 %/base 1-3 bp indels,
     50 % reverse-complemented.  Returns (reads uint8 [R,M], truth pos, rc)."""
@@ -127,6 +152,182 @@ def make_reads(words, n, n_reads, M, device, seed, chunk=1_000_000, family=None)
     return torch.cat(out), torch.cat(pos_all), torch.cat(rc_all)
 
 
+
+def timed_ms(torch, fn, reps=5, warm=1):
+    """median of `reps` event-timed calls on torch's current stream (which is the stream every library call is handed)"""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2]
+
+
+def i32(torch, t):
+    return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32)
+
+
+def run_configs(torch, amd, pipeline, fmi, genome, n, device, M, scale=1.0):
+    """BASELINE.json configs 2, 4 (one GPU's slice) and 5 (1 M pairs) at kernel / composition level on the index the run already holds;
+    each takes a few ms.  Not part of the timed step."""
+    out = {}
+    g = torch.Generator(device=device); g.manual_seed(2)
+    # ---- config 2: 1 M x 22 bp seeds (90 % substrings of the text, 10 % random) through match() -- plain table + rank steps, and the
+    #      reference's algorithm without a table (SURVEY 8d's unit of work: 32 B per distinct bwt_occ record + query + result) ----
+    Q, L = int(1_000_000 * scale), 22
+    starts = torch.randint(0, n - L, (Q,), device=device, generator=g, dtype=torch.int64)
+    sym = genome_symbols(genome, starts[:, None] + torch.arange(L, device=device)[None, :])
+    rnd = torch.randint(0, 4, (Q, L), device=device, generator=g, dtype=torch.uint8)
+    sym[::10] = rnd[::10]
+    padded = torch.zeros((Q, 24), dtype=torch.uint8, device=device); padded[:, :L] = sym
+    qs = amd.PackedStringSet(pack4(padded.reshape(-1)), 4, Q, fixed_len=L, stride=24, device=device)
+    _, blk = fmi.match(qs, amd.FM_NO_KMER_TABLE, want_blocks=True)
+    alg = int((blk.to(torch.int64) & 0xFFFFFFFF).sum()) * 32 + Q * (11 + 8)
+    ms_t = timed_ms(torch, lambda: fmi.match(qs, 0), reps=11, warm=2)
+    ms_n = timed_ms(torch, lambda: fmi.match(qs, amd.FM_NO_KMER_TABLE), reps=11, warm=2)
+    flt = amd.FMIndexFilter()
+    total = flt.rank(fmi, qs)
+    ms_l = timed_ms(torch, lambda: flt.locate(0, total), reps=11, warm=2) if total else None
+    out["fm_seeds_1M"] = {"queries": Q, "seed_len": L, "ms": ms_t, "queries_per_s": Q / (ms_t * 1e-3),
+                          "kernel": "fm_match_kernel<4,false,true,false> (plain k-mer table, then one rank step per symbol)",
+                          "alg_bytes": alg, "alg_frac_of_hbm_peak": alg / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "no_table": {"ms": ms_n, "queries_per_s": Q / (ms_n * 1e-3), "alg_frac_of_hbm_peak": alg / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "locate_every_hit": {"hits": int(total), "ms": ms_l}}
+    del qs, blk, padded, sym, rnd, starts, flt
+    # ---- config 4, one GPU's slice: 6.25 M pairs of (150, 181), band 31, LOCAL Gotoh match 2 / mismatch -6 (q >= 40) / gaps -8 -3 ----
+    P = int(6_250_000 * scale)
+    reads_sym, pos, rc = make_reads(genome, n, P, M, device, seed=4)
+    reads_sym = torch.where(rc[:, None], 3 - reads_sym.flip(1), reads_sym)          # back on the forward strand
+    r4 = pack4(reads_sym.reshape(-1))
+    roffs = (torch.arange(P + 1, device=device) * M).to(torch.int32)
+    wbeg = torch.clamp(pos - 15, min=0); wend = torch.clamp(wbeg + 31 + M, max=n)
+    b = amd.AlignmentBatch(r4, 4, roffs, genome, 2, i32(torch, wbeg), i32(torch, wend), max_read_len=M, device=device)
+    al = amd.make_gotoh_aligner(amd.LOCAL, amd.GotohScheme(2, 6, 6, -8, -3, -8, -3))
+    ms = timed_ms(torch, lambda: amd.batch_banded_alignment_score(31, al, b), reps=5, warm=1)
+    gc = P * 31 * M / (ms * 1e-3) / 1e9
+    peak = 64 * 2 * 31 / (DP_ROW_INSTRUCTIONS * 4.0) * 1024 * GPU_CLOCK_GHZ
+    out["banded_local_6.25M"] = {"pairs": P, "ms": ms, "gcups": gc, "pairs_per_s": P / (ms * 1e-3),
+                                 "kernel": "banded_gotoh_band31_pk_kernel<LOCAL,4> (two alignments per lane, int16 packed)",
+                                 "dp_issue_frac": gc / peak,
+                                 "note": "dp_issue_frac: against the end-to-end row loop's issue bound (%d instructions per row); the LOCAL row also clamps at 0 and keeps a per-cell sink key" % DP_ROW_INSTRUCTIONS}
+    del reads_sym, r4, b, wbeg, wend, pos, rc
+    # ---- config 5 shape on one GPU: 1 M pairs, 2 x 150 bp, FR, insert N(350, 50), anchor banded + opposite mate full matrix, CIGARs of both ----
+    Pp = int(1_000_000 * scale)
+    g.manual_seed(77)
+    ins = torch.clamp((torch.randn(Pp, device=device, generator=g) * 50 + 350).round().to(torch.int64), 160, 500)
+    left = torch.randint(0, n - 520, (Pp,), device=device, generator=g, dtype=torch.int64)
+    j = torch.arange(M, device=device, dtype=torch.int64)[None, :]
+
+    def mate(posv, seed):
+        gg = torch.Generator(device=device); gg.manual_seed(seed)
+        symv = genome_symbols(genome, posv[:, None] + j)
+        rndv = torch.randint(0, 4, (Pp, M), device=device, generator=gg, dtype=torch.uint8)
+        sub = torch.rand(Pp, M, device=device, generator=gg) < 0.01
+        return torch.where(sub, (symv + 1 + rndv % 3) % 4, symv)
+
+    m1 = mate(left, 1); m2 = 3 - mate(left + ins - M, 2).flip(1)
+    swap = torch.rand(Pp, device=device, generator=g) < 0.5
+    b1 = pipeline.ReadBatch(pack4(torch.where(swap[:, None], m2, m1).reshape(-1)), Pp, M)
+    b2 = pipeline.ReadBatch(pack4(torch.where(swap[:, None], m1, m2).reshape(-1)), Pp, M)
+    pparams = pipeline.SeedExtendParams.end_to_end()
+    pipeline.paired_end(fmi, genome, n, b1, b2, pparams, cigar_stride=16)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    po = pipeline.paired_end(fmi, genome, n, b1, b2, pparams, cigar_stride=16)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    paired = po["anchor"] >= 0
+    conc = paired & (po["rc1"] != po["rc2"]) & ((po["pos1"] - po["pos2"]).abs() <= 500)
+    out["paired_end_1M"] = {"pairs": Pp, "ms": dt * 1e3, "pairs_per_s": Pp / dt, "paired_fraction": float(paired.float().mean()),
+                            "concordant_fraction": float(conc.float().mean()), "with_cigars_of_both_mates": True,
+                            "composition": "pipeline.paired_end: each mate anchored in turn (seed + banded extend), the other by full-matrix DP in nvBowtie's "
+                                           "opposite-mate window, best pair, both mates traced back"}
+    return out
+
+
+def run_robust(torch, np, amd, pipeline, args, genome, n, R, M, device, rank, headline_ms):
+    """The step on input that is NOT the friendliest instance of the workload: a repeat family in the reference (10^4 copies of a 300 bp
+    element, 5 % of the reads drawn from inside a copy, seed-hit cap 16), per-base qualities under nvBowtie's default ramp (mismatch 2..6)
+    and reads of different lengths (100..150, each seeded at its own interval and held to its own min score).  Rebuilds the index (the
+    headline's handle has been closed: two 188 GB handles do not fit).  Results are checked against the plain operators."""
+    t0 = time.time()
+    family = plant_family(genome, n, args.robust_copies, device, seed=4321)
+    fmi = amd.FMIndex.build(genome, n, kmer_len=args.kmer, sa_int=1,
+                            table_flags=amd.FM_TABLE_CANONICAL if args.no_wide_table else amd.FM_TABLE_CANONICAL_WIDE)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    reads_sym, truth_pos, truth_rc = make_reads(genome, n, R, M, device, seed=5000 + rank, family=family)
+    min_len = min(100, M)
+    flat, offs, quals, lens = make_ragged(reads_sym, min_len, device, seed=6000 + rank)
+    del reads_sym
+    reads4 = pack4(flat)
+    del flat
+    batch = pipeline.ReadBatch(reads4, R, M, quals=quals, offsets=offs)
+    params = pipeline.SeedExtendParams.end_to_end(constant_quality=False, max_seed_hits=16)
+    params.mapq = not args.no_mapq
+    params.defer_heavy = not args.no_defer_heavy
+    extras = {}
+
+    def steps(k, timers=None):
+        out = None
+        pre = pipeline.seed_pass_begin(fmi, batch, params, 0, timers) if (not args.no_step_pipelining and k) else None
+        for i in range(k):
+            nxt = pipeline.seed_pass_begin(fmi, batch, params, (i + 1) & 1, timers) if (not args.no_step_pipelining and i + 1 < k) else None
+            out = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, pre=pre)
+            pre = nxt
+        return out
+
+    steps(1)
+    timers = {}
+    torch.cuda.synchronize(); w0 = time.perf_counter()
+    K = max(2, min(args.steps, 3))
+    bs, bp, brc, nc = steps(K, timers)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - w0) / K
+    stage = {k: float(np.mean(event_ms(v))) for k, v in timers.items()}
+    min_scores = extras.get("min_scores")
+    aligned = bs >= min_scores if min_scores is not None else bs >= params.min_score_for(M)
+    end_truth = torch.where(truth_rc, truth_pos + M, truth_pos + lens)      # a reverse-complemented read keeps the END of its locus when cut
+    near = (bp - end_truth).abs() <= 40
+    res = {"workload": ("3 Gbp i.i.d. reference with %d copies of a 300 bp element (5 %% of the reads drawn from inside a copy; max_seed_hits 16), "
+                        "per-base qualities from {2,12,23,37,40} under nvBowtie's default ramp (mismatch 2..6, scoring.h:73-92), read lengths uniform "
+                        "in [%d, %d] (seed interval and min score per read, mapping_inl.h:507-529)" % (args.robust_copies, min_len, M)),
+           "reads": R, "ms_per_step": dt * 1e3, "reads_per_s": R / dt, "x_headline_ms": (dt * 1e3 / headline_ms) if headline_ms else None,
+           "stage_ms": stage, "candidates_per_step": int(nc), "aligned_fraction": float(aligned.float().mean()),
+           "correct_locus_fraction": float((aligned & near & (brc.bool() == truth_rc)).float().mean()),
+           "index_and_tables_s": build_s,
+           "switches": {"defer_heavy_searches": bool(params.defer_heavy), "quality_aware_first_pass": True, "one_pass_per_lane_for_ragged_reads": True}}
+    if not args.no_plain_ab:
+        # the same batch through the plain operators: match() + locate() of every seed of either strand, the DP for every candidate
+        params.direct = False
+        params.algo_flags = amd.ALN_NO_UNGAPPED_SCORE
+        pipeline.seed_and_extend(fmi, genome, n, batch, params, None)
+        torch.cuda.synchronize(); p0 = time.perf_counter()
+        pbs, pbp, pbrc, pnc = pipeline.seed_and_extend(fmi, genome, n, batch, params, None)
+        torch.cuda.synchronize(); pdt = time.perf_counter() - p0
+        res["plain_operators"] = {"ms_per_step": pdt * 1e3, "results_equal": bool(torch.equal(pbs, bs) and torch.equal(pbp, bp) and torch.equal(pbrc, brc))}
+    fmi.close()
+    return res
+
+
+def host_cpu_share():
+    """(logical CPUs this process may run on, CPUs its cgroup quota grants or None): OpenMP's default of one thread per logical CPU
+    oversubscribes a container whose quota is smaller -- round 2's baseline ran 128 threads on such a box"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return aff, quota
+
+
 # ---------------------------------------------------------------------------------------------
 def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
@@ -155,6 +356,7 @@ def main():
                     "then takes the group gather) instead of 16-byte ones (128 GiB, two occurrences in line)")
     ap.add_argument("--no-plain-ab", action="store_true", help="skip the (untimed) run through the plain operators without the two exact shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-port-baseline", action="store_true", help="do not also time the oracle's C restatement beside the reference build")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the result gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--no-mapq", action="store_true", help="leave nvBowtie's second-best bookkeeping and the mapping quality out of the step")
@@ -164,6 +366,14 @@ def main():
     ap.add_argument("--with-traceback", action="store_true", help="put the traceback of every aligned read's best alignment (CIGARs) inside the timed step")
     ap.add_argument("--build-breakdown", action="store_true", help="build the index once more without tables to report index_build_s and table_build_s separately")
     ap.add_argument("--max-seed-hits", type=int, default=0, help="extend at most this many SA rows of a seed's range (0: all; needed with --repeat-family)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank maps --reads reads per step; strong: --reads reads per step in all, split over the ranks")
+    ap.add_argument("--no-step-pipelining", action="store_true",
+                    help="do not enqueue the next step's seed pass ahead of this step's extension (the host then waits for the seed pass's counts with the GPU idle)")
+    ap.add_argument("--no-defer-heavy", action="store_true", help="the searches the canonical table cannot answer run inside the seed pass instead of as a dense launch behind it")
+    ap.add_argument("--no-configs", action="store_true", help="skip the (untimed) kernel-level runs of BASELINE configs 2, 4 and 5")
+    ap.add_argument("--no-robust", action="store_true", help="skip the robust-input step (repeat family + per-base qualities + ragged reads: rebuilds the index)")
+    ap.add_argument("--robust-copies", type=int, default=10000, help="copies of the 300 bp element planted for the robust-input step")
     ap.add_argument("--repeat-family", type=int, default=0, metavar="COPIES",
                     help="plant COPIES copies of a random 300 bp element in the reference (and draw 5 %% of the reads from them): a repeat-rich workload")
     args = ap.parse_args()
@@ -192,6 +402,8 @@ def main():
 
     n = int(args.ref_len)
     R = int(args.reads)
+    if args.scaling == "strong":
+        R = R // world                                            # strong scaling: the batch of --reads reads is split over the ranks
     M = args.read_len
     t0 = time.time()
     genome = make_reference(n, device, seed=1234)                 # every rank holds the same replica
@@ -241,6 +453,7 @@ def main():
     if args.algo_flags:
         params.algo_flags = (params.algo_flags or 0) | args.algo_flags
     params.fused_seed_pass = not args.no_fused_seeds
+    params.defer_heavy = not args.no_defer_heavy
     params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c
     scheme_t = tuple(int(getattr(sv, f)) for f, _ in sv._fields_)
@@ -252,18 +465,31 @@ def main():
 
     extras = {}
 
-    def step(timers=None):
+    def step(timers=None, pre=None):
         if args.with_traceback:
-            bs, bp, brc, nc, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, return_windows=True)
+            bs, bp, brc, nc, bwb, _ = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, return_windows=True, pre=pre)
             extras["traceback"] = pipeline.traceback_best_all(genome, n, batch, params, extras["best_keys"], bwb, cigar_stride=TB_STRIDE, timers=timers)
         else:
-            bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras)
+            bs, bp, brc, nc = pipeline.seed_and_extend(fmi, genome, n, batch, params, timers, extras=extras, pre=pre)
         if gatherer is not None:
             gatherer.submit(sharding.pack_result64(bs, bp, brc))
         return bs, bp, brc, nc
 
-    for _ in range(args.warmup):
-        step()
+    # Steps are software-pipelined as a caller that streams batches would: the seed pass of step i+1 is enqueued BEFORE the extension of
+    # step i, so the host learns i+1's candidate count (the one host synchronisation of a step: it sizes the extension's launches) while the
+    # GPU extends batch i and the GPU never waits for the host.  K steps still are K seed passes and K extensions inside the timed region.
+    can_pipe = (not args.no_step_pipelining and params.direct and fmi.supports_direct() and params.fused_seed_pass and bool(fmi.canonical))
+
+    def run_steps(k, timers=None):
+        out = None
+        pre = pipeline.seed_pass_begin(fmi, batch, params, 0, timers) if (can_pipe and k) else None
+        for i in range(k):
+            nxt = pipeline.seed_pass_begin(fmi, batch, params, (i + 1) & 1, timers) if (can_pipe and i + 1 < k) else None
+            out = step(timers, pre)
+            pre = nxt
+        return out
+
+    run_steps(args.warmup)
     if gatherer is not None:
         gatherer.wait()
     timers = {}
@@ -271,8 +497,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     w0 = time.perf_counter()
-    for _ in range(args.steps):
-        bs, bp, brc, nc = step(timers)
+    bs, bp, brc, nc = run_steps(args.steps, timers)
     if gatherer is not None:
         gatherer.wait()                                               # every batch's results have landed on rank 0
     torch.cuda.synchronize()
@@ -329,19 +554,20 @@ def main():
     use_fused = bool(use_direct and params.fused_seed_pass)
     use_both = bool(use_fused and fmi.canonical)                 # one launch serves both strands
     launches = 1 if use_both else 2
-    seed_tag = (SEED_BOTH_KERNEL_TAG % ("false" if args.no_wide_table else "true")) if use_both else SEED_KERNEL_TAG
+    seed_tag = (SEED_BOTH_KERNEL_TAG % ("false" if args.no_wide_table else "true", "false" if args.no_defer_heavy else "true")) if use_both else SEED_KERNEL_TAG
     # (1) bytes the TIMED launch has to move, at the 64-byte sector granularity of the fabric (outside the timed region, by the
     #     kernel's accounting instantiation, NVBIO_FM_COUNT_SECTORS): every gather of a search -- direct-table entry, group of a
     #     2..7-occurrence k-mer, bwt_occ records of the rank steps that are left, SA word, text words -- counted as one sector
     #     per distinct 64 bytes, plus what the launch streams: the packed reads once, the tiles' keys and counts written, then
     #     read and written again by the compaction, the residual list.
-    launch_bytes = sectors = None
+    launch_bytes = sectors = streamed = None
     if use_both:
         bufs = fmi.match_seed_diagonals_both(qs, M, flags=amd.FM_COUNT_SECTORS)
         c = bufs["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         n_tiles = -(-R // (64 // spr))
         sectors = float(int(c[4] | (c[5] << 32)))
-        launch_bytes = sectors * SECTOR + float(R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1] + c[2]))
+        streamed = float(R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1] + c[2]))
+        launch_bytes = sectors * LINE + streamed
         del bufs
     elif use_fused:
         acc = []
@@ -350,11 +576,11 @@ def main():
             c = bufs["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             n_tiles = -(-R // (64 // spr if spr <= 64 else 1))
             sect = int(c[2] | (c[3] << 32))
-            streamed = R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1])
-            acc.append((sect, streamed))
+            acc.append((sect, R * M // 2 + 3 * 8 * int(c[0]) + 3 * 4 * n_tiles + 12 * int(c[1])))
             del bufs
         sectors = float(np.mean([a_[0] for a_ in acc]))
-        launch_bytes = sectors * SECTOR + float(np.mean([a_[1] for a_ in acc]))
+        streamed = float(np.mean([a_[1] for a_ in acc]))
+        launch_bytes = sectors * LINE + streamed
     # (2) algorithmic bytes of the REFERENCE's algorithm for the same launch: 32 B x distinct bwt_occ records its
     #     backward search touches (counted by the match kernel's NO_KMER_TABLE accounting mode) + 11 B of query symbols
     #     (22 x 4 bit) + 8 B of result per query -- and the time of that algorithm's own kernel (no table, every symbol stepped)
@@ -408,23 +634,29 @@ def main():
                     and bool(tj.get("direct", False)) == use_direct and bool(tj.get("fused", False)) == use_fused
                     and tj.get("kernel_tag") == seed_tag):
                 traffic = tj.get("match_hbm_bytes_per_launch")
-                traffic_src = ("profiles/traffic.json (tag %s): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this configuration, "
-                               "not measured in this run" % tj.get("tag"))
+                traffic_src = "profiles/traffic.json (tag %s): %s; a profile of this configuration, not measured in this run" % (tj.get("tag"), tj.get("note"))
         except Exception:
             traffic = None
     # the measured ceiling for this access pattern: a chain of two dependent random 8-byte gathers over the table's footprint (128 GiB
     # direct table, 64 GiB canonical table)
     # (scripts/ubench/gather_rate.hip, profiles/r02_gather_rate.jsonl)
+    # the chip's rate of random 128-byte lines over the table's footprint, from the round-3 micro-benchmark (scripts/ubench/gather2.hip ->
+    # profiles/r03_gather2_sweep.jsonl: flat in occupancy, gathers in flight per lane and chain length; its counters: r03_gather2_pmc_128GiB.jsonl)
     ceiling = None
-    gpath = os.path.join(ROOT, "profiles", "r02_gather_rate.jsonl")
+    gpath = os.path.join(ROOT, "profiles", "r03_gather2_sweep.jsonl")
     if os.path.exists(gpath):
+        want_log = 36 if (use_both and args.no_wide_table) else 37
+        best_fit = None
         for line in open(gpath):
             try:
                 gj = json.loads(line)
             except Exception:
                 continue
-            if gj.get("footprint_bytes") == ((64 << 30) if (use_both and args.no_wide_table) else (128 << 30)) and gj.get("chain") == 2 and gj.get("elem_bytes") == 8 and not gj.get("window_bytes"):
-                ceiling = gj.get("G_gathers_per_s")
+            if gj.get("elem_bytes") == 8 and gj.get("chain") == 1 and gj.get("inflight_per_lane") == 1 and gj.get("waves_per_simd") == 8 and not gj.get("precomputed_addresses"):
+                if best_fit is None or abs(gj["footprint_log2"] - want_log) < abs(best_fit["footprint_log2"] - want_log):
+                    best_fit = gj
+        if best_fit is not None:
+            ceiling = best_fit.get("G_gathers_per_s")
     cells = float(nc) * params.band * M
     extend_ms = stage_ms.get("extend_fw", 0.0) + stage_ms.get("extend_rc", 0.0) + stage_ms.get("extend", 0.0) + stage_ms.get("extend_res", 0.0)
     step_ms = elapsed / args.steps * 1e3
@@ -439,7 +671,7 @@ def main():
         "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u32 (FM-index coordinates) / i16x2 (band-31 DP, two alignments per 32-bit lane; exact, bound-checked on the host)",
         "data": "synthetic",
         "config": {"workload": ("nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150 and not args.repeat_family) else "custom"),
@@ -447,7 +679,9 @@ def main():
                    "seed_interval": params.interval_for(M), "seeds_per_read": 2 * spr, "band": params.band,
                    "alignment": ("end-to-end (SEMI_GLOBAL) Gotoh, match 0, mismatch -6 (constant q>=40), gaps -8/-3, min score -0.6-0.6L"
                                  if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "canonical_table": use_both, "wide_entries": bool(use_both and not args.no_wide_table), "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
-                   "index_bytes_per_gpu": fmi.device_bytes(), "parallelism": "read-shard x%d" % world,
+                   "index_bytes_per_gpu": fmi.device_bytes(), "index_bytes_per_reference_base": fmi.device_bytes() / float(n),
+                   "parallelism": "read-shard x%d" % world, "reads_per_step_all_ranks": world * R,
+                   "steps_pipelined": bool(can_pipe), "defer_heavy_searches": bool(params.defer_heavy),
                    "traceback_in_step": bool(args.with_traceback), "repeat_family_copies": args.repeat_family,
                    "max_seed_hits": params.max_seed_hits},
         "left_out_of_the_step": {"note": "the timed step re-runs one HBM-resident batch: no H2D/D2H, no index build"
@@ -465,10 +699,16 @@ def main():
                                     "; single-row searches finish on the text and return positions: match + locate fused" if use_direct else ""))),
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "bytes": ("bytes the timed launch has to move at 64-byte sector granularity (counted by the kernel's accounting instantiation, outside "
-                               "the timed region): gathered sectors x 64 + packed reads + keys / counts written and compacted"),
+                     "bytes": ("bytes the timed launch has to move at the granularity the hardware moves them: every gather is ONE 128-byte fabric read "
+                               "whatever its width, the memory kind or the cache-policy bits (TCC_EA0_RDREQ_128B = gathers, _64B = _32B = 0: "
+                               "profiles/r03_gather2_modes.jsonl), so gathers (counted by the kernel's accounting instantiation, outside the timed "
+                               "region) x 128 + what the launch streams (packed reads, keys / counts written and compacted)"),
                      "bytes_per_launch": launch_bytes, "gathered_sectors_per_launch": sectors, "ms_per_launch": match_ms,
                      "sectors_per_seed": (sectors / n_seeds) if sectors else None,
+                     # of those bytes, the ones the searches look at: the entry / group / record a gather was issued for (<= 64 B of each line)
+                     "useful_bytes_per_launch": (sectors * SECTOR + streamed) if (sectors and streamed is not None) else None,
+                     "useful_frac": ((sectors * SECTOR + streamed) / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sectors and streamed is not None and match_ms > 0) else None,
+                     "frac_of_measured_copy_rate": (achieved / 6290.0) if achieved else None,     # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
                      "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_frac": (traffic / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and match_ms > 0) else None,
                      "launches_per_step": launches,
@@ -524,6 +764,8 @@ def main():
         del b_occ, ssa
         g_host = amd.u32(genome)
         use_ref = oracle.Reference.available()
+        aff, quota = host_cpu_share()
+        cores_granted = max(1, min(aff, int(quota)) if quota else aff)
         if use_ref:
             Rf = oracle.Reference()
             Rf.adopt_index(hidx)
@@ -533,8 +775,10 @@ def main():
                 out = cpu_pipeline.seed_and_extend_ref(Rf, O, hidx, g_host, n, reads_np, timing=tm, aln_type=params.aln_type,
                                                        scheme=oracle.Scheme(*scheme_t))
                 return out, tm["ref_seconds"]
+            Rf.set_num_threads(cores_granted)
             cores = Rf.num_threads()
         else:
+            O.set_num_threads(cores_granted)
             def run(reads_np):
                 c0 = time.perf_counter()
                 out = cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, reads_np, genome_is_packed=True,
@@ -554,9 +798,42 @@ def main():
             "sample": "first %d reads of rank 0's batch; whole path (2x9 exact 22-mer seeds, locate of every hit, band-31 "
                       "Gotoh of every candidate, same mode) through %s, OpenMP over work items; %.1f s"
                       % (Rs, "the reference's own host templates (oracle/_ref)" if use_ref else "the oracle's C restatement", cdt),
-            "results_equal_gpu": same}
+            "results_equal_gpu": same,
+            "logical_cpus": aff, "cgroup_quota_cpus": quota,
+            "threads_note": ("threads = CPUs the process is granted (min of its affinity mask and its cgroup quota); round 2 ran one thread per logical CPU "
+                             "(128 / 256 by box) whatever the quota")}
         log("cpu baseline (%s): %d reads in %.1fs on %d threads (equal to GPU results: %s)"
             % (result["cpu_baseline"]["kind"], Rs, cdt, cores, same))
+        if use_ref and not args.no_port_baseline:
+            # the oracle's C restatement on (a tenth of) the same sample, beside the reference build
+            O.set_num_threads(cores)
+            Rp = max(1000, Rs // 10)
+            sub_np = reads_sym[:Rp].cpu().numpy()
+            c0 = time.perf_counter()
+            pout = cpu_pipeline.seed_and_extend_cpu(O, hidx, g_host, n, sub_np, genome_is_packed=True,
+                                                    aln_type=params.aln_type, scheme=oracle.Scheme(*scheme_t))
+            pdt_cpu = time.perf_counter() - c0
+            result["cpu_baseline"]["port"] = {"value": Rp / pdt_cpu, "unit": "reads/s", "cores": cores, "kind": "port", "reads": Rp,
+                                              "note": "the oracle's C restatement; includes its numpy glue (the reference leg counts the time inside the reference's functions only)",
+                                              "results_equal_reference": bool(np.array_equal(pout[0], cs[:Rp]) and np.array_equal(pout[1], cp[:Rp]))}
+
+    # ---- BASELINE configs 2, 4, 5 at kernel / composition level on the same index (untimed extras; rank 0, one GPU) ----
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            result["configs"] = run_configs(torch, amd, pipeline, fmi, genome, n, device, M, scale=min(1.0, R / 1e7 * 4.0 if R < 2_500_000 else 1.0))
+        except Exception as e:                                     # an extra must not take the line down
+            result["configs"] = {"error": repr(e)}
+
+    # ---- the robust-input step (rank 0, one GPU): needs the headline's handle gone ----
+    if rank == 0 and world == 1 and not args.no_robust and use_both:
+        try:
+            del batch, reads4, reads_sym, truth_pos, truth_rc, extras
+            fmi.close()
+            del fmi
+            torch.cuda.empty_cache()
+            result["robust"] = run_robust(torch, np, amd, pipeline, args, genome, n, R, M, device, rank, step_ms)
+        except Exception as e:
+            result["robust"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

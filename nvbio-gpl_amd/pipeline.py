@@ -87,6 +87,69 @@ class ReadBatch:
         self.offsets = offsets
 
 
+def _batch_geometry(torch, fmi, reads, params):
+    """seed enumeration of a read batch: the seed set (infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernels:
+    uniform_seeds_functor semantics, no offset array is materialised), the reads' offsets and, for a ragged batch, every read's own
+    seed interval (seed_freq( read_len ), mapping_inl.h:507-529) and score threshold -- the tables are evaluated on the host in float32
+    as the reference evaluates them, per length, and gathered per read on the device"""
+    dev = fmi.device
+    R, M, L = reads.n, reads.read_len, params.seed_len
+    S_int = params.interval_for(M)
+    spr = (M - L) // S_int + 1                                   # seeds per read and strand
+    ragged = reads.offsets is not None
+    intervals = min_scores = None
+    if ragged:
+        cache = getattr(reads, "_ragged", None)
+        if cache is None or cache[0] is not params:
+            lens = (reads.offsets[1:] - reads.offsets[:-1]).to(torch.int64)
+            itab = params.interval_table(M)
+            it = torch.from_numpy(itab).to(dev)
+            mt = torch.from_numpy(params.min_score_table(M)).to(dev)
+            spr_max = max(((l - L) // int(itab[l]) + 1) if l >= L else 0 for l in range(M + 1))
+            cache = reads._ragged = (params, it[lens].contiguous(), mt[lens].contiguous(), int(spr_max))
+        _, intervals, min_scores, spr = cache
+        qs = PackedStringSet(reads.reads4, 4, R * spr, offsets=reads.offsets, fixed_len=L, stride=0, device=dev, seeds_per_string=spr,
+                             seed_intervals=intervals)
+        read_off = reads.offsets
+    else:
+        qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
+                             seed_interval=S_int)
+        read_off = getattr(reads, "_read_off", None)
+        if read_off is None:
+            read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
+    return dict(S_int=S_int, spr=spr, ragged=ragged, intervals=intervals, min_scores=min_scores, qs=qs, read_off=read_off)
+
+
+def seed_pass_begin(fmi, reads, params, slot=0, timers=None):
+    """Enqueue the two-strand seed pass of a batch and the copy of its counts to pinned host memory; returns the handle
+    seed_and_extend( ..., pre = handle ) continues from.  A caller that streams batches enqueues batch i+1's seed pass BEFORE batch i's
+    extension: the host then reads i+1's counts while the GPU extends batch i, and the one host synchronisation of a step -- the sizes
+    of the extension's launches -- never leaves the GPU idle (bench.py does this).  slot: which of the handle's buffer sets to use
+    (two consecutive batches need different ones)."""
+    import torch
+    geo = _batch_geometry(torch, fmi, reads, params)
+    bufs = getattr(fmi, "_seed_bufs2", None)
+    if bufs is None:
+        bufs = fmi._seed_bufs2 = {}
+    b = bufs.setdefault(slot, {})
+    ev_t = None
+    if timers is not None:
+        a, ev_t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        timers.setdefault("match_both", []).append((a, ev_t))
+        a.record()
+    # seeds that end on 2..4 rows (short repeats) leave all their keys at once: on unique-ish genomes the residual lists stay
+    # empty and the scan + locate path with its host round trips is not entered at all
+    fmi.match_seed_diagonals_both(geo["qs"], reads.read_len, b, inline_hits=min(4, params.max_seed_hits or 4), defer_heavy=params.defer_heavy)
+    if ev_t is not None:
+        ev_t.record()
+    if "host" not in b:
+        b["host"] = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    b["host"].copy_(b["counts"][:4], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return dict(b=b, ev=ev, reads=reads)
+
+
 SCORE_BIAS = 1 << 20
 
 
@@ -98,7 +161,7 @@ def pack_best_key(torch, scores, rc, pos):
     return (s << 34) | (rc.to(torch.int64) << 33) | pos.to(torch.int64)
 
 
-def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return_windows=False, extras=None):
+def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return_windows=False, extras=None, pre=None):
     """returns (best_score[int32 R], best_pos[int64 R] (text position of the alignment's end, or -1),
     best_rc[uint8 R], n_candidates).  timers: optional dict name -> list of (start, end) events.
     return_windows: also return best_wb[int64 R], the window begin of each read's best candidate (-1 if
@@ -112,22 +175,8 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
     from . import best_candidate_reduce, best_candidate_unpack, best_candidate_windows, diagonals_to_windows, mapq, second_candidate_reduce
     dev = fmi.device
     R, M, L = reads.n, reads.read_len, params.seed_len
-    S_int = params.interval_for(M)
-    spr = (M - L) // S_int + 1                                   # seeds per read and strand
-    ragged = reads.offsets is not None
-    intervals = min_scores = None
-    if ragged:
-        # every read its own length, seed interval (seed_freq( read_len ), mapping_inl.h:507-529) and score threshold; the tables are
-        # evaluated on the host in float32 as the reference evaluates them, per length, and gathered per read on the device
-        cache = getattr(reads, "_ragged", None)
-        if cache is None or cache[0] is not params:
-            lens = (reads.offsets[1:] - reads.offsets[:-1]).to(torch.int64)
-            it = torch.from_numpy(params.interval_table(M)).to(dev)
-            mt = torch.from_numpy(params.min_score_table(M)).to(dev)
-            itab = params.interval_table(M)
-            spr_max = max(((l - L) // int(itab[l]) + 1) if l >= L else 0 for l in range(M + 1))
-            cache = reads._ragged = (params, it[lens].contiguous(), mt[lens].contiguous(), int(spr_max))
-        _, intervals, min_scores, spr = cache
+    geo = _batch_geometry(torch, fmi, reads, params)
+    S_int, spr, ragged, intervals, min_scores, qs, read_off = (geo[k] for k in ("S_int", "spr", "ragged", "intervals", "min_scores", "qs", "read_off"))
 
     def tick(name):
         if timers is None:
@@ -141,18 +190,6 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         if b is not None:
             b.record()
 
-    # 1. seeds: infixes [r*M + j*S, +L) of the read stream, enumerated inside the kernel
-    #    (uniform_seeds_functor semantics; no offset array is materialised)
-    if ragged:
-        qs = PackedStringSet(reads.reads4, 4, R * spr, offsets=reads.offsets, fixed_len=L, stride=0, device=dev, seeds_per_string=spr,
-                             seed_intervals=intervals)
-        read_off = reads.offsets
-    else:
-        qs = PackedStringSet(reads.reads4, 4, R * spr, fixed_len=L, stride=M, device=dev, seeds_per_string=spr,
-                             seed_interval=S_int)
-        read_off = getattr(reads, "_read_off", None)
-        if read_off is None:
-            read_off = reads._read_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * M
     ext_flags = (params.algo_flags or 0) | (ALN_RAGGED_READS if ragged else 0)
     aligner = GotohAligner(params.aln_type, params.scheme)
     top = torch.zeros((R,), dtype=torch.int64, device=dev)      # best selection key per read (0: no candidate)
@@ -197,25 +234,16 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     ck = fmi.canonical_kmer if fused else 0
     both = fused and ck and ck <= L <= ck + 7 and spr <= 64 and getattr(params, "two_strand_pass", True)
-    if ragged and not both:
-        raise ValueError("ragged read batches go through the two-strand seed pass (an index built with FM_TABLE_CANONICAL[_WIDE])")
+    if ragged and fused and not both:
+        fused = False                   # (the per-strand one-call pass serves uniform batches only: a ragged batch takes the separate operators)
     if both:
         # 2.-4. for BOTH strands in one kernel over the canonical table (a k-mer and its reverse complement share an entry): one table
         #    gather per seed window instead of one per window and strand
-        b = getattr(fmi, "_seed_bufs2", None)
-        if b is None:
-            b = fmi._seed_bufs2 = {}
-        e = tick("match_both")
-        # seeds that end on 2..4 rows (short repeats) leave all their keys at once: on unique-ish genomes the residual lists stay
-        # empty and the scan + locate path with its host round trips is not entered at all
-        fmi.match_seed_diagonals_both(qs, M, b, inline_hits=min(4, params.max_seed_hits or 4), defer_heavy=params.defer_heavy)
-        tock(e)
-        if "host" not in b:
-            b["host"] = torch.empty(4, dtype=torch.int32, pin_memory=True)
-        b["host"].copy_(b["counts"][:4], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        ev.synchronize()
+        if pre is None:
+            pre = seed_pass_begin(fmi, reads, params, 0, timers)
+        assert pre["reads"] is reads
+        b = pre["b"]
+        pre["ev"].synchronize()
         n_keys, n_rf, n_rr = int(b["host"][0]), int(b["host"][1]), int(b["host"][2])
         parts = [b["keys"][:n_keys]]
         if n_rf or n_rr:
@@ -294,7 +322,7 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
         #    arrive in seed order, so an adjacent compare removes nearly all duplicates without a sort; a survivor only
         #    costs a repeated extension)
         e = tick("locate")
-        keys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand)
+        keys = flt.locate_diagonals(0, n_hits, spr, S_int, L, M, strand, read_offsets=read_off if ragged else None, seed_intervals=intervals)
         tock(e)
         e = tick("diagonals")
         keys = torch.unique_consecutive(keys)

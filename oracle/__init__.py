@@ -147,6 +147,9 @@ class Oracle:
     def num_threads(self):
         return int(self.lib.orc_num_threads())
 
+    def set_num_threads(self, n):
+        self.lib.orc_set_num_threads(int(n))
+
     # ---- packing -------------------------------------------------------------------------
     def pack2(self, syms):
         syms = _c8(syms)
@@ -617,6 +620,9 @@ class Reference:
 
     def num_threads(self):
         return int(self.lib.ref_num_threads())
+
+    def set_num_threads(self, n):
+        self.lib.ref_set_num_threads(int(n))
 
     def banded_gotoh_batch(self, band, typ, scheme, pats, pat_off, txts, txt_off, quals=None):
         pats, txts, quals = _c8(pats), _c8(txts), _c8(quals)

@@ -21,6 +21,15 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+/* the OpenMP team size of the batch loops (bench.py sets it to the CPUs the process is really granted) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads( n );
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------
  * packed streams: PackedStream<..,2,true> / <..,4,true>  (nvbio/basic/packedstream_inl.h:33-75)

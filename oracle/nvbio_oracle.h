@@ -218,6 +218,7 @@ void orc_full_gotoh_many_to_one(int type, int blocking, const orc_gotoh_scheme* 
                                 const uint8_t* text, uint32_t text_len, uint32_t n, int32_t min_score, int32_t* scores, uint32_t* sinks);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 /* hamming_backtrack (nvbio/fmindex/backtrack.h) with a counting delegate; see nvbio_oracle.c */
 uint32_t orc_hamming_backtrack(const orc_fm_index* f, const uint8_t* stream, uint32_t begin, uint32_t len, uint32_t seed, uint32_t mismatches,

@@ -648,6 +648,14 @@ int ref_num_threads(void)
     return 1;
 #endif
 }
+void ref_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads( n );
+#else
+    (void)n;
+#endif
+}
 
 void ref_fm_destroy(void* h) { delete (RefIndex*)h; }
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_json_contract(extra):
     """the default configuration (canonical table, one seed pass for both strands) and the per-strand one over the direct table"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ref-len", "4e6", "--reads", "40000", "--steps", "2",
-                          "--warmup", "1", "--kmer", "15", "--cpu-sample", "5000"] + extra, capture_output=True, text=True, timeout=600)
+                          "--warmup", "1", "--kmer", "15", "--cpu-sample", "5000", "--robust-copies", "40"] + extra, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -36,6 +36,7 @@ def test_bench_json_contract(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # a roofline fraction is a fraction: the bytes are those the TIMED launch moves (sector-granular, counted by the kernel)
     assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["reference_algorithm"]["frac"] <= 1.0
+    assert r["useful_bytes_per_launch"] <= r["bytes_per_launch"] and 0.0 < r["useful_frac"] <= r["frac"]
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["gathered_sectors_per_launch"] > 0 and 0.5 < r["sectors_per_seed"] < 40.0       # about 1.07 on the 3 Gbp / k = 17 workload; rank steps dominate on this toy index
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]          # counter traffic comes from a named profile, never from thin air
@@ -52,3 +53,17 @@ def test_bench_json_contract(extra):
     assert d["plain_operators"]["results_equal"] is True
     assert d["traceback"]["scores_equal_scoring_pass"] is True
     assert d["aligned_fraction"] > 0.99 and d["correct_locus_fraction"] > 0.98
+    assert c["cores"] <= c["logical_cpus"] and (c["kind"] != "reference" or c["port"]["results_equal_reference"] is True)
+    # BASELINE configs 2, 4, 5 at kernel / composition level, in the same line
+    cf = d["configs"]
+    assert "error" not in cf, cf
+    assert cf["fm_seeds_1M"]["queries_per_s"] > 0 and 0.0 < cf["fm_seeds_1M"]["no_table"]["alg_frac_of_hbm_peak"] <= 1.0
+    assert cf["banded_local_6.25M"]["gcups"] > 0 and 0.0 < cf["banded_local_6.25M"]["dp_issue_frac"] <= 1.0
+    assert cf["paired_end_1M"]["pairs_per_s"] > 0 and cf["paired_end_1M"]["concordant_fraction"] > 0.9
+    # the robust-input step (repeat family + per-base qualities + ragged reads) over the canonical table, checked against the plain operators
+    if canon:
+        rb = d["robust"]
+        assert "error" not in rb, rb
+        assert rb["ms_per_step"] > 0 and rb["plain_operators"]["results_equal"] is True and rb["aligned_fraction"] > 0.97
+    else:
+        assert "robust" not in d
