@@ -431,6 +431,22 @@ nvbio_status nvbio_mapq_ragged(int device, const uint64_t* best_dev, const uint6
                                const uint32_t* read_offsets_dev, const int32_t* min_scores_dev, int32_t* second_scores_dev, uint8_t* mapq_dev,
                                void* stream);
 
+/* The residual seeds of a seed pass (nvbio_fm_match_seed_diagonals[_both]: searches that ended on several SA rows) under a seed-hit cap, in
+ * ONE call: the first `cap` rows of every range (nvBowtie bounds repeats with its max_hits deque, mapping_inl.h:242-244; this is the order-free
+ * stand-in the default pipeline uses) are located and turned into diagonal keys, as nvbio_fm_filter_scan + nvbio_fm_filter_locate_diagonals
+ * over the capped ranges would -- without the scan, its host synchronisation and the global sort a duplicate removal would take: the
+ * entries are sorted by seed id, so that consecutive seeds of a read are neighbours, and a key equal to the one the previous entry leaves
+ * at the same row is dropped (the seeds of a read inside a repeat list the same loci row for row).  The SET of keys equals that of the
+ * two-call form; a duplicate that survives costs a repeated extension, nothing else.
+ *   ids_dev[e]        seed id of entry e, bit 31 = reverse strand (the convention of nvbio_fm_filter_locate_diagonals' query_ids_dev)
+ *   keys_dev          room for n * cap keys; *n_keys_dev (device) = keys written
+ *   read_offsets_dev / seed_intervals_dev   ragged reads (both or neither; then seed_interval and read_len are ignored)
+ * Needs the full suffix array (sa_int = 1).  1 <= cap <= 64, n * cap < 2^31. */
+nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint32_t* ids_dev, uint32_t n, uint32_t cap,
+                                         uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                         const uint32_t* read_offsets_dev, const uint32_t* seed_intervals_dev,
+                                         uint64_t* keys_dev, uint32_t* n_keys_dev, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * nvBowtie's scoring stream, as data: what a specialisation of aln::BatchedBandedAlignmentScore for
  * bowtie2::cuda::BestScoreStream (nvBowtie/bowtie2/cuda/score_inl.h:44-136) hands over instead of per-item callbacks.
@@ -625,6 +641,7 @@ enum
                                               end-to-end kernel -- two alignments per lane -- then runs a build that takes a lane's two alignments
                                               in one pass whatever their lengths (the shorter one starts late); without the hint such a lane takes
                                               two passes.  Results are identical either way.                                        */
+    NVBIO_ALN_NO_LENGTH_SORT        = 8192, /* with NVBIO_ALN_RAGGED_READS: the DP's job list in batch order instead of ascending read length (A/B)   */
     NVBIO_ALN_NO_QUALITY_SHORTCUT   = 2048, /* band-31 end-to-end scoring of reads WITH base qualities under a quality-dependent mismatch penalty
                                               (nvBowtie's default ramp): every job through the DP, as before round 3 (A/B)          */
     NVBIO_ALN_NO_NARROW_TRACEBACK   = 64   /* band-31 end-to-end traceback: every DP over the whole band (no band-15 route for the jobs

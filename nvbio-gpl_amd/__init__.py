@@ -34,7 +34,7 @@ TRACEBACK_SINKS_GIVEN = 1
 # nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)
 ALN_NO_UNGAPPED_SCORE, ALN_NO_THIRD_CHANCE, ALN_NO_PACKED_DP, ALN_FORCE_PACKED_DP, ALN_NO_UNGAPPED_TRACEBACK, ALN_PK_THREE_WAVES = 1, 2, 4, 8, 16, 32
 ALN_NO_NARROW_TRACEBACK, ALN_NO_SECOND_CHANCE, ALN_PK_STRIPE8, ALN_NO_NARROW_SCORE, ALN_NO_BAND_ROUTE = 64, 128, 256, 512, 1024
-ALN_NO_QUALITY_SHORTCUT, ALN_RAGGED_READS = 2048, 4096
+ALN_NO_QUALITY_SHORTCUT, ALN_RAGGED_READS, ALN_NO_LENGTH_SORT = 2048, 4096, 8192
 DEFAULT_ALGO_FLAGS = 0          # what an AlignmentBatch is created with unless told otherwise (tests set it for a whole run)
 BACKTRACK_REFERENCE_QUIRKS = 1
 
@@ -421,6 +421,19 @@ class FMIndex:
             _ptr(buffers["keys"]), _ptr(buffers["ranges"]), _ptr(buffers["ids"]), ctypes.c_uint32(n), _ptr(buffers["counts"]),
             _ptr(buffers["temp"]), ctypes.c_uint64(buffers["temp"].numel()), _stream_ptr(self.device)))
         return buffers
+
+    def residual_diagonals(self, ranges, ids, cap, seeds_per_read, seed_interval, seed_len, read_len, read_offsets=None, seed_intervals=None):
+        """nvbio_fm_residual_diagonals: the first `cap` rows of every residual range located and turned into diagonal keys (duplicates of
+        neighbouring seeds dropped) -> (keys int64 [n * cap], n_keys int32 [1] on the device)"""
+        torch = _torch()
+        n = int(ids.numel())
+        keys = torch.empty(max(n * int(cap), 1), dtype=torch.int64, device=self.device)
+        n_keys = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(lib().nvbio_fm_residual_diagonals(
+            self._h, _ptr(ranges), _ptr(ids), ctypes.c_uint32(n), ctypes.c_uint32(int(cap)), ctypes.c_uint32(seeds_per_read),
+            ctypes.c_uint32(seed_interval), ctypes.c_uint32(seed_len), ctypes.c_uint32(read_len), _ptr(read_offsets), _ptr(seed_intervals),
+            _ptr(keys), _ptr(n_keys), _stream_ptr(self.device)))
+        return keys, n_keys
 
     def rank(self, rows, syms):
         torch = _torch()

@@ -966,6 +966,43 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The residual seeds of a seed pass under a seed-hit cap (nvbio_fm_residual_diagonals): entry e = (SA range, seed id | strand << 31);
+// the first `cap` rows of every range are located (the handle holds the full suffix array: one gather) and turned into diagonal keys
+// at a fixed stride -- keys[e * cap + t], unused slots = ~0 -- so that no scan is needed before the expansion.  Entries arrive SORTED
+// by id: consecutive seeds of a read are neighbours, and a key equal to the key the previous entry leaves at the same row t is dropped
+// (the seeds of a read that lies in a repeat list the same loci, row for row, because the suffixes that decide the order of a repeat's
+// copies in the suffix array begin behind the repeat whatever the seed's offset in it).  What survives is made dense by a select.
+// A duplicate that survives only costs a repeated extension.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+residual_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids, const uint32_t n, const uint32_t cap,
+                       const DiagSpec ds, uint64_t* __restrict__ keys)
+{
+    const uint64_t total = (uint64_t)n * cap;
+    auto key_of = [&](const uint32_t e, const uint32_t t) -> uint64_t {
+        const uint2 r = ranges[e];
+        if (r.x > r.y || (uint64_t)r.x + t > r.y) return ~0ull;
+        const uint32_t sv  = f.ssa[r.x + t];
+        const uint32_t pos = (sv == 0xFFFFFFFFu) ? f.length : sv;
+        const uint32_t qv  = ids[e];
+        const uint32_t sid = qv & 0x7FFFFFFFu, str = (ds.strand ^ (qv >> 31)) & 1u;
+        const uint32_t rid = sid / ds.spr;
+        uint32_t       p   = (sid - rid * ds.spr) * (ds.intervals ? ds.intervals[rid] : ds.interval);
+        if (str) p = (ds.read_offsets ? ds.read_offsets[rid + 1] - ds.read_offsets[rid] : ds.read_len) - p - ds.seed_len;
+        return ((uint64_t)rid << 34) | ((uint64_t)str << 33) | ((uint64_t)pos + 1024u - p);
+    };
+    for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint32_t e = (uint32_t)(slot / cap), t = (uint32_t)(slot - (uint64_t)e * cap);
+        uint64_t k = key_of( e, t );
+        if (k != ~0ull && e > 0u && key_of( e - 1u, t ) == k) k = ~0ull;
+        keys[slot] = k;
+    }
+}
+struct KeyIsSet { __host__ __device__ __forceinline__ bool operator()(const uint64_t k) const { return k != ~0ull; } };
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1873,6 +1910,61 @@ nvbio_status nvbio_fm_filter_locate_diagonals_ragged(nvbio_fm_index_t index, con
                                     strand, query_ids_dev, read_offsets_dev, seed_intervals_dev, keys_dev, stream );
 }
 
+
+
+nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uint2* ranges_dev, const uint32_t* ids_dev, uint32_t n, uint32_t cap,
+                                         uint32_t seeds_per_read, uint32_t seed_interval, uint32_t seed_len, uint32_t read_len,
+                                         const uint32_t* read_offsets_dev, const uint32_t* seed_intervals_dev,
+                                         uint64_t* keys_dev, uint32_t* n_keys_dev, void* stream)
+{
+    NVB_REQUIRE( index != nullptr && n_keys_dev != nullptr, "NULL argument" );
+    FMIndexImpl* idx = (FMIndexImpl*)index;
+    DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    NVB_HIP( hipMemsetAsync( n_keys_dev, 0, sizeof(uint32_t), s ) );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( ranges_dev && ids_dev && keys_dev, "NULL device pointer" );
+    NVB_REQUIRE( cap >= 1u && cap <= 64u, "cap must be in 1..64" );
+    NVB_REQUIRE( (uint64_t)n * cap < (1ull << 31), "n * cap must stay below 2^31" );
+    NVB_REQUIRE( seeds_per_read > 0, "seeds_per_read must be positive" );
+    NVB_REQUIRE( (read_offsets_dev == nullptr) == (seed_intervals_dev == nullptr), "ragged reads need both read_offsets_dev and seed_intervals_dev" );
+    if (!(idx->view.ssa_dev && idx->view.sa_int == 1))
+    {
+        set_error( "nvbio_fm_residual_diagonals needs the full suffix array: build the index with sa_int = 1" );
+        return NVBIO_ERR_UNSUPPORTED;
+    }
+    // scratch: sorted ids | sorted ranges | padded keys | sort / select temp
+    const uint64_t ids_bytes = ((uint64_t)n * 4u + 255u) & ~255ull, rng_bytes = ((uint64_t)n * 8u + 255u) & ~255ull;
+    const uint64_t pad_bytes = ((uint64_t)n * cap * 8u + 255u) & ~255ull;
+    size_t sort_bytes = 0, sel_bytes = 0;
+    NVB_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 32, s ) );
+    NVB_HIP( hipcub::DeviceSelect::If( nullptr, sel_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (int)(n * cap), KeyIsSet(), s ) );
+    const uint64_t tmp_bytes = ((uint64_t)(sort_bytes > sel_bytes ? sort_bytes : sel_bytes) + 255u) & ~255ull;
+    uint8_t* aux = nullptr;
+    if (hipMallocAsync( (void**)&aux, ids_bytes + rng_bytes + pad_bytes + tmp_bytes + 256u, s ) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        set_error( "residual diagonals: out of device memory" );
+        return NVBIO_ERR_NOMEM;
+    }
+    uint32_t* ids_s = (uint32_t*)aux;
+    uint64_t* rng_s = (uint64_t*)(aux + ids_bytes);
+    uint64_t* padk  = (uint64_t*)(aux + ids_bytes + rng_bytes);
+    void*     tmp   = aux + ids_bytes + rng_bytes + pad_bytes;
+    size_t tb = tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs( tmp, tb, ids_dev, ids_s, (const uint64_t*)ranges_dev, rng_s, (int)n, 0, 32, s );
+    if (e == hipSuccess)
+    {
+        const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, 0u, nullptr, read_offsets_dev, seed_intervals_dev };
+        hipLaunchKernelGGL( residual_locate_kernel, dim3( grid_for( (uint64_t)n * cap ) ), dim3(256), 0, s, idx->dev(), (const uint2*)rng_s, (const uint32_t*)ids_s, n, cap, ds, padk );
+        e = hipGetLastError();
+    }
+    tb = tmp_bytes;
+    if (e == hipSuccess) e = hipcub::DeviceSelect::If( tmp, tb, (const uint64_t*)padk, keys_dev, n_keys_dev, (int)(n * cap), KeyIsSet(), s );
+    (void)hipFreeAsync( aux, s );
+    if (e != hipSuccess) { set_error( "residual diagonals failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    return NVBIO_OK;
+}
 
 nvbio_status nvbio_seed_hits_map_approx(nvbio_fm_index_t index, nvbio_fm_index_t reverse_index, const void* reads_dev, uint32_t read_bits,
                                         const uint32_t* read_queue_dev, uint32_t n_reads, const nvbio_seed_hits_params* p, nvbio_uint2* deques_dev,

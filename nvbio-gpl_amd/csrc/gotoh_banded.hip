@@ -1037,6 +1037,59 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
 struct IsTwo { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 2u ? 1u : 0u; } };
 struct FlagIs { const uint8_t* flags; uint8_t code; __host__ __device__ __forceinline__ bool operator()(const uint32_t i) const { return flags[i] == code; } };
 
+
+// RAGGED batches: the DP's job list in ascending order of read length, so that the two alignments of a lane -- and the lanes of a wave --
+// (nearly always) run the same number of rows: sort key = the job's read length, 0xFFFF behind the list's end (jobs = NULL: every job of
+// the batch).  One or two radix passes over (uint16 key, uint32 job).
+__global__ void __launch_bounds__(256)
+job_length_keys_kernel(const BatchDev b, const uint32_t* __restrict__ jobs, const uint32_t* __restrict__ job_count, uint16_t* __restrict__ keys,
+                       uint32_t* __restrict__ jobs_all, uint32_t* __restrict__ count_all)
+{
+    const uint32_t n = jobs ? *job_count : b.n;
+    if (!jobs && blockIdx.x == 0 && threadIdx.x == 0) *count_all = b.n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += gridDim.x * blockDim.x)
+    {
+        uint32_t key = 0xFFFFu;
+        if (i < n)
+        {
+            const uint32_t job = jobs ? jobs[i] : i;
+            const uint32_t rid = b.read_id ? b.read_id[job] : job;
+            const uint32_t M   = b.read_offsets[rid + 1] - b.read_offsets[rid];
+            key = M < 0xFFFEu ? M : 0xFFFEu;
+        }
+        keys[i] = (uint16_t)key;
+        if (!jobs) jobs_all[i] = i;
+    }
+}
+
+// sorted list and its length (device) in *list_out / *count_out; the scratch is freed stream-ordered by the caller through *aux_out
+static nvbio_status sort_jobs_by_length(const BatchDev& b, const uint32_t* job_list, const uint32_t* job_count, const uint32_t** list_out,
+                                        const uint32_t** count_out, void** aux_out, hipStream_t s)
+{
+    const uint64_t kb = ((uint64_t)b.n * 2u + 255u) & ~255ull, lb = ((uint64_t)b.n * 4u + 255u) & ~255ull;
+    size_t sort_bytes = 0;
+    int bits = 1; while ((1u << bits) <= (b.max_read_len ? b.max_read_len : 0xFFFEu) && bits < 16) ++bits;
+    bits = 16;                                   // (the 0xFFFF keys behind the list's end must sort last: all 16 bits)
+    NVB_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, sort_bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                 (int)b.n, 0, bits, s ) );
+    uint8_t* aux = nullptr;
+    if (hipMallocAsync( (void**)&aux, 2u * kb + 2u * lb + 256u + sort_bytes, s ) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        set_error( "banded score: out of device memory for the length-sorted job list" );
+        return NVBIO_ERR_NOMEM;
+    }
+    uint16_t* k_in = (uint16_t*)aux; uint16_t* k_out = (uint16_t*)(aux + kb);
+    uint32_t* l_all = (uint32_t*)(aux + 2u * kb); uint32_t* l_out = (uint32_t*)(aux + 2u * kb + lb);
+    uint32_t* c_all = (uint32_t*)(aux + 2u * kb + 2u * lb);
+    void* tmp = aux + 2u * kb + 2u * lb + 256u;
+    hipLaunchKernelGGL( job_length_keys_kernel, dim3( (b.n + 255u) / 256u < 65536u ? (b.n + 255u) / 256u : 65536u ), dim3( 256 ), 0, s, b, job_list, job_count, k_in, l_all, c_all );
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs( tmp, sort_bytes, (const uint16_t*)k_in, k_out, job_list ? job_list : (const uint32_t*)l_all, l_out, (int)b.n, 0, bits, s );
+    if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "job sort failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    *list_out = l_out; *count_out = job_list ? job_count : c_all; *aux_out = aux;
+    return NVBIO_OK;
+}
+
 // the packed kernel's instantiation for this scheme: match = 0 (every end-to-end scheme of nvBowtie) drops one operation per cell
 template <int TYPE, int RB>
 static void launch_pk_kernel(const BatchDev& b, const SchemeDev& sc, const uint32_t pairs, int32_t* scores, uint2* sinks,
@@ -1126,10 +1179,26 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
         {
-            launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, job_list, job_count, s );
+            const uint32_t* jl = job_list; const uint32_t* jc = job_count; void* aux2 = nullptr;
+            if (TYPE == NVBIO_SEMI_GLOBAL && sc.match == 0 && (b.algo & NVBIO_ALN_RAGGED_READS) && !(b.algo & NVBIO_ALN_NO_LENGTH_SORT))
+            {
+                const nvbio_status st = sort_jobs_by_length( b, job_list, job_count, &jl, &jc, &aux2, s );
+                if (st != NVBIO_OK) { (void)hipFreeAsync( aux, s ); return st; }
+            }
+            launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, jl, jc, s );
+            if (aux2) (void)hipFreeAsync( aux2, s );
         }
         (void)hipFreeAsync( aux, s );
         if (e != hipSuccess) { set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        NVB_HIP( hipGetLastError() );
+        return NVBIO_OK;
+    }
+    if (TYPE == NVBIO_SEMI_GLOBAL && sc.match == 0 && (b.algo & NVBIO_ALN_RAGGED_READS) && !(b.algo & NVBIO_ALN_NO_LENGTH_SORT) && b.n > 1u)
+    {
+        const uint32_t* jl = nullptr; const uint32_t* jc = nullptr; void* aux2 = nullptr;
+        NVB_CHECK( sort_jobs_by_length( b, nullptr, nullptr, &jl, &jc, &aux2, s ) );
+        launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, jl, jc, s );
+        (void)hipFreeAsync( aux2, s );
         NVB_HIP( hipGetLastError() );
         return NVBIO_OK;
     }

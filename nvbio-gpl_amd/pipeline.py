@@ -218,6 +218,14 @@ def seed_and_extend(fmi, genome2, genome_len, reads, params, timers=None, return
 
     def residual_keys(ranges, ids, strand):
         """seeds that ended on several SA rows (repeats): the ordinary scan + locate path -> their diagonal keys"""
+        if params.max_seed_hits is not None and params.max_seed_hits <= 64 and use_direct and ids.numel() * params.max_seed_hits < 2 ** 31 \
+                and getattr(params, "one_call_residuals", True):
+            # under a seed-hit cap: one call (sort by seed id, capped expansion at a fixed stride, neighbour-duplicate removal, select)
+            if strand:
+                ids = ids ^ -2 ** 31
+            rk, nk = fmi.residual_diagonals(ranges.contiguous(), ids.contiguous(), params.max_seed_hits, spr, S_int, L, M,
+                                            read_offsets=read_off if ragged else None, seed_intervals=intervals)
+            return rk[:int(nk.item())]
         if params.max_seed_hits is not None:
             x = ranges[:, 0].to(torch.int64) & 0xFFFFFFFF
             y = ranges[:, 1].to(torch.int64) & 0xFFFFFFFF

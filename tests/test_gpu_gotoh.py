@@ -368,7 +368,8 @@ def test_end_to_end_shortcut_with_qualities_reversed_reads(amd, orc):
     for quals in _quality_sets(rng, len(flat)):
         wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we,
                                                  read_id=rid, flags=flags, quals=quals)
-        for algo in (None, amd.ALN_NO_UNGAPPED_SCORE):
+        for algo in (None, amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_RAGGED_READS, amd.ALN_RAGGED_READS | amd.ALN_NO_LENGTH_SORT,
+                     amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE | amd.ALN_NO_LENGTH_SORT):
             batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, flags=flags, max_read_len=150, algo_flags=algo)
             sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
             assert np.array_equal(sc.cpu().numpy(), wsc), algo

@@ -290,13 +290,13 @@ def test_pipeline_ragged_reads_with_qualities_and_a_repeat_family(amd, orc):
     g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
     scheme = oracle.Scheme(0, 2, 6, -8, -3, -8, -3)
     results = {}
-    for defer in (True, False):
+    for defer, one_call in ((True, True), (False, True), (True, False)):
         for algo in (0, amd.ALN_NO_UNGAPPED_SCORE):
-            params.defer_heavy, params.algo_flags = defer, algo
+            params.defer_heavy, params.algo_flags, params.one_call_residuals = defer, algo, one_call
             ex = {}
             bs, bp, brc, nc = pipeline.seed_and_extend(fmi, g_dev, G, rb, params, extras=ex)
-            results[(defer, algo)] = (bs.cpu().numpy(), bp.cpu().numpy(), brc.cpu().numpy(), ex["mapq"].cpu().numpy(), ex["second_score"].cpu().numpy())
-    base = results[(True, 0)]
+            results[(defer, one_call, algo)] = (bs.cpu().numpy(), bp.cpu().numpy(), brc.cpu().numpy(), ex["mapq"].cpu().numpy(), ex["second_score"].cpu().numpy())
+    base = results[(True, True, 0)]
     for key, val in results.items():
         for a, b in zip(base, val):
             assert np.array_equal(a, b), key
