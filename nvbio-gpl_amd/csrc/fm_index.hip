@@ -969,39 +969,67 @@ fm_filter_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, cons
 
 // ---------------------------------------------------------------------------------------------
 // The residual seeds of a seed pass under a seed-hit cap (nvbio_fm_residual_diagonals): entry e = (SA range, seed id | strand << 31);
-// the first `cap` rows of every range are located (the handle holds the full suffix array: one gather) and turned into diagonal keys
-// at a fixed stride -- keys[e * cap + t], unused slots = ~0 -- so that no scan is needed before the expansion.  Entries arrive SORTED
-// by id: consecutive seeds of a read are neighbours, and a key equal to the key the previous entry leaves at the same row t is dropped
-// (the seeds of a read that lies in a repeat list the same loci, row for row, because the suffixes that decide the order of a repeat's
-// copies in the suffix array begin behind the repeat whatever the seed's offset in it).  What survives is made dense by a select.
-// A duplicate that survives only costs a repeated extension.
+// the first `cap` rows of every range are located (the handle holds the full suffix array: the rows of a range are consecutive words)
+// and turned into diagonal keys.  Entries arrive SORTED by id: consecutive seeds of a read are neighbours, and a key equal to the key
+// the previous entry leaves at the same row t is dropped (the seeds of a read that lies in a repeat list the same loci, row for row,
+// because the suffixes that decide the order of a repeat's copies in the suffix array begin behind the repeat whatever the seed's offset
+// in it).  One lane per entry, two sweeps over its rows (count, then write: the second finds the SA words in L2), one returning atomic
+// per workgroup and 256 entries for the output offset.  A duplicate that survives only costs a repeated extension.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 residual_locate_kernel(const DevIndex f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids, const uint32_t n, const uint32_t cap,
-                       const DiagSpec ds, uint64_t* __restrict__ keys)
+                       const DiagSpec ds, uint64_t* __restrict__ keys, unsigned int* __restrict__ n_keys)
 {
-    const uint64_t total = (uint64_t)n * cap;
-    auto key_of = [&](const uint32_t e, const uint32_t t) -> uint64_t {
-        const uint2 r = ranges[e];
-        if (r.x > r.y || (uint64_t)r.x + t > r.y) return ~0ull;
-        const uint32_t sv  = f.ssa[r.x + t];
-        const uint32_t pos = (sv == 0xFFFFFFFFu) ? f.length : sv;
-        const uint32_t qv  = ids[e];
-        const uint32_t sid = qv & 0x7FFFFFFFu, str = (ds.strand ^ (qv >> 31)) & 1u;
-        const uint32_t rid = sid / ds.spr;
-        uint32_t       p   = (sid - rid * ds.spr) * (ds.intervals ? ds.intervals[rid] : ds.interval);
-        if (str) p = (ds.read_offsets ? ds.read_offsets[rid + 1] - ds.read_offsets[rid] : ds.read_len) - p - ds.seed_len;
-        return ((uint64_t)rid << 34) | ((uint64_t)str << 33) | ((uint64_t)pos + 1024u - p);
-    };
-    for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += (uint64_t)gridDim.x * blockDim.x)
+    __shared__ uint32_t s_wave[4], s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u)              // (block-uniform trip count)
     {
-        const uint32_t e = (uint32_t)(slot / cap), t = (uint32_t)(slot - (uint64_t)e * cap);
-        uint64_t k = key_of( e, t );
-        if (k != ~0ull && e > 0u && key_of( e - 1u, t ) == k) k = ~0ull;
-        keys[slot] = k;
+        const uint32_t e = base + threadIdx.x;
+        const bool have = e < n;
+        uint32_t x = 1u, rows = 0u, xp = 1u, rows_p = 0u; uint64_t hi = 0, hi_p = ~0ull; uint32_t p = 0, pp = 0;
+        auto describe = [&](const uint32_t ee, uint32_t& x0, uint32_t& nr, uint64_t& khi, uint32_t& off) {
+            const uint2 r = ranges[ee];
+            x0 = r.x; nr = r.x <= r.y ? (r.y - r.x + 1u < cap ? r.y - r.x + 1u : cap) : 0u;
+            const uint32_t qv  = ids[ee];
+            const uint32_t sid = qv & 0x7FFFFFFFu, str = (ds.strand ^ (qv >> 31)) & 1u;
+            const uint32_t rid = sid / ds.spr;
+            off = (sid - rid * ds.spr) * (ds.intervals ? ds.intervals[rid] : ds.interval);
+            if (str) off = (ds.read_offsets ? ds.read_offsets[rid + 1] - ds.read_offsets[rid] : ds.read_len) - off - ds.seed_len;
+            khi = ((uint64_t)rid << 34) | ((uint64_t)str << 33);
+        };
+        if (have) { describe( e, x, rows, hi, p ); if (e > 0u) describe( e - 1u, xp, rows_p, hi_p, pp ); }
+        const bool cmp = have && hi == hi_p;                                                 // the previous entry is a seed of the same read and strand
+        auto key_at = [&](const uint32_t x0, const uint32_t t, const uint64_t khi, const uint32_t off) -> uint64_t {
+            const uint32_t sv = f.ssa[x0 + t];
+            return khi | ((uint64_t)((sv == 0xFFFFFFFFu) ? f.length : sv) + 1024u - off);
+        };
+        uint32_t cnt = 0;
+        uint64_t kept = 0;                                                                    // bit t: row t's key is written (cap <= 64)
+        for (uint32_t t = 0; t < rows; ++t)
+        {
+            const uint64_t k = key_at( x, t, hi, p );
+            const bool dup = cmp && t < rows_p && key_at( xp, t, hi_p, pp ) == k;
+            if (!dup) { kept |= 1ull << t; ++cnt; }
+        }
+        uint32_t incl = cnt;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t a = (uint32_t)__shfl_up( (int)incl, d ); if (lane >= (uint32_t)d) incl += a; }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = tot ? atomicAdd( n_keys, tot ) : 0u;
+        }
+        __syncthreads();
+        uint32_t o = s_base + incl - cnt;
+        for (uint32_t w = 0; w < wave; ++w) o += s_wave[w];
+        for (uint32_t t = 0; t < rows; ++t)
+            if ((kept >> t) & 1ull) keys[o++] = key_at( x, t, hi, p );
+        __syncthreads();
     }
 }
-struct KeyIsSet { __host__ __device__ __forceinline__ bool operator()(const uint64_t k) const { return k != ~0ull; } };
+
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1933,15 +1961,12 @@ nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uin
         set_error( "nvbio_fm_residual_diagonals needs the full suffix array: build the index with sa_int = 1" );
         return NVBIO_ERR_UNSUPPORTED;
     }
-    // scratch: sorted ids | sorted ranges | padded keys | sort / select temp
+    // scratch: sorted ids | sorted ranges | sort temp
     const uint64_t ids_bytes = ((uint64_t)n * 4u + 255u) & ~255ull, rng_bytes = ((uint64_t)n * 8u + 255u) & ~255ull;
-    const uint64_t pad_bytes = ((uint64_t)n * cap * 8u + 255u) & ~255ull;
-    size_t sort_bytes = 0, sel_bytes = 0;
+    size_t sort_bytes = 0;
     NVB_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 32, s ) );
-    NVB_HIP( hipcub::DeviceSelect::If( nullptr, sel_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (int)(n * cap), KeyIsSet(), s ) );
-    const uint64_t tmp_bytes = ((uint64_t)(sort_bytes > sel_bytes ? sort_bytes : sel_bytes) + 255u) & ~255ull;
     uint8_t* aux = nullptr;
-    if (hipMallocAsync( (void**)&aux, ids_bytes + rng_bytes + pad_bytes + tmp_bytes + 256u, s ) != hipSuccess)
+    if (hipMallocAsync( (void**)&aux, ids_bytes + rng_bytes + sort_bytes + 256u, s ) != hipSuccess)
     {
         (void)hipGetLastError();
         set_error( "residual diagonals: out of device memory" );
@@ -1949,18 +1974,15 @@ nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uin
     }
     uint32_t* ids_s = (uint32_t*)aux;
     uint64_t* rng_s = (uint64_t*)(aux + ids_bytes);
-    uint64_t* padk  = (uint64_t*)(aux + ids_bytes + rng_bytes);
-    void*     tmp   = aux + ids_bytes + rng_bytes + pad_bytes;
-    size_t tb = tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs( tmp, tb, ids_dev, ids_s, (const uint64_t*)ranges_dev, rng_s, (int)n, 0, 32, s );
+    void*     tmp   = aux + ids_bytes + rng_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs( tmp, sort_bytes, ids_dev, ids_s, (const uint64_t*)ranges_dev, rng_s, (int)n, 0, 32, s );
     if (e == hipSuccess)
     {
         const DiagSpec ds = { seeds_per_read, seed_interval, seed_len, read_len, 0u, nullptr, read_offsets_dev, seed_intervals_dev };
-        hipLaunchKernelGGL( residual_locate_kernel, dim3( grid_for( (uint64_t)n * cap ) ), dim3(256), 0, s, idx->dev(), (const uint2*)rng_s, (const uint32_t*)ids_s, n, cap, ds, padk );
+        hipLaunchKernelGGL( residual_locate_kernel, dim3( grid_for( n ) ), dim3(256), 0, s, idx->dev(), (const uint2*)rng_s, (const uint32_t*)ids_s, n, cap, ds,
+                            keys_dev, (unsigned int*)n_keys_dev );
         e = hipGetLastError();
     }
-    tb = tmp_bytes;
-    if (e == hipSuccess) e = hipcub::DeviceSelect::If( tmp, tb, (const uint64_t*)padk, keys_dev, n_keys_dev, (int)(n * cap), KeyIsSet(), s );
     (void)hipFreeAsync( aux, s );
     if (e != hipSuccess) { set_error( "residual diagonals failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
