@@ -555,6 +555,35 @@ nvbio_status nvbio_score_reduce_effort(int device, const uint32_t* active_dev, c
                                        const nvbio_seed_hits_params* params, int32_t* best_dev, uint8_t* best_rc_dev, uint32_t* trys_dev,
                                        uint32_t* sizes_dev, void* stream);
 
+/* The several-hits-per-read form of the two calls above (select_multi_kernel, select_inl.h:268-437; score_reduce_kernel's loop over a read's
+ * hits, reduce_inl.h:94-134): once fewer than half a batch of reads are active nvBowtie takes up to n_multi = BATCH_SIZE / active SA rows per read
+ * and pass (aligner_best_approx.h:487-510).  A read's hits take CONSECUTIVE slots of the hit queue in selection order:
+ * hits_first_dev[s] / hits_count_dev[s] for the read in slot s of active_out_dev; counts_dev[0] = reads written, counts_dev[1] = hits written
+ * (<= n_active * n_multi).  The reduction runs the one-hit rule over every read's hits in that order with n_ext + i as the extension
+ * count of hit i (ReduceBestApproxContext::failure( idx, .. ), reduce.h:82-92). */
+nvbio_status nvbio_seed_hits_select_multi(int device, const uint32_t* active_in_dev, uint32_t n_active, const uint32_t* trys_dev, uint32_t capacity,
+                                          uint32_t n_multi, nvbio_uint2* deques_dev, uint32_t* sizes_dev, uint32_t* active_out_dev,
+                                          uint32_t* hits_first_dev, uint32_t* hits_count_dev, const nvbio_hit_queues* hits, uint32_t* counts_dev,
+                                          void* stream);
+nvbio_status nvbio_score_reduce_effort_multi(int device, const uint32_t* active_dev, uint32_t n_active, const uint32_t* hits_first_dev,
+                                             const uint32_t* hits_count_dev, const nvbio_hit_queues* hits, uint32_t read_len, uint32_t n_ext,
+                                             const nvbio_seed_hits_params* params, int32_t* best_dev, uint8_t* best_rc_dev, uint32_t* trys_dev,
+                                             uint32_t* sizes_dev, void* stream);
+
+/* The read queues of nvBowtie's best-approx loop as calls, so that a host loop over this ABI needs no device code of its own
+ * (aligner_best_approx.h:77,148-207,363-450):
+ *   nvbio_best_approx_init      best_dev[4 r ..] = { worst, -1, worst, -1 }, best_rc_dev[r] = 0: init_alignments( reads, threshold_score )
+ *   nvbio_read_queue_begin      for the n reads of queue_dev (NULL: reads 0..n-1), any of: seed_offsets_dev[t] = read * read_len + first_offset (the
+ *                               offsets of a seeding pass's seed set), active_dev[t] = read | top_seed << 31 (packed_read), trys_dev[read] =
+ *                               max_effort_init (select_init)
+ *   nvbio_read_queue_filter     queue_out_dev = the reads of queue_dev (NULL: 0..n-1) with read_flags_dev[read] != 0, in order (the reads that asked
+ *                               for reseeding go round again); *count_dev (device) = how many */
+nvbio_status nvbio_best_approx_init(int device, uint32_t n_reads, int32_t worst_score, int32_t* best_dev, uint8_t* best_rc_dev, void* stream);
+nvbio_status nvbio_read_queue_begin(int device, const uint32_t* queue_dev, uint32_t n, uint32_t read_len, uint32_t first_offset, uint32_t top_seed,
+                                    uint32_t max_effort_init, uint32_t* seed_offsets_dev, uint32_t* active_dev, uint32_t* trys_dev, void* stream);
+nvbio_status nvbio_read_queue_filter(int device, const uint32_t* queue_dev, uint32_t n, const uint8_t* read_flags_dev, uint32_t* queue_out_dev,
+                                     uint32_t* count_dev, void* stream);
+
 /* Two conversions a binding of sw-benchmark's stream needs (sw-benchmark/sw-benchmark.cu:70-209): its reference text is packed
  * 2-bit LITTLE-endian (REF_BIG_ENDIAN = false, :64-65; the library reads the big-endian layout of io::SequenceData<DNA>), and its
  * output() stores `sink.score` into an int16 array (:197). */

@@ -698,3 +698,60 @@ def nvbowtie_best_approx(fmi, genome2, genome_len, stored_reads, params, nvb=Non
     loc = lambda c: torch.where(b[:, c] == -1, b[:, c], b[:, c] & 0xFFFFFFFF)
     return dict(best_score=best[:, 0].clone(), best_loc=loc(1), best_rc=(best_rc & 1), second_score=best[:, 2].clone(), second_loc=loc(3),
                 second_rc=((best_rc >> 1) & 1), n_extensions=n_extensions, passes=passes)
+
+
+# ---- the same loop as a C++ host loop over the C ABI (host/nvbio_amd/best_approx.hpp behind lib/libnvbio_amd_host.so) --------------------------
+_HOST_LIB = None
+
+
+def _host_lib():
+    import ctypes
+    import os
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        from . import lib as _core
+        _core()                                                       # libnvbio_amd.so (and torch's HIP runtime) first
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnvbio_amd_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: build it with __graft_entry__.build()" % path)
+        L = ctypes.CDLL(path)
+        L.nvbio_host_last_error.restype = ctypes.c_char_p
+        _HOST_LIB = L
+    return _HOST_LIB
+
+
+def nvbowtie_best_approx_host(fmi, genome2, genome_len, stored_reads, params, nvb=None, batch_size=0, multi_hit=True):
+    """nvbowtie_best_approx as the C++ host loop (nvbio_host_best_approx): every data-parallel step behind the C ABI, the loop in C++, two
+    counters read per extension pass through pinned memory, queues allocated once -- and the reference's several-hits-per-read phase
+    (aligner_best_approx.h:487-510; batch_size = its BATCH_SIZE, 0 = the number of reads).  Same return value as nvbowtie_best_approx."""
+    import ctypes
+    import torch
+    from . import FMIndex, _ptr, _stream_ptr
+    nvb = nvb or NvBowtieParams()
+    dev = fmi.device
+    R, M = stored_reads.n, stored_reads.read_len
+
+    class _P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_uint32) for k in ("seed_len", "seed_freq", "max_hits", "rep_seeds", "max_effort", "max_effort_init", "min_ext", "max_ext",
+                                                  "max_reseed", "band", "top_seed", "batch_size", "multi_hit")]
+
+    class _S(ctypes.Structure):
+        _fields_ = [("n_extensions", ctypes.c_uint64), ("passes", ctypes.c_uint32), ("multi_passes", ctypes.c_uint32), ("seeding_passes", ctypes.c_uint32),
+                    ("pad", ctypes.c_uint32)]
+
+    p = _P(nvb.seed_len, nvb.seed_freq or params.interval_for(M), nvb.max_hits, nvb.rep_seeds, nvb.max_effort, nvb.max_effort_init, nvb.min_ext, nvb.max_ext,
+           nvb.max_reseed, nvb.band, nvb.top_seed, int(batch_size), 1 if multi_hit else 0)
+    st = _S()
+    best = torch.empty((R, 4), dtype=torch.int32, device=dev)
+    best_rc = torch.zeros(R, dtype=torch.uint8, device=dev)
+    rc = _host_lib().nvbio_host_best_approx(
+        ctypes.c_int(FMIndex._dev_index(dev)), fmi._h, _ptr(genome2), ctypes.c_uint32(genome_len), _ptr(stored_reads.reads4), _ptr(stored_reads.quals),
+        ctypes.c_uint32(R), ctypes.c_uint32(M), ctypes.c_int(int(params.aln_type)), ctypes.byref(params.scheme.c), ctypes.c_int32(params.min_score_for(M)),
+        ctypes.byref(p), _ptr(best), _ptr(best_rc), _stream_ptr(dev), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError(_host_lib().nvbio_host_last_error().decode())
+    b = best.to(torch.int64)
+    loc = lambda c: torch.where(b[:, c] == -1, b[:, c], b[:, c] & 0xFFFFFFFF)
+    return dict(best_score=best[:, 0].clone(), best_loc=loc(1), best_rc=(best_rc & 1), second_score=best[:, 2].clone(), second_loc=loc(3),
+                second_rc=((best_rc >> 1) & 1), n_extensions=int(st.n_extensions), passes=int(st.passes), multi_passes=int(st.multi_passes),
+                seeding_passes=int(st.seeding_passes))

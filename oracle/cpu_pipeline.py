@@ -326,6 +326,95 @@ def paired_end_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, min_score_
     return out
 
 
+
+def nvbowtie_best_approx_batch_cpu(O, hidx, text, genome_len, reads, scheme, aln_type, min_score, seed_len=22, seed_freq=None, max_hits=100,
+                                   rep_seeds=1000, max_effort=15, max_effort_init=15, min_ext=30, max_ext=400, max_reseed=2, band=31, top_seed=0,
+                                   batch_size=None, multi_hit=True):
+    """The same loop run as the reference runs it -- pass by pass over the whole batch -- with its several-hits-per-read phase
+    (aligner_best_approx.h:487-510: once at most BATCH_SIZE / 2 reads are active every read selects up to n = min( BATCH_SIZE / active,
+    min( 4096, max_ext - n_ext ) ) SA rows per pass, select_multi_kernel select_inl.h:268-437; score_reduce_kernel then walks a read's
+    hits in selection order with n_ext + i as hit i's extension count, reduce_inl.h:94-134, reduce.h:82-92; n_ext advances by n).
+    The number of hits a read selects in a pass depends on how many OTHER reads are still active, so this cannot be run read by read.
+    Test infrastructure; parity unpinned beyond the pieces that are pinned on their own."""
+    R, M = reads.shape
+    L = min(seed_len, M)
+    S = seed_freq or int(np.float32(1.0) + np.float32(1.15) * np.sqrt(np.float32(M)))
+    retry_stride = S // (max_reseed + 1)
+    max_effort_init = max(max_effort_init, max_effort); max_ext = max(max_ext, max_effort)
+    BATCH = batch_size or R
+    stored = reads[:, ::-1]
+    best = np.zeros((R, 6), dtype=np.int64)
+    best[:, 0] = min_score; best[:, 3] = min_score; best[:, 1] = 0xFFFFFFFF; best[:, 4] = 0xFFFFFFFF
+    n_extensions = passes = multi_passes = 0
+    queue = list(range(R))
+    for seeding_pass in range(max_reseed + 1):
+        if not queue:
+            break
+        first = seeding_pass * retry_stride
+        if M < L + first:
+            break
+        spr = (M - L - first) // S + 1
+        seed_off = first + np.arange(spr) * S
+        deques, trys, nxt = {}, {}, []
+        for r in queue:
+            seeds = np.concatenate([stored[r, o:o + L] for o in seed_off]).astype(np.uint8)
+            offs = (np.arange(spr + 1) * L).astype(np.uint32)
+            fw = O.match_batch(hidx, seeds, offs, reverse=True)
+            comp = np.where(seeds < 4, 3 - seeds, seeds).astype(np.uint8)
+            rc = O.match_batch(hidx, comp, offs)
+            deques[r], reseed = O.map_exact_read(fw, rc, seed_off, M, L, max_hits, rep_seeds)
+            trys[r] = max_effort_init
+            if reseed:
+                nxt.append(r)
+        active = [(r, top_seed) for r in queue]
+        n_ext = 0
+        while active and n_ext < max_ext:
+            n_multi = 1
+            if multi_hit and len(active) <= BATCH // 2:
+                n_multi = max(1, min(BATCH // len(active), min(4096, max_ext - n_ext)))
+            out = []
+            for r, top in active:
+                if trys[r] == 0 or len(deques[r]) == 0:
+                    if trys[r] != 0:
+                        deques[r] = deques[r][:0]
+                    continue
+                hits = []
+                for _ in range(n_multi):
+                    ok, row, seed, top, deques[r] = O.select_read(deques[r], top)
+                    if not ok:
+                        break
+                    hits.append((row, seed))
+                if hits:
+                    out.append((r, top, hits))
+            if not out:
+                break
+            for r, top, hits in out:
+                b = list(best[r]); erase_any = False
+                for idx, (row, seed) in enumerate(hits):
+                    pos = int(O.locate_batch(hidx, np.array([row], dtype=np.uint32))[0])
+                    g_pos = (pos - (seed & 0xFFF)) & 0xFFFFFFFF
+                    read_rc = (seed >> 13) & 1
+                    begin = g_pos - band // 2 if g_pos > band // 2 else 0
+                    end = min((begin + band + M) & 0xFFFFFFFF, genome_len)
+                    pat = (np.where(reads[r, ::-1] < 4, 3 - reads[r, ::-1], reads[r, ::-1]) if read_rc else reads[r]).astype(np.uint8)
+                    if end > begin:
+                        _, score, _ = O.banded_gotoh(band, aln_type, scheme, pat, text[begin:end])
+                    else:
+                        score = SCORE_MIN
+                    score = max(score, -65536)
+                    b, trys[r], erase = O.score_reduce_effort(b, trys[r], score, g_pos, read_rc, (seed >> 14) & 1, M, n_ext + idx, max_effort, min_ext, max_ext)
+                    erase_any = erase_any or erase
+                best[r] = b
+                if erase_any:
+                    deques[r] = deques[r][:0]
+                n_extensions += len(hits)
+            n_ext += n_multi; passes += 1; multi_passes += (n_multi > 1)
+            active = [(r, top) for r, top, _ in out]
+        queue = nxt
+    return dict(best_score=best[:, 0].astype(np.int32), best_loc=np.where(best[:, 1] == 0xFFFFFFFF, -1, best[:, 1]), best_rc=best[:, 2].astype(np.uint8),
+                second_score=best[:, 3].astype(np.int32), second_loc=np.where(best[:, 4] == 0xFFFFFFFF, -1, best[:, 4]),
+                second_rc=best[:, 5].astype(np.uint8), n_extensions=n_extensions, passes=passes, multi_passes=multi_passes)
+
 # ---- nvBowtie's scoring stream, restated (test infrastructure; parity unpinned: score_inl.h is device-only CUDA) ------------------
 def score_stream_flatten(idx_queue, hit_read_id, hit_seed, hit_loc, read_index, band_len, genome_len, reads_reversed=True):
     """BestScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:85-115) and the read orientation load_strings requests

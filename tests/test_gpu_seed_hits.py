@@ -104,6 +104,20 @@ def test_best_approx_loop_equals_the_oracle(amd, orc, mode):
     assert got["n_extensions"] == want["n_extensions"]
     aligned = got["best_loc"].cpu().numpy() >= 0
     assert aligned[:-15].mean() > 0.97 and not aligned[-15:].any()
+    # the same loop as the C++ host loop over the C ABI (lib/libnvbio_amd_host.so), one hit per read and pass: identical
+    host = pipeline.nvbowtie_best_approx_host(fmi, g_dev, G, rb, params, pipeline.NvBowtieParams(**kw), multi_hit=False)
+    for k in ("best_score", "best_loc", "best_rc", "second_score", "second_loc", "second_rc"):
+        assert np.array_equal(host[k].cpu().numpy().astype(np.int64), want[k].astype(np.int64)), (mode, k, "host")
+    assert host["n_extensions"] == want["n_extensions"] and host["multi_passes"] == 0
+    # ... and with the reference's several-hits-per-read phase (active reads <= BATCH_SIZE / 2: n = BATCH_SIZE / active hits per read and pass),
+    # against the oracle's pass-by-pass restatement; two batch sizes, so that the phase starts at different points of the loop
+    for bs in (0, 3 * R):
+        wantb = cpu_pipeline.nvbowtie_best_approx_batch_cpu(orc, hidx, text, G, reads, osc, oracle.SEMI_GLOBAL, params.min_score_for(M), batch_size=bs or None, **kw)
+        hostb = pipeline.nvbowtie_best_approx_host(fmi, g_dev, G, rb, params, pipeline.NvBowtieParams(**kw), batch_size=bs, multi_hit=True)
+        for k in ("best_score", "best_loc", "best_rc", "second_score", "second_loc", "second_rc"):
+            assert np.array_equal(hostb[k].cpu().numpy().astype(np.int64), wantb[k].astype(np.int64)), (mode, k, "multi", bs)
+        assert hostb["n_extensions"] == wantb["n_extensions"] and hostb["passes"] == wantb["passes"] and hostb["multi_passes"] == wantb["multi_passes"]
+        assert hostb["multi_passes"] > 0
     fmi.close()
 
 
