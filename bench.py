@@ -375,6 +375,8 @@ def main():
                     help="do not enqueue the next step's seed pass ahead of this step's extension (the host then waits for the seed pass's counts with the GPU idle)")
     ap.add_argument("--no-defer-heavy", action="store_true", help="the searches the canonical table cannot answer run inside the seed pass instead of as a dense launch behind it")
     ap.add_argument("--no-sweep", action="store_true", help="skip the (untimed) 1-GPU sweep of the step over R/8 .. R reads")
+    ap.add_argument("--no-nvbowtie-mode", action="store_true", help="skip the (untimed) run of nvBowtie's own selection / effort loop (C++ host loop over the C ABI)")
+    ap.add_argument("--no-cpp-host", action="store_true", help="skip the run of the same step through the C++ host program (lib/fmmap_amd) on the same reads")
     ap.add_argument("--no-configs", action="store_true", help="skip the (untimed) kernel-level runs of BASELINE configs 2, 4 and 5")
     ap.add_argument("--no-robust", action="store_true", help="skip the robust-input step (repeat family + per-base qualities + ragged reads: rebuilds the index)")
     ap.add_argument("--robust-copies", type=int, default=10000, help="copies of the 300 bp element planted for the robust-input step")
@@ -857,16 +859,76 @@ def main():
         except Exception as e:                                     # an extra must not take the line down
             result["configs"] = {"error": repr(e)}
 
+    # ---- nvBowtie's own choices (which loci get extended, in which order, when a read gives up) as the C++ host loop over the C ABI, on the
+    #      same 10 M reads: seed-hit deques capped at max_hits, select -> locate -> BestScoreStream -> band-31 DP -> score_reduce with the effort
+    #      rules, the several-hits-per-read phase once fewer than half the batch is active, reseeding (aligner_best_approx.h:39-207,363-667) ----
+    if rank == 0 and world == 1 and not args.no_nvbowtie_mode:
+        try:
+            stored4 = pack4(reads_sym.flip(1).reshape(-1))                       # nvBowtie stores reads reversed (io::REVERSE)
+            sb = pipeline.ReadBatch(stored4, R, M)
+            pipeline.nvbowtie_best_approx_host(fmi, genome, n, pipeline.ReadBatch(stored4[:(min(R, 100000) * M + 7) // 8 + 4], min(R, 100000), M), params)   # warm
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nb = pipeline.nvbowtie_best_approx_host(fmi, genome, n, sb, params)
+            torch.cuda.synchronize(); ndt = time.perf_counter() - t0
+            nb_al = nb["best_loc"] >= 0
+            both_al = nb_al & aligned
+            result["nvbowtie_mode"] = {
+                "host": "C++ loop over the C ABI (nvbio-gpl_amd/host/nvbio_amd/best_approx.hpp -> lib/libnvbio_amd_host.so); two counters read per extension pass",
+                "reads": R, "ms_per_step": ndt * 1e3, "reads_per_s": R / ndt, "n_extensions": nb["n_extensions"], "extensions_per_read": nb["n_extensions"] / float(R),
+                "extension_passes": nb["passes"], "passes_with_several_hits_per_read": nb["multi_passes"], "seeding_passes": nb["seeding_passes"],
+                "aligned_fraction": float(nb_al.float().mean()),
+                "aligned_by_both": float(both_al.float().mean()),
+                "best_score_equals_default_pipeline": float(((nb["best_score"] == bs) & both_al).float().sum() / both_al.float().sum().clamp(min=1)),
+                "best_score_below_default_pipeline": float(((nb["best_score"] < bs) & both_al).float().sum() / both_al.float().sum().clamp(min=1)),
+                "best_score_above_default_pipeline": float(((nb["best_score"] > bs) & both_al).float().sum() / both_al.float().sum().clamp(min=1)),
+                "note": "the default pipeline extends every distinct diagonal once; this mode extends hit by hit as nvBowtie does and stops on its effort rules, so a read can end below the default pipeline's score, never above"}
+            del stored4, sb, nb
+        except Exception as e:
+            result["nvbowtie_mode"] = {"error": repr(e)}
+
     # ---- the robust-input step (rank 0, one GPU): needs the headline's handle gone ----
     if rank == 0 and world == 1 and not args.no_robust and use_both:
+        cpp_inputs = None
         try:
+            if not args.no_cpp_host and not args.repeat_family:
+                # the batch and the reference as files for the C++ host program (it builds its own index: the handle must go first)
+                import tempfile
+                tmpd = tempfile.mkdtemp(prefix="nvbio_bench_")
+                amd.u32(genome).tofile(os.path.join(tmpd, "genome.u32"))
+                amd.u32(reads4).tofile(os.path.join(tmpd, "reads.u32"))
+                cpp_inputs = (tmpd, bs.cpu().numpy(), bp.cpu().numpy(), brc.cpu().numpy())
             del batch, reads4, reads_sym, truth_pos, truth_rc, extras
             fmi.close()
             del fmi
             torch.cuda.empty_cache()
-            result["robust"] = run_robust(torch, np, amd, pipeline, args, genome, n, R, M, device, rank, step_ms)
         except Exception as e:
             result["robust"] = {"error": repr(e)}
+        if cpp_inputs is not None:
+            # the same step, same reads, as a plain C++ program over the C ABI (no Python, no torch): nvbio-gpl_amd/host/fmmap_amd.cpp
+            try:
+                import shutil
+                import subprocess
+                tmpd, hbs, hbp, hbrc = cpp_inputs
+                exe = os.path.join(ROOT, "nvbio-gpl_amd", "lib", "fmmap_amd")
+                outp = os.path.join(tmpd, "best.bin")
+                pr = subprocess.run([exe, "--genome", os.path.join(tmpd, "genome.u32"), "--genome-len", str(n), "--reads", os.path.join(tmpd, "reads.u32"),
+                                     "--n-reads", str(R), "--read-len", str(M), "--steps", "5", "--kmer", str(args.kmer), "--out", outp]
+                                    + (["--no-canonical"] if not use_both else []), capture_output=True, text=True, timeout=600)
+                cj = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+                raw = np.fromfile(outp, dtype=np.uint8)
+                cs_ = raw[:4 * R].view(np.int32); cp_ = raw[4 * R:12 * R].view(np.int64); cr_ = raw[12 * R:13 * R]
+                cj["results_equal_python_step"] = bool(np.array_equal(cs_, hbs) and np.array_equal(cp_, hbp) and np.array_equal(cr_, hbrc))
+                cj["note"] = ("the timed step's composition without second best / MAPQ, host side in C++ (hipDeviceSynchronize at both ends of every step, "
+                              "no step pipelining); same reads, same reference, its own index build")
+                result["cpp_host"] = cj
+                shutil.rmtree(tmpd, ignore_errors=True)
+            except Exception as e:
+                result["cpp_host"] = {"error": repr(e)}
+        if "robust" not in result:
+            try:
+                result["robust"] = run_robust(torch, np, amd, pipeline, args, genome, n, R, M, device, rank, step_ms)
+            except Exception as e:
+                result["robust"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -60,8 +60,16 @@ def test_bench_json_contract(extra):
     assert cf["fm_seeds_1M"]["queries_per_s"] > 0 and 0.0 < cf["fm_seeds_1M"]["no_table"]["alg_frac_of_hbm_peak"] <= 1.0
     assert cf["banded_local_6.25M"]["gcups"] > 0 and 0.0 < cf["banded_local_6.25M"]["dp_issue_frac"] <= 1.0
     assert cf["paired_end_1M"]["pairs_per_s"] > 0 and cf["paired_end_1M"]["concordant_fraction"] > 0.9
+    nm = d["nvbowtie_mode"]
+    assert "error" not in nm, nm
+    assert nm["ms_per_step"] > 0 and nm["n_extensions"] >= 40000 * 0.9 and nm["aligned_fraction"] > 0.97 and nm["best_score_equals_default_pipeline"] > 0.97
+    sw = d["strong_scaling_sweep_1gpu"]
+    assert [e["reads"] for e in sw] == [5000, 10000, 20000, 40000] and all(e["ms_per_step"] > 0 for e in sw)
     # the robust-input step (repeat family + per-base qualities + ragged reads) over the canonical table, checked against the plain operators
     if canon:
+        ch = d["cpp_host"]
+        assert "error" not in ch, ch
+        assert ch["ms_per_step"] > 0 and ch["results_equal_python_step"] is True
         rb = d["robust"]
         assert "error" not in rb, rb
         assert rb["ms_per_step"] > 0 and rb["plain_operators"]["results_equal"] is True and rb["aligned_fraction"] > 0.97
