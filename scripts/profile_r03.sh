@@ -16,26 +16,32 @@ run() {   # name, args..., then -- counters
   echo "$name rc $rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit $rc; fi
 }
-FULL="--steps 3 --warmup 1 --no-cpu-baseline --no-configs"
-FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-robust --no-plain-ab --no-traceback"
+FULL="--steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-sweep --no-nvbowtie-mode --no-cpp-host"
+FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-sweep --no-nvbowtie-mode --no-robust --no-plain-ab --no-traceback"
 run stats --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $REPO/bench.py $FULL
 run rdreq --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $OUT/${TAG}_rdreq -- python3 $REPO/bench.py $FAST
 run fetch --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $REPO/bench.py $FAST
 run write --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $FAST
 run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/${TAG}_sq -- python3 $REPO/bench.py $FAST
+run wrreq --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/${TAG}_wrreq -- python3 $REPO/bench.py $FAST
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_tcc -- python3 $REPO/bench.py $FAST
 # keep the summaries small: per-kernel means of every counter, the stats csv
 python3 - $OUT $TAG <<'PY'
 import csv, glob, json, os, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
-for name in ("rdreq", "fetch", "write", "sq", "tcc"):
+for name in ("rdreq", "fetch", "write", "wrreq", "sq", "tcc"):
     fs = glob.glob(os.path.join(out, "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True)
     if not fs:
         continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    # a dispatch can report one counter in several rows (one per XCD / dimension instance): sum them per dispatch, then average over dispatches
+    per = collections.defaultdict(float); name_of = {}
     for row in csv.DictReader(open(fs[0])):
-        agg[row["Kernel_Name"][:140]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        key = (row["Dispatch_Id"], row["Counter_Name"])
+        per[key] += float(row["Counter_Value"]); name_of[row["Dispatch_Id"]] = row["Kernel_Name"][:140]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (did, c), v in per.items():
+        agg[name_of[did]][c].append(v)
     for k, d in agg.items():
         for c, v in d.items():
             res.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "launches": len(v)}
@@ -47,5 +53,5 @@ if fs:
 print("summaries written")
 PY
 # the raw per-dispatch csv files are large: drop them, keep the summaries
-rm -rf $OUT/${TAG}_rdreq $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq $OUT/${TAG}_tcc $OUT/${TAG}_stats
+rm -rf $OUT/${TAG}_wrreq $OUT/${TAG}_rdreq $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq $OUT/${TAG}_tcc $OUT/${TAG}_stats
 ls -la $OUT | tail -20
