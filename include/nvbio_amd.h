@@ -584,6 +584,53 @@ nvbio_status nvbio_read_queue_begin(int device, const uint32_t* queue_dev, uint3
 nvbio_status nvbio_read_queue_filter(int device, const uint32_t* queue_dev, uint32_t n, const uint8_t* read_flags_dev, uint32_t* queue_out_dev,
                                      uint32_t* count_dev, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * nvBowtie's PAIRED-END best-approx loop, its data-parallel steps (aligner_best_approx_paired.h:84-200,590-1000): the anchor mate's seed hits
+ * are walked as in the single-end loop (deques, select, locate: the calls above); a selected hit's anchor is band-aligned against a
+ * threshold derived from the best PAIRS found so far (BestAnchorScoreStream, score_inl.h:143-274; compute_target_score,
+ * alignment_utils.h:93-102), the hits whose anchor passes get the opposite mate aligned by full-matrix DP in the window the fragment
+ * constraints allow (BestOppositeScoreStream, score_inl.h:283-456) and score_reduce_paired_kernel keeps the best two pairs, or the best two
+ * alignments of each mate while no pair has been found (reduce_inl.h:157-290).
+ * An alignment is 4 int32: { score, position (-1 = none), sink offset, rc | mate << 1 | paired << 2 } (io::Alignment, alignments.h:71-117);
+ * best_a_dev / best_o_dev hold two per read pair each (pipeline.best_alignments / best_alignments_o).  Reads of both mates are stored reversed.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct
+{
+    uint32_t anchor;                              /* 0: mate 1 is the anchor of this pass over the batch, 1: mate 2          */
+    uint32_t anchor_len, opposite_len;            /* read lengths (uniform)                                                   */
+    int32_t  anchor_perfect_score, opposite_perfect_score;   /* scheme.perfect_score( len ) = match * len                    */
+    int32_t  anchor_min_score, opposite_min_score;           /* scheme.min_score( len )                                      */
+    int32_t  score_limit;                         /* scheme.score_limit(): NVBIO_SCORE_MIN for the Smith-Waterman scheme     */
+    int32_t  worst_score;                         /* scheme_type::worst_score = -65536                                       */
+    int32_t  match, txt_gap_open, txt_gap_ext;    /* for aln::max_text_gaps (utils_inl.h:145-167)                            */
+    uint32_t band, genome_len;
+    uint32_t policy, min_frag_len, max_frag_len, overlap, unpaired;   /* NVBIO_PE_POLICY_*, minins, maxins, pe_overlap, pe_unpaired */
+    uint32_t max_effort, min_ext, max_ext;
+} nvbio_pe_params;
+nvbio_status nvbio_pe_init(int device, uint32_t n_reads, int32_t worst_score_mate1, int32_t worst_score_mate2, int32_t* best_a_dev, int32_t* best_o_dev, void* stream);
+/* per selected hit: the anchor's banded window + orientation + its min_score (INT32_MAX for a locus already held, whose window is empty) */
+nvbio_status nvbio_pe_anchor_flatten(int device, const nvbio_pe_params* params, const nvbio_hit_queues* hits, const int32_t* best_a_dev, const int32_t* best_o_dev,
+                                     uint32_t* read_id_dev, uint8_t* flags_dev, uint32_t* win_begin_dev, uint32_t* win_end_dev, int32_t* min_scores_dev,
+                                     void* stream);
+/* hit.score = score >= min_score ? score : worst_score, hit.sink; hit_opposite_score_dev[i] = worst_score; valid_dev[i] = the anchor passed */
+nvbio_status nvbio_pe_anchor_output(int device, const nvbio_pe_params* params, const nvbio_hit_queues* hits, const int32_t* scores_dev, const nvbio_uint2* sinks_dev,
+                                    const uint32_t* win_begin_dev, const int32_t* min_scores_dev, int32_t* hit_opposite_score_dev, uint8_t* valid_dev,
+                                    void* stream);
+/* for the hits queue_dev[0..n) whose anchor passed: the opposite mate's window, orientation and min_score (the empty window where it cannot run) */
+nvbio_status nvbio_pe_opposite_flatten(int device, const nvbio_pe_params* params, const uint32_t* queue_dev, uint32_t n, const nvbio_hit_queues* hits,
+                                       const int32_t* best_a_dev, const int32_t* best_o_dev, uint32_t* read_id_dev, uint8_t* flags_dev,
+                                       uint32_t* win_begin_dev, uint32_t* win_end_dev, int32_t* min_scores_dev, void* stream);
+nvbio_status nvbio_pe_opposite_output(int device, const nvbio_pe_params* params, const uint32_t* queue_dev, uint32_t n, const int32_t* scores_dev,
+                                      const nvbio_uint2* sinks_dev, const uint32_t* win_begin_dev, const uint32_t* win_end_dev, const int32_t* min_scores_dev,
+                                      int32_t* hit_opposite_score_dev, uint32_t* hit_opposite_loc_dev, uint32_t* hit_opposite_sink_dev, void* stream);
+/* score_reduce_paired_kernel over every active read's hits (hits_first / hits_count as nvbio_score_reduce_effort_multi) */
+nvbio_status nvbio_pe_score_reduce(int device, const nvbio_pe_params* params, const uint32_t* active_dev, uint32_t n_active, const uint32_t* hits_first_dev,
+                                   const uint32_t* hits_count_dev, const nvbio_hit_queues* hits, const int32_t* hit_opposite_score_dev,
+                                   const uint32_t* hit_opposite_loc_dev, const uint32_t* hit_opposite_sink_dev, uint32_t n_ext, int32_t* best_a_dev,
+                                   int32_t* best_o_dev, uint32_t* trys_dev, uint32_t* sizes_dev, void* stream);
+/* queue_out_dev = the indices i in [0, n) with flags_dev[i] != 0, in order; *count_dev (device) = how many */
+nvbio_status nvbio_select_flagged_indices(int device, const uint8_t* flags_dev, uint32_t n, uint32_t* queue_out_dev, uint32_t* count_dev, void* stream);
+
 /* Two conversions a binding of sw-benchmark's stream needs (sw-benchmark/sw-benchmark.cu:70-209): its reference text is packed
  * 2-bit LITTLE-endian (REF_BIG_ENDIAN = false, :64-65; the library reads the big-endian layout of io::SequenceData<DNA>), and its
  * output() stores `sink.score` into an int16 array (:197). */

@@ -460,4 +460,23 @@ nvbio_status nvbio_read_queue_filter(int device, const uint32_t* queue_dev, uint
     return NVBIO_OK;
 }
 
+nvbio_status nvbio_select_flagged_indices(int device, const uint8_t* flags_dev, uint32_t n, uint32_t* queue_out_dev, uint32_t* count_dev, void* stream)
+{
+    NVB_REQUIRE( count_dev != nullptr, "count_dev is NULL" );
+    DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    NVB_HIP( hipMemsetAsync( count_dev, 0, sizeof(uint32_t), s ) );
+    if (n == 0) return NVBIO_OK;
+    NVB_REQUIRE( flags_dev && queue_out_dev, "NULL device pointer" );
+    NVB_REQUIRE( n < (1u << 31), "n too large" );
+    size_t bytes = 0; void* tmp = nullptr;
+    hipcub::CountingInputIterator<uint32_t> ids( 0u );
+    NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, bytes, ids, flags_dev, queue_out_dev, count_dev, (int)n, s ) );
+    if (hipMallocAsync( &tmp, bytes ? bytes : 16, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "select_flagged_indices: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    const hipError_t e = hipcub::DeviceSelect::Flagged( tmp, bytes, ids, flags_dev, queue_out_dev, count_dev, (int)n, s );
+    (void)hipFreeAsync( tmp, s );
+    if (e != hipSuccess) { set_error( "select_flagged_indices failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    return NVBIO_OK;
+}
+
 } // extern "C"
