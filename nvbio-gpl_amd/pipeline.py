@@ -755,3 +755,46 @@ def nvbowtie_best_approx_host(fmi, genome2, genome_len, stored_reads, params, nv
     return dict(best_score=best[:, 0].clone(), best_loc=loc(1), best_rc=(best_rc & 1), second_score=best[:, 2].clone(), second_loc=loc(3),
                 second_rc=((best_rc >> 1) & 1), n_extensions=int(st.n_extensions), passes=int(st.passes), multi_passes=int(st.multi_passes),
                 seeding_passes=int(st.seeding_passes))
+
+
+def nvbowtie_best_approx_paired_host(fmi, genome2, genome_len, stored_mates1, stored_mates2, params, nvb=None, pe=None, unpaired=True, batch_size=0, multi_hit=True):
+    """nvBowtie's PAIRED-END best-approx loop (Aligner::best_approx, aligner_best_approx_paired.h:84-200,590-1000) as the C++ host loop
+    nvbio_host_best_approx_paired: for anchor = mate 1, then mate 2, the single-end loop over the anchor's seed hits with every selected hit scored as
+    a pair -- the anchor against a threshold that tightens with the pairs found so far (compute_target_score), the opposite mate by full-matrix DP in
+    its fragment window for the hits whose anchor passed, score_reduce_paired keeping the best two pairs (or per-mate bests while unpaired).
+    -> dict( best_a, best_o [R, 2, 4] int32 = { score, position, sink offset, rc | mate << 1 | paired << 2 } x { best, second }, counters )."""
+    import ctypes
+    import torch
+    from . import FMIndex, _ptr, _stream_ptr
+    nvb = nvb or NvBowtieParams()
+    pe = pe or PairedEndParams()
+    dev = fmi.device
+    R, M1, M2 = stored_mates1.n, stored_mates1.read_len, stored_mates2.read_len
+    if stored_mates2.n != R:
+        raise ValueError("the two mate batches must hold the same number of reads")
+
+    class _P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_uint32) for k in ("seed_len", "seed_freq", "max_hits", "rep_seeds", "max_effort", "max_effort_init", "min_ext", "max_ext",
+                                                  "max_reseed", "band", "top_seed", "batch_size", "multi_hit")]
+
+    class _PE(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_uint32) for k in ("policy", "min_frag_len", "max_frag_len", "overlap", "unpaired")]
+
+    class _S(ctypes.Structure):
+        _fields_ = [("n_extensions", ctypes.c_uint64), ("n_opposite", ctypes.c_uint64), ("passes", ctypes.c_uint32), ("multi_passes", ctypes.c_uint32)]
+
+    p = _P(nvb.seed_len, nvb.seed_freq or 0, nvb.max_hits, nvb.rep_seeds, nvb.max_effort, nvb.max_effort_init, nvb.min_ext, nvb.max_ext, nvb.max_reseed, nvb.band,
+           nvb.top_seed, int(batch_size), 1 if multi_hit else 0)
+    q = _PE(int(pe.policy), int(pe.min_frag_len), int(pe.max_frag_len), 1 if pe.overlap else 0, 1 if unpaired else 0)
+    st = _S()
+    best_a = torch.empty((R, 2, 4), dtype=torch.int32, device=dev)
+    best_o = torch.empty((R, 2, 4), dtype=torch.int32, device=dev)
+    rc = _host_lib().nvbio_host_best_approx_paired(
+        ctypes.c_int(FMIndex._dev_index(dev)), fmi._h, _ptr(genome2), ctypes.c_uint32(genome_len), _ptr(stored_mates1.reads4), _ptr(stored_mates2.reads4),
+        _ptr(stored_mates1.quals), _ptr(stored_mates2.quals), ctypes.c_uint32(R), ctypes.c_uint32(M1), ctypes.c_uint32(M2), ctypes.c_int(int(params.aln_type)),
+        ctypes.byref(params.scheme.c), ctypes.c_int32(params.min_score_for(M1)), ctypes.c_int32(params.min_score_for(M2)), ctypes.byref(p), ctypes.byref(q),
+        _ptr(best_a), _ptr(best_o), _stream_ptr(dev), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError(_host_lib().nvbio_host_last_error().decode())
+    return dict(best_a=best_a, best_o=best_o, n_extensions=int(st.n_extensions), n_opposite=int(st.n_opposite), passes=int(st.passes),
+                multi_passes=int(st.multi_passes))

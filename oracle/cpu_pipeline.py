@@ -415,6 +415,237 @@ def nvbowtie_best_approx_batch_cpu(O, hidx, text, genome_len, reads, scheme, aln
                 second_score=best[:, 3].astype(np.int32), second_loc=np.where(best[:, 4] == 0xFFFFFFFF, -1, best[:, 4]),
                 second_rc=best[:, 5].astype(np.uint8), n_extensions=n_extensions, passes=passes, multi_passes=multi_passes)
 
+
+def nvbowtie_best_approx_paired_cpu(O, hidx, text, genome_len, mates1, mates2, scheme, aln_type, min_score_of, seed_len=22, seed_freq=None, max_hits=100,
+                                    rep_seeds=1000, max_effort=15, max_effort_init=15, min_ext=30, max_ext=400, max_reseed=2, band=31, top_seed=0,
+                                    batch_size=None, multi_hit=True, policy=1, min_frag=0, max_frag=500, overlap=True, unpaired=True):
+    """nvBowtie's PAIRED-END best-approx loop (Aligner::best_approx, aligner_best_approx_paired.h:84-200,590-1000), pass by pass over the batch:
+    for anchor = mate 1, then mate 2, the single-end loop over the anchor's seed hits, a selected hit scored as a pair --
+    BestAnchorScoreStream (score_inl.h:143-274): the anchor band-aligned against max( target_pair - perfect( opposite ), min_score( anchor ) ) + 1,
+    target_pair = compute_target_score (alignment_utils.h:93-102: the sum of the two min scores until a second pair exists, then
+    second + 3/4 (best - second)); BestOppositeScoreStream (score_inl.h:283-456): full-matrix DP of the other mate in its fragment window for the
+    hits whose anchor passed; score_reduce_paired_kernel (reduce_inl.h:157-290) with the effort context -- including what the reference's
+    code does rather than intends: init_alignments passes `mate` where io::Alignment takes `rc`; the unpaired update writes memory but not the
+    kernel's local copy.  Not reproduced: BestAnchorScoreStream::init_context's read of context->min_score before it is assigned (taken as false).
+    Alignment = [score, pos, sink, rc, mate, paired].  Test infrastructure; parity unpinned (device-only sources)."""
+    R = len(mates1)
+    reads = (mates1, mates2)
+    lens = (mates1.shape[1], mates2.shape[1])
+    worst = (min_score_of(lens[0]), min_score_of(lens[1]))
+    BATCH = batch_size or R
+    max_effort_init = max(max_effort_init, max_effort); max_ext = max(max_ext, max_effort)
+    NONE = 0xFFFFFFFF
+    best_a = [[[worst[0], NONE, 255, 0, 0, 0], [worst[0], NONE, 255, 0, 0, 0]] for _ in range(R)]
+    best_o = [[[worst[1], NONE, 255, 1, 0, 0], [worst[1], NONE, 255, 1, 0, 0]] for _ in range(R)]
+
+    def paired(a): return a[5] == 1 and a[1] != NONE
+    def best_score(b): return b[0][0] + (b[2][0] if paired(b[0]) else 0)
+    def second_score(b): return b[1][0] + (b[3][0] if paired(b[1]) else 0)
+
+    def target_score(b, aw, ow):
+        if not paired(b[1]):
+            return aw + ow
+        delta = best_score(b) - second_score(b)
+        return second_score(b) + int(delta * 3 / 4) if delta * 3 >= 0 else second_score(b) - ((-delta * 3) // 4)      # C division truncates toward zero
+
+    def visited(b, mate, rc, g):
+        return any(mate == x[4] and rc == x[3] and g == x[1] for x in b)
+
+    def frame(anchor, anchor_fw):
+        a1 = anchor == 0
+        if policy == 0: return (a1 != anchor_fw), anchor_fw
+        if policy == 3: return (a1 == anchor_fw), anchor_fw
+        if policy == 1: return (not anchor_fw), (not anchor_fw)
+        return anchor_fw, (not anchor_fw)
+
+    def oriented(read, rc):
+        return (np.where(read[::-1] < 4, 3 - read[::-1], read[::-1]) if rc else read).astype(np.uint8)
+
+    def pair_mate(a, o, m): return a if m == a[4] else o
+
+    def pairs_distinct(a1, o1, a2, o2, dist=None):
+        p10, p11, p20, p21 = pair_mate(a1, o1, 0), pair_mate(a1, o1, 1), pair_mate(a2, o2, 0), pair_mate(a2, o2, 1)
+        u = lambda v: v & 0xFFFFFFFF
+        ap1, op1, ap2, op2 = u(p10[1] + p10[2]), u(p11[1] + p11[2]), u(p20[1] + p20[2]), u(p21[1] + p21[2])
+        if dist is None:
+            return p10[3] != p20[3] or p11[3] != p21[3] or ap1 != ap2 or op1 != op2
+        if p10[3] != p20[3] or p11[3] != p21[3]:
+            return True
+        near = lambda x, y: x >= y - min(y, dist) and x <= y + dist
+        return not (near(ap1, ap2) and near(op1, op2))
+
+    def distinct(pos1, rc1, pos2, rc2, dist):
+        return True if rc1 != rc2 else not (pos1 >= pos2 - min(pos2, dist) and pos1 <= pos2 + dist)
+
+    n_extensions = n_opposite = passes = 0
+    for anchor in (0, 1):
+        a_reads, o_reads = reads[anchor], reads[1 - anchor]
+        M, Mo = lens[anchor], lens[1 - anchor]
+        a_worst, o_worst = worst[anchor], worst[1 - anchor]
+        a_opt, o_opt = scheme.match * M, scheme.match * Mo
+        L = min(seed_len, M)
+        S = seed_freq or int(np.float32(1.0) + np.float32(1.15) * np.sqrt(np.float32(M)))
+        retry_stride = S // (max_reseed + 1)
+        stored = a_reads[:, ::-1]
+        queue = list(range(R))
+        for seeding_pass in range(max_reseed + 1):
+            if not queue:
+                break
+            first = seeding_pass * retry_stride
+            if M < L + first:
+                break
+            spr = (M - L - first) // S + 1
+            seed_off = first + np.arange(spr) * S
+            deques, trys, nxt = {}, {}, []
+            for r in queue:
+                seeds = np.concatenate([stored[r, o:o + L] for o in seed_off]).astype(np.uint8)
+                offs = (np.arange(spr + 1) * L).astype(np.uint32)
+                fw = O.match_batch(hidx, seeds, offs, reverse=True)
+                comp = np.where(seeds < 4, 3 - seeds, seeds).astype(np.uint8)
+                rc = O.match_batch(hidx, comp, offs)
+                deques[r], reseed = O.map_exact_read(fw, rc, seed_off, M, L, max_hits, rep_seeds)
+                trys[r] = max_effort_init
+                if reseed:
+                    nxt.append(r)
+            active = [(r, top_seed) for r in queue]
+            n_ext = 0
+            while active and n_ext < max_ext:
+                n_multi = 1
+                if multi_hit and len(active) <= BATCH // 2:
+                    n_multi = max(1, min(BATCH // len(active), min(4096, max_ext - n_ext)))
+                out = []
+                for r, top in active:
+                    if trys[r] == 0 or len(deques[r]) == 0:
+                        continue
+                    hits = []
+                    for _ in range(n_multi):
+                        ok, row, seed, top, deques[r] = O.select_read(deques[r], top)
+                        if not ok:
+                            break
+                        hits.append((row, seed))
+                    if hits:
+                        out.append((r, top, hits))
+                if not out:
+                    break
+                # score every selected hit against the state BEFORE this pass's reduction (the streams run before score_reduce)
+                scored = []
+                for r, top, hits in out:
+                    bb = [best_a[r][0], best_a[r][1], best_o[r][0], best_o[r][1]]          # [a1, a2, o1, o2]
+                    rows = []
+                    for row, seed in hits:
+                        pos = int(O.locate_batch(hidx, np.array([row], dtype=np.uint32))[0])
+                        g = (pos - (seed & 0xFFF)) & 0xFFFFFFFF
+                        rc = (seed >> 13) & 1
+                        tp = target_score(bb, a_worst, o_worst)
+                        tm = max(tp - o_opt, a_worst)
+                        skip = visited(bb, anchor, rc, g)
+                        begin = g - band // 2 if g > band // 2 else 0
+                        end = min((begin + band + M) & 0xFFFFFFFF, genome_len)
+                        ms = max(tm + 1, SCORE_MIN)
+                        s1, sink1 = SCORE_MIN, 0xFFFFFFFF
+                        if not skip and begin < genome_len and end >= begin and end > begin:
+                            _, s1, k1 = O.banded_gotoh(band, aln_type, scheme, oriented(a_reads[r], rc), text[begin:end])
+                            sink1 = k1[0]
+                        passed = (not skip) and s1 >= ms
+                        hit_score = s1 if passed else -65536
+                        hit_sink = (begin + sink1) & 0xFFFFFFFF if not (skip or begin >= genome_len or end < begin) else 0xFFFFFFFF
+                        o_score, o_loc, o_sink = -65536, 0, 0
+                        if passed and hit_score != -65536:
+                            n_opposite += 1
+                            tm2 = max(tp - hit_score, o_worst)
+                            ms2 = max(tm2 + 1, SCORE_MIN)
+                            run = not (ms2 > o_opt)
+                            o_left, o_fw = frame(anchor, rc == 0)
+                            gaps = max_text_gaps(scheme, ms2, Mo)
+                            gaps = gaps - (1 << 32) if gaps >= (1 << 31) else gaps
+                            og = (Mo + gaps) & 0xFFFFFFFF
+                            if o_left:
+                                max_end = g + M + og - min_frag if g + M + og > min_frag else 0
+                                obeg = g + M - max_frag if g + M > max_frag else 0
+                                oend = g + M if overlap else g
+                                oend = min(oend, max_end)
+                            else:
+                                min_begin = g + min_frag - og if g + min_frag > og else 0
+                                oend = g + max_frag
+                                obeg = g if overlap else g + M
+                                obeg = max(obeg, min_begin)
+                            oend = min(oend, genome_len)
+                            if obeg >= genome_len:
+                                run = False
+                            o_rc = 0 if o_fw else 1
+                            if visited(bb, 1 - anchor, o_rc, g) or obeg == oend or oend < obeg:
+                                run = False
+                            o_loc = obeg if run else 0
+                            o_sink = o_loc
+                            if run:
+                                _, s2, k2 = O.full_gotoh(aln_type, 0, scheme, oriented(o_reads[r], o_rc), text[obeg:oend], None, ms2)
+                                if s2 >= ms2:
+                                    o_score = s2
+                                o_sink = (obeg + (k2[0] if k2[0] != 0xFFFFFFFF else 0)) & 0xFFFFFFFF
+                        rows.append((g, hit_sink, hit_score, o_score, o_loc, o_sink, rc, (seed >> 14) & 1))
+                    scored.append(rows)
+                # score_reduce_paired
+                for (r, top, hits), rows in zip(out, scored):
+                    a1, a2, o1, o2 = [list(x) for x in (best_a[r][0], best_a[r][1], best_o[r][0], best_o[r][1])]
+                    m = [list(a1), list(a2), list(o1), list(o2)]              # what has been written to memory
+                    tr = trys[r]; erase = False
+
+                    def failure(idx, top_flag):
+                        nonlocal tr
+                        if tr > 0:
+                            if n_ext + idx >= min_ext and top_flag == 0:
+                                tr -= 1
+                                if tr == 0:
+                                    return True
+                            if n_ext + idx >= max_ext:
+                                return True
+                        return False
+
+                    for idx, (gx, gy, s1, s2, ox, oy, rc, top_flag) in enumerate(rows):
+                        score = s1 + s2
+                        o_left, o_fw = frame(anchor, rc == 0)
+                        o_rc = 0 if o_fw else 1
+                        pa = [s1, gx, (gy - gx) & 0xFFFFFFFF, rc, anchor, 1]
+                        po = [s2, ox, (oy - ox) & 0xFFFFFFFF, o_rc, 1 - anchor, 1]
+                        bl = [a1, a2, o1, o2]
+                        if (not pairs_distinct(a1, o1, pa, po)) or (not pairs_distinct(a2, o2, pa, po)):
+                            continue
+                        if score > best_score(bl):
+                            tr = max_effort
+                            a2, o2 = a1, o1; a1, o1 = pa, po
+                            m = [list(a1), list(a2), list(o1), list(o2)]
+                        elif score > second_score(bl) and pairs_distinct(a1, o1, pa, po, M // 2):
+                            tr = max_effort
+                            a2, o2 = pa, po
+                            m = [list(a1), list(a2), list(o1), list(o2)]
+                        elif unpaired and not paired(a1):
+                            m1 = a1 if anchor == a1[4] else o1
+                            m2 = a2 if anchor == a2[4] else o2
+                            m1, m2 = list(m1), list(m2)
+                            wrote = False
+                            if s1 > m1[0]:
+                                m2 = m1; m1 = [s1, gx, (gy - gx) & 0xFFFFFFFF, rc, anchor, 0]; wrote = True
+                            elif s1 > m2[0] and distinct(m1[1], m1[3], gx, rc, M // 2):
+                                m2 = [s1, gx, (gy - gx) & 0xFFFFFFFF, rc, anchor, 0]; wrote = True
+                            elif failure(idx, top_flag):
+                                erase = True
+                            if wrote:
+                                if anchor:
+                                    m[2], m[3] = list(m1), list(m2)
+                                else:
+                                    m[0], m[1] = list(m1), list(m2)
+                        elif failure(idx, top_flag):
+                            erase = True
+                    best_a[r] = [m[0], m[1]]; best_o[r] = [m[2], m[3]]
+                    trys[r] = tr
+                    if erase:
+                        deques[r] = deques[r][:0]
+                    n_extensions += len(rows)
+                n_ext += n_multi; passes += 1
+                active = [(r, top) for r, top, _ in out]
+            queue = nxt
+    return dict(best_a=np.array(best_a, dtype=np.int64), best_o=np.array(best_o, dtype=np.int64), n_extensions=n_extensions, n_opposite=n_opposite, passes=passes)
+
 # ---- nvBowtie's scoring stream, restated (test infrastructure; parity unpinned: score_inl.h is device-only CUDA) ------------------
 def score_stream_flatten(idx_queue, hit_read_id, hit_seed, hit_loc, read_index, band_len, genome_len, reads_reversed=True):
     """BestScoreStream::init_context (nvBowtie/bowtie2/cuda/score_inl.h:85-115) and the read orientation load_strings requests

@@ -121,6 +121,80 @@ def test_best_approx_loop_equals_the_oracle(amd, orc, mode):
     fmi.close()
 
 
+@pytest.mark.parametrize("mode", ["default", "tight", "no_unpaired_ff"])
+def test_paired_best_approx_loop_equals_the_oracle(amd, orc, mode):
+    """the PAIRED-END loop (nvbio_host_best_approx_paired): anchor = mate 1 then mate 2, the anchor band-aligned against the pair-derived
+    threshold (compute_target_score tightening as pairs are found), the opposite mate by full-matrix DP in its fragment window, the paired
+    reduction with the unpaired fallback and the effort counter -- best_a / best_o of every pair, bit for bit, and the counters equal the
+    oracle's pass-by-pass restatement; concordant pairs, pairs whose second mate lies elsewhere, a repeat family, unalignable mates"""
+    import torch
+    pipeline = importlib.import_module("nvbio_gpl_amd.pipeline")
+    rng = np.random.default_rng(47)
+    G = 300_000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    unit = rng.integers(0, 4, 600, dtype=np.uint8)
+    for c in range(12):                                            # a 12-copy repeat long enough to hold whole fragments
+        text[40000 + 5000 * c:40600 + 5000 * c] = unit
+        for _ in range(3):
+            text[40000 + 5000 * c + int(rng.integers(0, 600))] = rng.integers(0, 4)
+    hidx = orc.build_index(text)
+    R, M1, M2 = 260, 100, 120
+    frag = rng.integers(230, 480, R)
+    starts = rng.integers(0, G - 500, R)
+    starts[:60] = 40000 + 5000 * rng.integers(0, 12, 60) + rng.integers(0, 100, 60)
+    starts[60:66] = rng.integers(0, 5, 6); starts[66:72] = G - frag[66:72] - rng.integers(0, 4, 6)
+    ff = mode == "no_unpaired_ff"
+    # FR: mate 1 forward at the fragment's start and mate 2 reverse-complemented at its end -- or, the fragment read from the other strand,
+    # mate 1 reverse-complemented at the end and mate 2 forward at the start; FF: both forward, mate 1 upstream
+    flip = (rng.random(R) < 0.5) & (not ff)
+    p1 = np.where(flip, starts + frag - M1, starts)
+    p2 = np.where(flip, starts, starts + frag - M2)
+    p2[72:100] = rng.integers(0, G - M2, 28)                       # the second mate somewhere else: no concordant pair
+    m1 = mutate_reads(rng, text, p1, M1, sub=0.03)
+    m2 = mutate_reads(rng, text, p2, M2, sub=0.03)
+    if not ff:
+        m1[flip] = (3 - m1[flip][:, ::-1]).astype(np.uint8)
+        m2[~flip] = (3 - m2[~flip][:, ::-1]).astype(np.uint8)
+    m1[rng.random(m1.shape) < 0.002] = 4
+    m1[-8:] = rng.integers(0, 4, (8, M1)); m2[-12:] = rng.integers(0, 4, (12, M2))          # unalignable mates
+    kw = dict(max_hits=6, rep_seeds=8, max_effort=2, min_ext=3, max_ext=12, max_reseed=2) if mode == "tight" else \
+         dict(max_hits=100, rep_seeds=1000, max_effort=15, min_ext=30, max_ext=400, max_reseed=2)
+    policy = amd.PE_POLICY_FF if ff else amd.PE_POLICY_FR
+    pe = pipeline.PairedEndParams(policy=policy, min_frag_len=0 if mode == "default" else 150, max_frag_len=500, overlap=mode != "tight")
+    params = pipeline.SeedExtendParams.end_to_end()
+    osc = oracle.Scheme(0, 6, 6, -8, -3, -8, -3)
+    genome2 = orc.pack2(text)
+    fmi = amd.FMIndex.build(genome2, G, kmer_len=8, sa_int=16)
+    g_dev = torch.from_numpy(genome2.view(np.int32)).cuda()
+    rb = [pipeline.ReadBatch(torch.from_numpy(orc.pack4(np.ascontiguousarray(m[:, ::-1]).reshape(-1)).view(np.int32)).cuda(), R, m.shape[1]) for m in (m1, m2)]
+    n_paired = 0
+    for bs, multi in ((0, False), (0, True), (3 * R, True)):
+        want = cpu_pipeline.nvbowtie_best_approx_paired_cpu(orc, hidx, text, G, m1, m2, osc, oracle.SEMI_GLOBAL, params.min_score_for, batch_size=bs or None,
+                                                            multi_hit=multi, policy=int(policy), min_frag=pe.min_frag_len, max_frag=pe.max_frag_len,
+                                                            overlap=pe.overlap, unpaired=not ff, **kw)
+        got = pipeline.nvbowtie_best_approx_paired_host(fmi, g_dev, G, rb[0], rb[1], params, pipeline.NvBowtieParams(**kw), pe, unpaired=not ff, batch_size=bs,
+                                                        multi_hit=multi)
+        for k in ("best_a", "best_o"):
+            g = got[k].cpu().numpy().astype(np.int64)
+            w = want[k]
+            flags = w[..., 3] | (w[..., 4] << 1) | (w[..., 5] << 2)
+            assert np.array_equal(g[..., 0], w[..., 0]), (mode, k, "score", bs, multi)
+            assert np.array_equal(g[..., 1] & 0xFFFFFFFF, w[..., 1]), (mode, k, "pos", bs, multi)
+            assert np.array_equal(g[..., 2] & 0xFFFFFFFF, w[..., 2]), (mode, k, "sink", bs, multi)
+            assert np.array_equal(g[..., 3], flags), (mode, k, "flags", bs, multi)
+        for k in ("n_extensions", "n_opposite", "passes"):
+            assert got[k] == want[k], (mode, k, bs, multi)
+        assert (got["multi_passes"] > 0) == multi
+        a = got["best_a"].cpu().numpy()
+        paired = ((a[:, 0, 3] >> 2) & 1) == 1
+        n_paired = int(paired[:60].sum() + paired[100:-12].sum())
+        assert paired[100:-12].mean() > (0.9 if mode == "default" else 0.75) and not paired[-12:].any()              # concordant pairs found as pairs; unalignable mates not
+        if not ff:                                                                 # the per-mate fallback holds mate 1 of the pairs that are none
+            assert (a[72:100, 0, 1] != -1).mean() > 0.9 and not paired[72:100].any()
+    assert n_paired > 0
+    fmi.close()
+
+
 @pytest.mark.parametrize("max_hits", [100, 7])
 def test_approximate_seed_mapper_equals_the_oracle(amd, orc, max_hits):
     """seed_mapper<APPROX_MAPPING>: four one-mismatch searches per seed over the forward index and the index of the reversed text; the
