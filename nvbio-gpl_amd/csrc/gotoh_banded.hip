@@ -227,6 +227,17 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s pk(const int a, const int b) { v2s r; r.x = (short)a; r.y = (short)b; return r; }
 __device__ __forceinline__ v2s pk_max(const v2s a, const v2s b) { return __builtin_elementwise_max( a, b ); }
 __device__ __forceinline__ v2s pk_from_bits(const uint32_t u) { return __builtin_bit_cast( v2s, u ); }
+// the same pair of lanes as two binary16 numbers: every integer of magnitude <= 2048 is exact there, and gfx950 has a packed three-operand
+// maximum (v_pk_maximum3_f16) where the integer pipe needs two v_pk_max_i16
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2h pk_max(const v2h a, const v2h b) { return __builtin_elementwise_maximum( a, b ); }
+__device__ __forceinline__ v2s pk_max3(const v2s a, const v2s b, const v2s c) { return pk_max( pk_max( a, b ), c ); }
+__device__ __forceinline__ v2h pk_max3(const v2h a, const v2h b, const v2h c) { return __builtin_elementwise_maximum( __builtin_elementwise_maximum( a, b ), c ); }
+template <typename V> __device__ __forceinline__ V pk_of(const int a, const int b);
+template <> __device__ __forceinline__ v2s pk_of<v2s>(const int a, const int b) { return pk( a, b ); }
+template <> __device__ __forceinline__ v2h pk_of<v2h>(const int a, const int b) { v2h r; r.x = (_Float16)a; r.y = (_Float16)b; return r; }
+template <bool FP> struct PkLanes { typedef v2s type; };
+template <> struct PkLanes<true> { typedef v2h type; };
 
 // 32 bits of a big-endian packed stream starting at absolute bit position `bit`, assembled from the
 // two words (a = word bit>>5, b = the next one) that were loaded one chunk earlier
@@ -265,13 +276,19 @@ __device__ __forceinline__ uint32_t even_bits64(uint64_t x)
 // starts late, at row pad = (rows of the longer) - (its own rows), so that both end in the same row and report from the band there.  Its
 // streams are read at row - pad (before its start it computes on whatever they hold), and in the row it starts its half of the band and of
 // the text cache is set to the initial state -- one extra wave-level branch per row while some lane of the wave is still waiting to start.
-template <int TYPE, int RBITS, int MINW = 3, bool M0 = false, bool RAGGED = false>
+// FP (M0, not LOCAL; the host checks that every score stays inside +-2040): the two lanes of a register are binary16 numbers.  Integers of that
+// size, their sums and maxima are exact there, the mismatch flag becomes 2^-7 (bit 13 of each half) against a penalty scaled by 128 in one
+// v_pk_fma_f16, and h = max( f, d, E ) is ONE v_pk_maximum3_f16: 9 operations per cell instead of 10.  (The -16384 stand-in for the reference's
+// infimum stays where it is under + GE: 16 is the spacing of binary16 there.)
+template <int TYPE, int RBITS, int MINW = 3, bool M0 = false, bool RAGGED = false, bool FP = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MINW, 3)))
 banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __restrict__ scores, uint2* __restrict__ sinks,
                               const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
 {
     constexpr int BAND = 31;
     constexpr uint32_t RMASK = (1u << RBITS) - 1u;
+    static_assert( !FP || (M0 && TYPE != NVBIO_LOCAL), "the binary16 build: match = 0, GLOBAL / SEMI_GLOBAL" );
+    typedef typename PkLanes<FP>::type v2;
     __shared__ int32_t s_mm[64];
     if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
     __syncthreads();
@@ -329,8 +346,9 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
     const uint32_t* __restrict__ qwords = (const uint32_t*)((uintptr_t)b.quals - qadj);
     const bool has_quals = (b.quals != nullptr);
 
-    const v2s GO = pk( sc.pat_go, sc.pat_go ), GE = pk( sc.pat_ge, sc.pat_ge );
-    const v2s INF = pk( -16384, -16384 ), ZERO = pk( 0, 0 ), K32 = pk( 32, 32 );
+    const v2 GO = pk_of<v2>( sc.pat_go, sc.pat_go ), GE = pk_of<v2>( sc.pat_ge, sc.pat_ge );
+    const v2 INF = pk_of<v2>( -16384, -16384 ), ZERO = pk_of<v2>( 0, 0 );
+    const v2s K32 = pk( 32, 32 );
     const int V = sc.match;
     const int S_noq = s_mm[0];                                       // without qualities every row scores a mismatch like this
     uint32_t cx[2], lim[2];
@@ -416,12 +434,12 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
         };
         issue_loads( 0 );
 
-        v2s H[BAND], Hg[BAND], F[BAND];                              // Hg = H + GO, kept beside H: feeds the next row's F and this row's E
+        v2 H[BAND], Hg[BAND], F[BAND];                               // Hg = H + GO, kept beside H: feeds the next row's F and this row's E
         #pragma unroll
         for (int j = 0; j < BAND; ++j)
         {
             const int h0 = (TYPE == NVBIO_GLOBAL && j > 0) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;      // init_row_zero (:37-68)
-            H[j] = pk( h0, h0 ); F[j] = INF; Hg[j] = H[j] + GO;
+            H[j] = pk_of<v2>( h0, h0 ); F[j] = INF; Hg[j] = H[j] + GO;
         }
 
         for (uint32_t r0 = 0; r0 < rows; r0 += 8u)
@@ -471,8 +489,9 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                         for (int j = 0; j < BAND; ++j)
                         {
                             const int h0 = (TYPE == NVBIO_GLOBAL && j > 0) ? sc.txt_go + (j - 1) * sc.txt_ge : 0;
-                            if (s0) { H[j].x = (short)h0; F[j].x = (short)-16384; Hg[j].x = (short)(h0 + sc.pat_go); }
-                            if (s1) { H[j].y = (short)h0; F[j].y = (short)-16384; Hg[j].y = (short)(h0 + sc.pat_go); }
+                            const v2 hh = pk_of<v2>( h0, h0 ), hhg = pk_of<v2>( h0 + sc.pat_go, h0 + sc.pat_go );
+                            if (s0) { H[j].x = hh.x; F[j].x = INF.x; Hg[j].x = hhg.x; }
+                            if (s1) { H[j].y = hh.y; F[j].y = INF.y; Hg[j].y = hhg.y; }
                         }
                         if (s0) { c0[0] = c0i[0]; c1[0] = c1i[0]; }
                         if (s1) { c0[1] = c0i[1]; c1[1] = c1i[1]; }
@@ -510,52 +529,77 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
                 const uint32_t NWa = __builtin_amdgcn_perm( nq[1], nq[0], 0x05040100u );
                 const uint32_t NWb = __builtin_amdgcn_perm( nq[1], nq[0], 0x07060302u );
 
-                const v2s SS = pk( S[0], S[1] );                      // M0 (match = 0): d = H + mismatch * S
-                const v2s SD = pk( S[0] - V, S[1] - V );              // else          : d = (H + V) + mismatch * (S - V)
-                const v2s VV = pk( V, V );
+                // M0 (match = 0): d = H + mismatch * S; else d = (H + V) + mismatch * (S - V); FP: the flag is 2^-7, the penalty S * 128
+                const v2 SS = FP ? pk_of<v2>( S[0] * 128, S[1] * 128 ) : pk_of<v2>( S[0], S[1] );
+                const v2 SD = pk_of<v2>( S[0] - V, S[1] - V );
+                const v2 VV = pk_of<v2>( V, V );
+                // column j's pair of mismatch flags: bits 30-j / 46-j of NWa (j >= 15) or 14-j / 30-j of NWb (j < 15), moved to bit 0 (13 with FP)
+                // of each half
+                auto flags_at = [&](const int j) -> uint32_t {                // ... moved into place,
+                    const uint32_t w = (j < 15) ? NWb : NWa;
+                    const int bit = (j < 15) ? 14 - j : 30 - j;              // of the low half
+                    const int to  = FP ? 13 : 0;
+                    return bit >= to ? w >> (bit - to) : w << (to - bit);
+                };
+                auto flags_in = [&](const uint32_t q) -> v2 { return __builtin_bit_cast( v2, q & (FP ? 0x20002000u : 0x00010001u) ); };   // ... and masked
+                auto flags_of = [&](const int j) -> v2 { return flags_in( flags_at( j ) ); };
+                auto diag_of = [&](const v2 h, const v2 t) -> v2 {
+                    if (FP) return __builtin_bit_cast( v2, __builtin_elementwise_fma( __builtin_bit_cast( v2h, t ), __builtin_bit_cast( v2h, SS ), __builtin_bit_cast( v2h, h ) ) );
+                    return M0 ? h + t * SS : (h + VV) + t * SD;
+                };
 
                 // One cell is 10 operations: f = max(F[j+1] + GE, Hg[j+1]); d = H[j] + mismatch * S; t = max(f, d); h = max(t, E);
-                // hg = h + GO; E' = max(hg, E + GE).  Only E runs along the row; gfx950 needs one idle slot between a packed 16-bit
-                // operation and a consumer issued right behind it, so the row is software-pipelined by hand: the E steps of cell j
-                // are interleaved with everything of cell j+1 that does not depend on E, in an order in which no operation directly
-                // follows its producer (sched_barrier keeps the compiler from undoing it: measured 15 -> 10 issue slots per cell).
-                v2s E = ZERO, a = ZERO, tt;
+                // hg = h + GO; E' = max(hg, E + GE) -- 9 with FP, where h = max(f, d, E) is one operation.  Only E runs along the row; gfx950
+                // needs one idle slot between a packed 16-bit operation and a consumer issued right behind it, so the row is software-pipelined by
+                // hand: the E steps of cell j are interleaved with everything of cell j+1 that does not depend on E, in an order in which no
+                // operation directly follows its producer (sched_barrier keeps the compiler from undoing it: measured 15 -> 10 issue slots per cell).
+                v2 E = ZERO, a = ZERO, tt, ff = INF, dd = ZERO;              // (FP carries f and d of the next cell instead of their maximum)
                 v2s key = pk( -1, -1 );
                 {
-                    const v2s x  = F[1] + GE;
-                    const v2s t0 = pk_from_bits( (NWb >> 14) & 0x00010001u );
-                    const v2s d  = M0 ? H[0] + t0 * SS : (H[0] + VV) + t0 * SD;
-                    const v2s f  = pk_max( x, Hg[1] );
+                    const v2 x  = F[1] + GE;
+                    const v2 t0 = flags_of( 0 );
+                    const v2 d  = diag_of( H[0], t0 );
+                    const v2 f  = pk_max( x, Hg[1] );
                     F[0] = f;
-                    tt = pk_max( f, d );
-                    if (TYPE == NVBIO_LOCAL) tt = pk_max( tt, ZERO );
+                    if (FP) { ff = f; dd = d; tt = ZERO; }
+                    else
+                    {
+                        tt = pk_max( f, d );
+                        if (TYPE == NVBIO_LOCAL) tt = pk_max( tt, ZERO );
+                    }
                 }
                 #pragma unroll
                 for (int j = 0; j < BAND; ++j)
                 {
                     constexpr int Z = 0;
                     const int j1 = j + 1, j2 = j + 2;
-                    v2s x = INF, d = ZERO, f = INF, t1 = ZERO, tn = ZERO, an = ZERO;
+                    v2 x = INF, d = ZERO, f = INF, t1 = ZERO, tn = ZERO, an = ZERO;
                     uint32_t q1 = 0;
                     if (j2 < BAND) x  = F[j2] + GE;
                     __builtin_amdgcn_sched_barrier( Z );
-                    const v2s h = (j == 0) ? tt : pk_max( tt, E );
-                    if (j1 < BAND) q1 = (j1 < 15) ? NWb >> (14 - j1) : NWa >> (30 - j1);
+                    const v2 h = FP ? ((j == 0) ? pk_max( ff, dd ) : pk_max3( ff, dd, E )) : ((j == 0) ? tt : pk_max( tt, E ));
+                    if (j1 < BAND) q1 = flags_at( j1 );
                     __builtin_amdgcn_sched_barrier( Z );
-                    const v2s hg = h + GO;
+                    const v2 hg = h + GO;
+                    if (!FP && j1 < BAND) t1 = flags_in( q1 );
                     if (j2 < BAND) f  = pk_max( x, Hg[j2] );
                     __builtin_amdgcn_sched_barrier( Z );
-                    const v2s En = (j == 0) ? hg : pk_max( hg, a );
-                    if (j1 < BAND) t1 = pk_from_bits( q1 & 0x00010001u );
-                    if (j1 < BAND) d  = M0 ? H[j1] + t1 * SS : (H[j1] + VV) + t1 * SD;
+                    const v2 En = (j == 0) ? hg : pk_max( hg, a );
+                    if (FP) __builtin_amdgcn_sched_barrier( Z );            // (one cell is an operation shorter: keep E' away from its consumer)
+                    if (FP && j1 < BAND) t1 = flags_in( q1 );
+                    if (j1 < BAND) d  = diag_of( H[j1], t1 );
                     __builtin_amdgcn_sched_barrier( Z );
                     if (j1 < BAND) an = En + GE;
-                    if (TYPE == NVBIO_LOCAL) key = pk_max( key, h * K32 + pk( j, j ) );
+                    if (TYPE == NVBIO_LOCAL) key = pk_max( key, __builtin_bit_cast( v2s, h ) * K32 + pk( j, j ) );
                     __builtin_amdgcn_sched_barrier( Z );
                     if (j1 < BAND)
                     {
-                        tn = (j2 < BAND) ? pk_max( f, d ) : d;
-                        if (TYPE == NVBIO_LOCAL) tn = pk_max( tn, ZERO );
+                        if (FP) { ff = (j2 < BAND) ? f : d; dd = d; }
+                        else
+                        {
+                            tn = (j2 < BAND) ? pk_max( f, d ) : d;
+                            if (TYPE == NVBIO_LOCAL) tn = pk_max( tn, ZERO );
+                        }
                         F[j1] = f;
                     }
                     H[j] = h; Hg[j] = hg;
@@ -718,28 +762,39 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     }
     else
     {
+        // A diagonal matters only while its count can still change the outcome: no class of alignments the three chances know settles a job
+        // whose best diagonal scores 3 G - P or less (the third chance's `beyond`), so counts above `cap` mean "DP" whatever they are, and
+        // without qualities neither does a count above the best one found so far.  The first word of a diagonal (32 rows; about 24
+        // mismatches on a diagonal that is not the read's own or its partner across an indel) decides that for the whole wave nearly
+        // always: its other words are evaluated only if SOME lane is still interested (a wave-uniform branch) -- 24 of 31 diagonals cost one
+        // word instead of six.  The text planes are taken d symbols on with one funnel shift per word (d is a constant of the unrolled loop).
+        const int64_t floor_u = 3 * (int64_t)(G < gap_open ? G : gap_open) - P;          // U <= floor_u: DP whatever else holds
+        const uint32_t cap = (uint32_t)((-floor_u - 1) / (int64_t)P);                   // the largest count with -P cnt > floor_u
         uint32_t cnt_d[QUAL ? 31 : 1];
         #pragma unroll
-        for (uint32_t d = 0; d < 31u; ++d)                           // (unrolled, no early exit: a window is rarely clipped)
+        for (uint32_t d = 0; d < 31u; ++d)
         {
             const bool on = (d == 0u || d < m);                      // reportable columns are a prefix of 0..30
-            uint32_t cnt = 0;
-            #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            uint32_t cnt;
             {
-                const uint32_t mm = (((pl[k] ^ ql[k]) | (ph[k] ^ qh[k])) & pm[k]) | pn[k];
-                cnt += (uint32_t)__popc( mm );
+                const uint32_t tl = d ? __builtin_amdgcn_alignbit( ql0[1], ql0[0], d ) : ql0[0], th = d ? __builtin_amdgcn_alignbit( qh0[1], qh0[0], d ) : qh0[0];
+                cnt = (uint32_t)__popc( (((pl[0] ^ tl) | (ph[0] ^ th)) & pm[0]) | pn[0] );
             }
+            const uint32_t thr = QUAL ? cap : (best_cnt < cap ? best_cnt : cap);
+            if (__any( on && cnt <= thr ))
+            {
+                #pragma unroll
+                for (int k = 1; k < 6; ++k)
+                {
+                    const uint32_t tl = d ? __builtin_amdgcn_alignbit( ql0[k + 1], ql0[k], d ) : ql0[k], th = d ? __builtin_amdgcn_alignbit( qh0[k + 1], qh0[k], d ) : qh0[k];
+                    cnt += (uint32_t)__popc( (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k] );
+                }
+            }
+            else cnt = 0xFFFFFFFFu;                                  // (partial, and above every lane's threshold)
             if (QUAL) cnt_d[d] = on ? cnt : 0xFFFFFFFFu;
             if (on && cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
-            #pragma unroll
-            for (int k = 0; k < 6; ++k)
-            {
-                ql[k] = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], 1u );
-                qh[k] = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], 1u );
-            }
-            ql[6] >>= 1; qh[6] >>= 1;
         }
+        if (best_cnt > cap) { need_dp[job] = 1; return; }           // (includes: no diagonal evaluated)
         U = -(int64_t)P * (int64_t)best_cnt;
         if (QUAL)
         {
@@ -1097,17 +1152,24 @@ static void launch_pk_kernel(const BatchDev& b, const SchemeDev& sc, const uint3
 {
     const dim3 grid( (pairs + 127u) / 128u ), block( 128 );
     const bool two = (b.algo & NVBIO_ALN_PK_THREE_WAVES) == 0;
+    // the binary16 build is exact while every score stays an integer of magnitude <= 2040 (and the scaled penalties finite)
+    int64_t step = 0;
+    { const int c[] = { sc.mm_min, sc.mm_max, -sc.pat_go, -sc.pat_ge, -sc.txt_go, -sc.txt_ge }; for (int v : c) if (v > step) step = v; }
+    const bool fp = two && sc.match == 0 && TYPE == NVBIO_SEMI_GLOBAL && !(b.algo & NVBIO_ALN_NO_F16_DP) && ((int64_t)b.max_read_len + 32) * step <= 2040 && sc.mm_max <= 400;
     if (TYPE == NVBIO_SEMI_GLOBAL && sc.match == 0 && (b.algo & NVBIO_ALN_RAGGED_READS))
     {
         // reads of different lengths (the caller says so): both alignments of a lane in one pass
         constexpr int T = (TYPE == NVBIO_SEMI_GLOBAL) ? TYPE : NVBIO_SEMI_GLOBAL;
-        hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        if (fp) hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true,true,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        else    hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
         return;
     }
     if (TYPE != NVBIO_LOCAL && sc.match == 0)
     {
         constexpr int T = (TYPE == NVBIO_LOCAL) ? NVBIO_SEMI_GLOBAL : TYPE;      // (never LOCAL here: keeps that instantiation out)
-        if (two) hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        // (the binary16 build of the GLOBAL kernel spills: SEMI_GLOBAL only)
+        if (fp)  hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<NVBIO_SEMI_GLOBAL,RB,2,true,false,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
+        else if (two) hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,2,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
         else     hipLaunchKernelGGL( (banded_gotoh_band31_pk_kernel<T,RB,3,true>), grid, block, 0, s, b, sc, scores, sinks, job_list, job_count );
     }
     else

@@ -79,7 +79,7 @@ void enact_best_score_stream(const stream_type& stream, nvbio_alignment_type typ
     const uint32_t* read_index = raw_pointer( p.reads.sequence_index() );
     check( nvbio_score_stream_flatten( device, &hq, read_index, stream.m_band_len, p.genome_length, /*reads_reversed*/1u,
                                        read_id, flags, wb, we, s ) );
-    nvbio_alignment_batch b;
+    nvbio_alignment_batch b = {};
     b.reads_dev        = raw_pointer( p.reads.sequence_storage() );
     b.read_bits        = 4;                                                      // io::SequenceDataTraits<DNA_N>::SEQUENCE_BITS
     b.read_offsets_dev = read_index;
@@ -128,7 +128,7 @@ void enact_sw_benchmark_stream(const stream_type& stream, nvbio_alignment_type t
     check( nvbio_text_2bit_le_to_be( device, raw_pointer( stream.m_text ), text_words, text_be, s ) );   // REF_BIG_ENDIAN = false (:65)
     check_hip( hipMemsetAsync( wb, 0, n * sizeof(uint32_t), s ), "hipMemsetAsync" );                       // text_length(i) = m_text_len: the whole text
     check_hip( hipMemsetD32Async( (hipDeviceptr_t)we, (int)text_len, n, s ), "hipMemsetD32Async" );
-    nvbio_alignment_batch b;
+    nvbio_alignment_batch b = {};
     b.reads_dev        = raw_pointer( stream.m_patterns );                       // 4-bit big-endian (SequenceDataTraits<DNA_N>)
     b.read_bits        = 4;
     b.read_offsets_dev = stream.m_offsets;                                       // pattern i = [m_offsets[i], m_offsets[i+1])

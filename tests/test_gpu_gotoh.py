@@ -310,6 +310,11 @@ def test_end_to_end_shortcut_edge_cases(amd, orc):
         bad = np.nonzero(sc.cpu().numpy() != wsc)[0]
         assert len(bad) == 0, (sv, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]])
         assert np.array_equal(amd.u32(sk), wsk), sv
+        # the same with 16-bit integer lanes in the DP instead of binary16 ones
+        for kw in (dict(algo_flags=amd.ALN_NO_F16_DP),):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M, **kw)
+            sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+            assert np.array_equal(sc.cpu().numpy(), wsc) and np.array_equal(amd.u32(sk), wsk), (sv, sorted(kw))
     # the indel reads really are cases where a gapped alignment beats a 2-3 mismatch diagonal
     assert ((wsc[1200:2700] > -18) & (wsc[1200:2700] <= -3)).mean() > 0.5
     # the same jobs with base qualities under quality-dependent mismatch penalties (nvBowtie's default ramp 2..6 and two others):
@@ -369,11 +374,13 @@ def test_end_to_end_shortcut_with_qualities_reversed_reads(amd, orc):
         wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we,
                                                  read_id=rid, flags=flags, quals=quals)
         for algo in (None, amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_RAGGED_READS, amd.ALN_RAGGED_READS | amd.ALN_NO_LENGTH_SORT,
-                     amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE | amd.ALN_NO_LENGTH_SORT):
-            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, flags=flags, max_read_len=150, algo_flags=algo)
-            sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
-            assert np.array_equal(sc.cpu().numpy(), wsc), algo
-            assert np.array_equal(amd.u32(sk), wsk), algo
+                     amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_RAGGED_READS | amd.ALN_NO_UNGAPPED_SCORE | amd.ALN_NO_LENGTH_SORT,
+                     amd.ALN_RAGGED_READS | amd.ALN_NO_F16_DP):
+            for kw in ({},):
+                batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, flags=flags, max_read_len=150, algo_flags=algo, **kw)
+                sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+                assert np.array_equal(sc.cpu().numpy(), wsc), (algo, bool(kw))
+                assert np.array_equal(amd.u32(sk), wsk), (algo, bool(kw))
     assert (wsc > -8).mean() > 0.3                                    # a good share is settled by the first pass
 
 
