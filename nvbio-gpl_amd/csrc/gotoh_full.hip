@@ -252,6 +252,136 @@ full_gotoh_kernel(const BatchDev b, const SchemeDev sc, const uint32_t job_begin
 }
 
 // ---------------------------------------------------------------------------------------------
+// The COOPERATIVE full-matrix kernel: L lanes per job (gotoh_warp_inl.h:33-245 is the reference's several-threads-per-alignment form).
+// full_gotoh_kernel gives a job to one lane and keeps the boundary column between stripes in memory: a batch of 100 k jobs (the sw-benchmark
+// shape, BASELINE configs[0]) is 1.5 waves per SIMD, each waiting for its boundary cell row after row.  Here lane l of a job owns the W pattern
+// columns [l W, (l + 1) W) for the WHOLE sweep over the text and runs l rows behind lane l - 1: at step t it computes text row t - l from the
+// (H, E) its left neighbour left in that row one step earlier (one DPP row-shift each), so the boundary never leaves the registers, L times as
+// many lanes are busy, and there is no scratch.  GLOBAL and SEMI_GLOBAL without the stripe early exit (min_scores = NULL): there the reference's
+// result does not depend on how the matrix is swept -- the score of cell (N, M), or the last maximum of column M over ascending text positions --
+// as long as no value leaves the int16 range of its boundary cells (the host checks (M + N) * largest step).  The two blockings differ only in
+// which gap terms initialise which border (gotoh_inl.h:56-74 against :676-681 / :1061-1066): `text_blocking` picks them.
+// ---------------------------------------------------------------------------------------------
+template <int TYPE, int L, int W, int RBITS>
+__global__ void __launch_bounds__(256)
+full_gotoh_coop_kernel(const BatchDev b, const SchemeDev sc, const bool text_blocking, int32_t* __restrict__ scores, uint2* __restrict__ sinks)
+{
+    static_assert( TYPE != NVBIO_LOCAL && (L == 4 || L == 8 || L == 16), "GLOBAL / SEMI_GLOBAL; the lanes of a job inside one DPP row" );
+    __shared__ int32_t s_mm[64];
+    if (threadIdx.x < 64) s_mm[threadIdx.x] = mismatch_score( sc, threadIdx.x );
+    __syncthreads();
+
+    const uint32_t gl  = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t l   = gl % L;
+    const uint32_t jid = gl / L;
+    const bool     valid = jid < b.n;
+    const uint32_t job = valid ? jid : b.n - 1u;                // (lanes past the batch repeat its last job and report nothing)
+
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    const bool     fits  = M >= 1u && M <= (uint32_t)(L * W);
+
+    // border terms: a pattern prefix of length n scores po + pe (n - 1), a text prefix to + te (n - 1) (GLOBAL only; free otherwise)
+    const int32_t po = text_blocking ? sc.txt_go : sc.pat_go, pe = text_blocking ? sc.txt_ge : sc.pat_ge;
+    const int32_t to = text_blocking ? sc.pat_go : sc.txt_go, te = text_blocking ? sc.pat_ge : sc.txt_ge;
+    const int32_t go = sc.pat_go, ge = sc.pat_ge, V = sc.match;
+    const int32_t infimum = -32768 - (sc.pat_go < sc.pat_ge ? sc.pat_go : sc.pat_ge);
+
+    // my columns: symbols, mismatch scores, the cells of the row above the matrix
+    const uint32_t c0 = l * (uint32_t)W;
+    uint32_t psym[W]; int32_t pmm[W], H[W], F[W];
+    {
+        SymbolReader<RBITS> prd( b.reads );
+        #pragma unroll
+        for (int k = 0; k < W; ++k)
+        {
+            const uint32_t j = c0 + (uint32_t)k;
+            uint32_t q = 4u, qq = 0u;                            // (columns past the pattern: a symbol that matches nothing)
+            if (j < M)
+            {
+                const uint32_t idx = rev ? first + M - 1u - j : first + j;
+                q = prd.get( idx );
+                if (comp && q < 4u) q = 3u - q;
+                qq = b.quals ? b.quals[idx] : 0u;
+            }
+            psym[k] = q; pmm[k] = s_mm[qq < 63u ? qq : 63u];
+            H[k] = po + pe * (int32_t)j;                         // prefix length j + 1
+            F[k] = infimum;
+        }
+    }
+    int32_t h_diag_left = c0 ? po + pe * (int32_t)(c0 - 1u) : 0;  // H( row above, my first column - 1 ): the corner is 0
+    int32_t h_out = 0, e_out = infimum;                          // my last column's (H, E) of the row I computed last
+
+    // where column M lives
+    const uint32_t lm = fits ? (M - 1u) / (uint32_t)W : 0u, km = fits ? (M - 1u) % (uint32_t)W : 0u;
+    int32_t  best = NVBIO_SCORE_MIN; uint32_t best_x = 0xFFFFFFFFu;
+
+    const uint32_t* __restrict__ twords = (const uint32_t*)b.text;
+    uint32_t steps = fits ? N + (uint32_t)L - 1u : 0u;          // every lane of the wave runs the longest job's steps
+    #pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor( (int)steps, o ); steps = v > steps ? v : steps; }
+
+    for (uint32_t t = 0; t < steps; ++t)
+    {
+        // the left neighbour's last column, from the step before (row_shr:1; lane 0 of a job takes the matrix's first column instead)
+        int32_t h_in = __builtin_amdgcn_update_dpp( 0, h_out, 0x111, 0xF, 0xF, false );
+        int32_t e_in = __builtin_amdgcn_update_dpp( 0, e_out, 0x111, 0xF, 0xF, false );
+        const uint32_t i = t - l;                                // my text row (wraps while I wait for my turn)
+        if (l == 0u) { h_in = (TYPE == NVBIO_GLOBAL) ? to + te * (int32_t)i : 0; e_in = infimum; }
+        if (i < N && fits)
+        {
+            const uint32_t tp = tb + i;
+            const uint32_t r_sym = (twords[tp >> 4] >> (30u - 2u * (tp & 15u))) & 3u;
+            int32_t H_diag = h_diag_left;
+            h_diag_left = h_in;
+            int32_t hl = h_in, E = e_in;
+            #pragma unroll
+            for (int k = 0; k < W; ++k)
+            {
+                F[k] = max2( F[k] + ge, H[k] + go );
+                E    = max2( E + ge, hl + go );
+                const int32_t S = (psym[k] == r_sym) ? V : pmm[k];
+                const int32_t hi = max3( E, F[k], H_diag + S );
+                H_diag = H[k];
+                H[k]   = hi; hl = hi;
+            }
+            h_out = hl; e_out = E;
+            if (TYPE == NVBIO_SEMI_GLOBAL && l == lm)
+            {
+                int32_t v = 0;
+                #pragma unroll
+                for (int k = 0; k < W; ++k) if ((uint32_t)k == km) v = H[k];
+                if (best <= v) { best = v; best_x = i + 1u; }    // ascending text positions, the last maximum wins
+            }
+        }
+    }
+    if (valid && (l == lm || !fits))
+    {
+        if (!fits) { if (l == 0u) { scores[job] = NVBIO_SCORE_MIN; sinks[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); } return; }
+        if (TYPE == NVBIO_GLOBAL)
+        {
+            // cell (N, M); with text blocking an empty text reports nothing (no stripe holds column N = 0)
+            int32_t v = 0;
+            #pragma unroll
+            for (int k = 0; k < W; ++k) if ((uint32_t)k == km) v = H[k];
+            if (N == 0u && text_blocking) { scores[job] = NVBIO_SCORE_MIN; sinks[job] = make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ); }
+            else { scores[job] = v; sinks[job] = make_uint2( N, M ); }
+        }
+        else
+        {
+            scores[job] = best;
+            sinks[job]  = best_x == 0xFFFFFFFFu ? make_uint2( 0xFFFFFFFFu, 0xFFFFFFFFu ) : make_uint2( best_x, M );
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ungapped shortcut for end-to-end (SEMI_GLOBAL, match = 0) full-matrix scoring: the same argument as
 // ungapped_e2e31_kernel (gotoh_banded.hip) over ALL diagonals of the window.  An alignment with a gap scores
 // at most G = max(gap opens) < 0; the ungapped alignments of the whole pattern are the diagonals d = 0..N-M,
@@ -1163,6 +1293,40 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
     NVB_REQUIRE( rows > 0, "max_pattern_len / max_text_len must bound the boundary column" );
     DeviceGuard g( device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
+
+    // ---- the cooperative kernel (L lanes per job, no boundary column in memory): GLOBAL, and SEMI_GLOBAL where the end-to-end shortcut does not
+    //      apply, without the stripe early exit; packed 2- / 4-bit reads in a 2-bit text; every value inside the int16 range of the reference's
+    //      boundary cells.  Batches large enough for the two-jobs-per-lane kernel keep that one.
+    {
+        int64_t step = sc.match > 0 ? sc.match : -(int64_t)sc.match;
+        const int64_t cc[] = { sc.mm_min, sc.mm_max, sc.pat_go, sc.pat_ge, sc.txt_go, sc.txt_ge };
+        for (int64_t v : cc) { const int64_t a = v < 0 ? -v : v; if (a > step) step = a; }
+        const bool pk_bits  = batch->text_bits == 2 && (batch->read_bits == 4 || batch->read_bits == 2);
+        const bool e2e      = type == NVBIO_SEMI_GLOBAL && sc.match == 0 && !(b.algo & NVBIO_ALN_NO_UNGAPPED_SCORE);      // (the shortcut's ground)
+        const bool pk_route = !text_blocking && (b.n >= 262144u || (b.algo & NVBIO_ALN_FORCE_PACKED_DP)) && !(b.algo & NVBIO_ALN_NO_PACKED_DP);
+        const bool coop = (type == NVBIO_GLOBAL || type == NVBIO_SEMI_GLOBAL) && !e2e && !pk_route && min_scores_dev == nullptr && pk_bits && plain_gotoh( sc ) &&
+                          max_pattern_len >= 1 && max_pattern_len <= 256u && ((int64_t)max_pattern_len + max_text_len + 2) * step <= 30000 &&
+                          !(b.algo & NVBIO_ALN_NO_COOPERATIVE_DP);
+        if (coop)
+        {
+#define NVB_COOP(TYPE_, L_, W_) do { const uint64_t lanes = (uint64_t)b.n * L_; const dim3 grid( (uint32_t)((lanes + 255u) / 256u) ), block( 256 ); \
+            if (batch->read_bits == 4) hipLaunchKernelGGL( (full_gotoh_coop_kernel<TYPE_,L_,W_,4>), grid, block, 0, s, b, sc, text_blocking != 0, scores_dev, (uint2*)sinks_dev ); \
+            else                       hipLaunchKernelGGL( (full_gotoh_coop_kernel<TYPE_,L_,W_,2>), grid, block, 0, s, b, sc, text_blocking != 0, scores_dev, (uint2*)sinks_dev ); } while (0)
+#define NVB_COOP_SHAPE(TYPE_) do { const uint32_t mp = max_pattern_len; \
+            if      (mp <=  32u) NVB_COOP( TYPE_, 4, 8 );  \
+            else if (mp <=  64u) NVB_COOP( TYPE_, 4, 16 ); \
+            else if (mp <= 100u) NVB_COOP( TYPE_, 4, 25 ); \
+            else if (mp <= 128u) NVB_COOP( TYPE_, 8, 16 ); \
+            else if (mp <= 152u) NVB_COOP( TYPE_, 8, 19 ); \
+            else if (mp <= 200u) NVB_COOP( TYPE_, 8, 25 ); \
+            else                 NVB_COOP( TYPE_, 8, 32 ); } while (0)
+            if (type == NVBIO_GLOBAL) NVB_COOP_SHAPE( NVBIO_GLOBAL ); else NVB_COOP_SHAPE( NVBIO_SEMI_GLOBAL );
+#undef NVB_COOP_SHAPE
+#undef NVB_COOP
+            NVB_HIP( hipGetLastError() );
+            return NVBIO_OK;
+        }
+    }
 
     // ---- which jobs need which kernel --------------------------------------------------------------------------
     //  1. end-to-end shortcut (ungapped_full_e2e_kernel): settles the jobs whose best diagonal beats every gapped

@@ -48,7 +48,12 @@ def main():
     scores = np.zeros(R, dtype=np.int32); sinks = np.zeros((R, 2), dtype=np.uint32)
     u8p, u32p, i32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)
     use_ref = oracle.Reference.available()
+    # one thread per CPU this container may really use (min of the affinity mask and the cgroup quota), as bench.py's cpu_baseline
+    import bench
+    aff, quota = bench.host_cpu_share()
+    threads = max(1, min(aff, int(quota) if quota else aff))
     if use_ref:
+        oracle.Reference().set_num_threads(threads)
         L = oracle.Reference().lib
         cores = oracle.Reference().num_threads()
         # many-to-one: the batch entry points take per-job text offsets; give every job the same slice
@@ -62,6 +67,7 @@ def main():
                                          ctypes.c_uint32(R), ctypes.c_int32(-(1 << 30)), scores.ctypes.data_as(i32p), sinks.ctypes.data_as(u32p))
     else:
         O = oracle.Oracle()
+        O.set_num_threads(threads)
         cores = O.num_threads()
         sch = oracle.Scheme(2, 1, 1, -2, -1, -2, -1)
 

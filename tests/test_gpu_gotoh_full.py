@@ -429,3 +429,57 @@ def test_packed_pattern_blocking_kernel(amd, orc, typ, M, monkeypatch):
                     ok, s_, k_ = orc.full_gotoh(typ, 0, oracle.Scheme(*sv), reads[j], text[wb[j]:we[j]], q if use_q else None,
                                                int(min_scores[j]) if min_scores is not None else oracle.SCORE_MIN)
                     assert got_s[j] == s_ and tuple(got_k[j]) == k_, (sv, use_q, min_scores is not None, j, lens[j], wlen[j])
+
+
+@pytest.mark.parametrize("max_m", [8, 32, 64, 100, 128, 152, 200, 256])
+def test_cooperative_kernel_equals_the_oracle(amd, orc, max_m):
+    """full_gotoh_coop_kernel (several lanes per job, the boundary column in registers): GLOBAL and SEMI_GLOBAL without early exit, every
+    pattern-length bucket of its launcher with ragged patterns (1 .. max_m) and windows (0 .. 300 symbols), reversed / complemented reads, N
+    symbols, base qualities under a quality ramp, border gap terms that differ between pattern and text, both blockings, batches that end
+    inside a wave -- equal to the oracle job by job and to the one-lane-per-job kernel (NVBIO_ALN_NO_COOPERATIVE_DP)"""
+    rng = np.random.default_rng(1000 + max_m)
+    G = 50000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    for R in (1, 3, 517):
+        lens = rng.integers(1, max_m + 1, R); lens[0] = max_m
+        roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+        wb = rng.integers(0, G - 400, R).astype(np.uint32)
+        wl = rng.integers(1, 300, R); wl[R // 2] = 0 if R > 1 else wl[R // 2]
+        we = (wb + wl).astype(np.uint32)
+        reads = []
+        for k in range(R):
+            src = text[wb[k] + 5:wb[k] + 5 + lens[k]].copy() if rng.random() < 0.7 else rng.integers(0, 4, lens[k], dtype=np.uint8)
+            if len(src) < lens[k]:
+                src = rng.integers(0, 4, lens[k], dtype=np.uint8)
+            mut = rng.random(lens[k]) < 0.05; src[mut] = rng.integers(0, 4, int(mut.sum()))
+            if rng.random() < 0.2:
+                src[int(rng.integers(0, lens[k]))] = 4
+            reads.append(src.astype(np.uint8))
+        flat = np.concatenate(reads)
+        flags = rng.integers(0, 4, R).astype(np.uint8)
+        quals = rng.integers(0, 50, len(flat), dtype=np.uint8)
+        toffs = np.zeros(R + 1, dtype=np.uint32); toffs[1:] = np.cumsum(we - wb)
+        txts = np.concatenate([text[wb[k]:we[k]] for k in range(R)] + [np.zeros(0, dtype=np.uint8)])
+        # the oracle takes patterns as they are aligned: apply the read flags and the matching quality order
+        pats_o, quals_o = [], []
+        for k in range(R):
+            p_, q_ = reads[k], quals[roffs[k]:roffs[k + 1]]
+            if flags[k] & 1:
+                p_, q_ = p_[::-1], q_[::-1]
+            if flags[k] & 2:
+                p_ = np.where(p_ < 4, 3 - p_, p_)
+            pats_o.append(p_.astype(np.uint8)); quals_o.append(q_)
+        pats_o = np.concatenate(pats_o); quals_o = np.concatenate(quals_o)
+        for sv, use_q in (((2, 1, 1, -2, -1, -2, -1), False), ((0, 2, 6, -8, -3, -5, -2), True), ((1, 3, 3, -4, -2, -7, -1), False)):
+            for blocking in (0, 1):
+                for typ in (oracle.GLOBAL, oracle.SEMI_GLOBAL):
+                    if typ == oracle.SEMI_GLOBAL and sv[0] == 0:
+                        continue                                            # (match = 0 end-to-end: the shortcut's route, tested elsewhere)
+                    wsc, wsk = orc.full_gotoh_batch(typ, blocking, oracle.Scheme(*sv), pats_o, roffs, txts, toffs, quals=quals_o if use_q else None)
+                    for algo in (None, amd.ALN_NO_COOPERATIVE_DP):
+                        batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals if use_q else None, flags=flags,
+                                                   algo_flags=algo)
+                        sc, sk = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(typ, _scheme(amd, sv)), text_blocking=bool(blocking)).enact(batch, max_m, 300)
+                        bad = np.nonzero((sc.cpu().numpy() != wsc) | (amd.u32(sk) != wsk).any(axis=1))[0]
+                        assert len(bad) == 0, (max_m, R, sv, blocking, typ, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]], amd.u32(sk)[bad[:5]], wsk[bad[:5]],
+                                               lens[bad[:5]], (we - wb)[bad[:5]])
