@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 GPU_CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
-DP_ROW_INSTRUCTIONS = 360            # banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4,2,true>: instructions of one pass through the row loop (profiles/r02h_pk_row_loop.s)
+DP_ROW_INSTRUCTIONS = 323            # banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4,2,true,false,true> (binary16 lanes): instructions of one pass through the row loop
+                                     # (profiles/r03_pk_row_loop_f16.s; the int16 build: 353, profiles/r02h_pk_row_loop.s)
 SECTOR = 64                      # the unit the kernel's accounting instantiation counts gathers in (distinct 64-byte sectors)
 LINE = 128                       # bytes the fabric MOVES for one gather: every L2 miss of gfx950 is a 128-byte read request, whatever
                                  # the load's width, the memory's kind or the cache policy bits (TCC_EA0_RDREQ_128B = gathers, _64B = _32B = 0:
@@ -199,6 +200,33 @@ def run_configs(torch, amd, pipeline, fmi, genome, n, device, M, scale=1.0):
                                        "queries_per_s": Q / (ms_n * 1e-3), "alg_frac_of_hbm_peak": alg / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS},
                           "locate_every_hit": {"hits": int(total), "ms": ms_l}}
     del qs, blk, padded, sym, rnd, starts, flt
+    # ---- config 0's shape (sw-benchmark: 100 k x 100 bp patterns against ONE 4,096-symbol text, GLOBAL Gotoh(2,-1,-2,-1), text blocking): the config
+    #      itself is the reference's CPU plumbing (scripts/bench_config1.py times that leg beside it); here the GPU side -- 100 k jobs are too few for
+    #      a lane per job (1.5 waves per SIMD), the cooperative kernel gives a job four lanes -- checked against the oracle on a sample ----
+    J, PM, TN = int(100_000 * scale), 100, 4096
+    pats = torch.randint(0, 4, (J * PM,), device=device, generator=g, dtype=torch.uint8)
+    twords = torch.randint(-2 ** 31, 2 ** 31 - 1, (TN // 16 + 8,), dtype=torch.int64, device=device, generator=g).to(torch.int32)   # 2-bit packed, random
+    poffs = (torch.arange(J + 1, device=device) * PM).to(torch.int32)
+    bj = amd.AlignmentBatch(pack4(pats), 4, poffs, twords, 2, torch.zeros(J, dtype=torch.int32, device=device),
+                            torch.full((J,), TN, dtype=torch.int32, device=device), device=device)
+    op = amd.BatchedAlignmentScore(amd.make_gotoh_aligner(amd.GLOBAL, amd.SimpleGotohScheme(2, -1, -2, -1)), text_blocking=True)
+    ms0 = timed_ms(torch, lambda: op.enact(bj, PM, TN), reps=5, warm=1)
+    sc0, _ = op.enact(bj, PM, TN)
+    try:
+        import numpy as np
+        import oracle
+        O = oracle.Oracle()
+        smp = min(J, 256)
+        pn = pats[:smp * PM].cpu().numpy(); tn_ = genome_symbols(twords, torch.arange(TN, device=device)).cpu().numpy()
+        want, _ = O.full_gotoh_batch(oracle.GLOBAL, 1, oracle.Scheme(2, 1, 1, -2, -1, -2, -1), pn, (np.arange(smp + 1) * PM).astype(np.uint32),
+                                     np.tile(tn_, smp), (np.arange(smp + 1) * TN).astype(np.uint32))
+        equal = bool(np.array_equal(sc0[:smp].cpu().numpy(), want))
+    except Exception as e:                                            # (the oracle is the checker only)
+        equal = repr(e)
+    out["sw_benchmark_100k"] = {"jobs": J, "pattern_len": PM, "text_len": TN, "ms": ms0, "gcups": J * PM * TN / (ms0 * 1e-3) / 1e9,
+                                "kernel": "full_gotoh_coop_kernel<GLOBAL,4,25> (four lanes per job, boundary column in registers)",
+                                "scores_equal_oracle_sample": equal}
+    del pats, twords, poffs, bj
     # ---- config 4, one GPU's slice: 6.25 M pairs of (150, 181), band 31, LOCAL Gotoh match 2 / mismatch -6 (q >= 40) / gaps -8 -3 ----
     P = int(6_250_000 * scale)
     reads_sym, pos, rc = make_reads(genome, n, P, M, device, seed=4)
@@ -241,7 +269,27 @@ def run_configs(torch, amd, pipeline, fmi, genome, n, device, M, scale=1.0):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     paired = po["anchor"] >= 0
     conc = paired & (po["rc1"] != po["rc2"]) & ((po["pos1"] - po["pos2"]).abs() <= 500)
-    out["paired_end_1M"] = {"pairs": Pp, "ms": dt * 1e3, "pairs_per_s": Pp / dt, "paired_fraction": float(paired.float().mean()),
+    # nvBowtie's own paired-end loop (Aligner::best_approx, paired form) over the same pairs: the C++ host loop, anchors iterated with the
+    # pair-tightened threshold, the opposite mate scored for every anchor that passes (scores only: no traceback in this leg)
+    loop = None
+    try:
+        s1 = pipeline.ReadBatch(pack4(torch.where(swap[:, None], m2, m1).flip(1).reshape(-1)), Pp, M)       # nvBowtie stores reads reversed
+        s2 = pipeline.ReadBatch(pack4(torch.where(swap[:, None], m1, m2).flip(1).reshape(-1)), Pp, M)
+        pipeline.nvbowtie_best_approx_paired_host(fmi, genome, n, s1, s2, pparams)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        lp = pipeline.nvbowtie_best_approx_paired_host(fmi, genome, n, s1, s2, pparams)
+        torch.cuda.synchronize(); dl = time.perf_counter() - t0
+        a1 = lp["best_a"][:, 0]; o1 = lp["best_o"][:, 0]
+        is_pair = ((a1[:, 3] >> 2) & 1) == 1
+        loop = {"ms": dl * 1e3, "pairs_per_s": Pp / dl, "paired_fraction": float(is_pair.float().mean()), "n_extensions": lp["n_extensions"],
+                "n_opposite_alignments": lp["n_opposite"], "passes": lp["passes"],
+                "best_pair_score_equals_composition": float(((a1[:, 0] + o1[:, 0]).to(torch.int64)[is_pair & paired] ==
+                                                             (po["score1"] + po["score2"]).to(torch.int64)[is_pair & paired]).float().mean()),
+                "host": "nvbio_host_best_approx_paired (lib/libnvbio_amd_host.so): aligner_best_approx_paired.h:84-200,590-1000"}
+        del s1, s2, lp
+    except Exception as e:
+        loop = {"error": repr(e)}
+    out["paired_end_1M"] = {"pairs": Pp, "ms": dt * 1e3, "nvbowtie_loop": loop, "pairs_per_s": Pp / dt, "paired_fraction": float(paired.float().mean()),
                             "concordant_fraction": float(conc.float().mean()), "with_cigars_of_both_mates": True,
                             "composition": "pipeline.paired_end: each mate anchored in turn (seed + banded extend), the other by full-matrix DP in nvBowtie's "
                                            "opposite-mate window, best pair, both mates traced back"}
@@ -678,7 +726,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "u32 (FM-index coordinates) / i16x2 (band-31 DP, two alignments per 32-bit lane; exact, bound-checked on the host)",
+        "dtype": "u32 (FM-index coordinates) / i16x2 (band-31 DP, two alignments per 32-bit lane: 16-bit integer scores, held in binary16 lanes where every score is an integer of magnitude <= 2040 -- exact -- and in int16 lanes otherwise; bound-checked on the host)",
         "data": "synthetic",
         "config": {"workload": ("nvbowtie-se-150bp-3gbp" if (n == 3_000_000_000 and R == 10_000_000 and M == 150 and not args.repeat_family) else "custom"),
                    "ref_len": n, "reads_per_gpu": R, "read_len": M, "seed_len": params.seed_len,
@@ -730,16 +778,16 @@ def main():
                                              "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "extend": {"kernel": ("ungapped_e2e31_kernel<4> (31 diagonals by XOR + popcount on bit planes; settles every candidate whose best diagonal "
                               "beats any gapped alignment) + banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4> over the rest (two alignments per lane, "
-                              "int16 packed)") if args.mode == "e2e" else
+                              "binary16 packed: exact for these scores, v_pk_maximum3_f16)") if args.mode == "e2e" else
                              "banded_gotoh_band31_pk_kernel<LOCAL,4> (two alignments per lane, int16 packed)",
-                   "bound": "valu (integer; MFMA not applicable)",
+                   "bound": "valu (packed 16-bit lanes; MFMA not applicable)",
                    "candidates_per_step": int(nc), "cells_per_step": cells, "ms": extend_ms,
                    # GCUPS of the DP kernel itself: the A/B run below, where the DP computes every cell of every candidate
                    "gcups": plain.get("extend_gcups") if plain else None,
                    # cells of the full band DP / time of the step's extension stage, in which the exact shortcuts settle most candidates
                    "effective_gcups": cells / (extend_ms * 1e-3) / 1e9 if extend_ms > 0 else 0.0,
                    # what bounds the DP kernel: VALU issue.  One row of a wave = 64 lanes x 2 alignments x 31 cells in DP_ROW_INSTRUCTIONS
-                   # instructions (the row loop's listing: profiles/r02h_pk_row_loop.s), 4 cycles each on a 16-lane SIMD, 1024 SIMDs
+                   # instructions (the row loop's listing: profiles/r03_pk_row_loop_f16.s), 4 cycles each on a 16-lane SIMD, 1024 SIMDs
                    "dp_issue_bound": (lambda peak: {"instructions_per_row": DP_ROW_INSTRUCTIONS, "cells_per_wave_row": 64 * 2 * 31,
                                                      "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": GPU_CLOCK_GHZ, "peak_gcups": peak,
                                                      "frac": (plain.get("extend_gcups") / peak) if plain and plain.get("extend_gcups") else None})(

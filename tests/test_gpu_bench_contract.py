@@ -57,6 +57,7 @@ def test_bench_json_contract(extra):
     # BASELINE configs 2, 4, 5 at kernel / composition level, in the same line
     cf = d["configs"]
     assert "error" not in cf, cf
+    assert cf["sw_benchmark_100k"]["gcups"] > 0 and cf["sw_benchmark_100k"]["scores_equal_oracle_sample"] is True
     assert cf["fm_seeds_1M"]["queries_per_s"] > 0 and 0.0 < cf["fm_seeds_1M"]["no_table"]["alg_frac_of_hbm_peak"] <= 1.0
     assert cf["banded_local_6.25M"]["gcups"] > 0 and 0.0 < cf["banded_local_6.25M"]["dp_issue_frac"] <= 1.0
     assert cf["paired_end_1M"]["pairs_per_s"] > 0 and cf["paired_end_1M"]["concordant_fraction"] > 0.9
