@@ -721,6 +721,8 @@ enum
     NVBIO_ALN_NO_LENGTH_SORT        = 8192, /* with NVBIO_ALN_RAGGED_READS: the DP's job list in batch order instead of ascending read length (A/B)   */
     NVBIO_ALN_NO_QUALITY_SHORTCUT   = 2048, /* band-31 end-to-end scoring of reads WITH base qualities under a quality-dependent mismatch penalty
                                               (nvBowtie's default ramp): every job through the DP, as before round 3 (A/B)          */
+    NVBIO_ALN_NO_GAP_CHANCE         = 65536, /* band-31 end-to-end scoring: jobs without a near-clean diagonal (reads with an indel) go to the DP instead of the
+                                               exact evaluation of their one-gap alignments (gap_chance_e2e31_kernel) (A/B)                               */
     NVBIO_ALN_NO_COOPERATIVE_DP     = 32768, /* full-matrix GLOBAL / SEMI_GLOBAL scoring: one lane per job and the boundary column in memory even where the
                                                several-lanes-per-job kernel (boundary in registers, no scratch) applies (A/B)                           */
     NVBIO_ALN_NO_F16_DP             = 16384, /* packed band-31 DP with 16-bit INTEGER lanes even where the binary16 lanes (exact while every score is an integer of

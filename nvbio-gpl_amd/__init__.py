@@ -34,7 +34,7 @@ TRACEBACK_SINKS_GIVEN = 1
 # nvbio_alignment_batch::algo_flags (which exact shortcuts / kernel variants a call may use; results do not depend on them)
 ALN_NO_UNGAPPED_SCORE, ALN_NO_THIRD_CHANCE, ALN_NO_PACKED_DP, ALN_FORCE_PACKED_DP, ALN_NO_UNGAPPED_TRACEBACK, ALN_PK_THREE_WAVES = 1, 2, 4, 8, 16, 32
 ALN_NO_NARROW_TRACEBACK, ALN_NO_SECOND_CHANCE, ALN_PK_STRIPE8, ALN_NO_NARROW_SCORE, ALN_NO_BAND_ROUTE = 64, 128, 256, 512, 1024
-ALN_NO_QUALITY_SHORTCUT, ALN_RAGGED_READS, ALN_NO_LENGTH_SORT, ALN_NO_F16_DP, ALN_NO_COOPERATIVE_DP = 2048, 4096, 8192, 16384, 32768
+ALN_NO_QUALITY_SHORTCUT, ALN_RAGGED_READS, ALN_NO_LENGTH_SORT, ALN_NO_F16_DP, ALN_NO_COOPERATIVE_DP, ALN_NO_GAP_CHANCE = 2048, 4096, 8192, 16384, 32768, 65536
 DEFAULT_ALGO_FLAGS = 0          # what an AlignmentBatch is created with unless told otherwise (tests set it for a whole run)
 BACKTRACK_REFERENCE_QUIRKS = 1
 

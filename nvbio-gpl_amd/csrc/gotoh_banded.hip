@@ -769,7 +769,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
         // always: its other words are evaluated only if SOME lane is still interested (a wave-uniform branch) -- 24 of 31 diagonals cost one
         // word instead of six.  The text planes are taken d symbols on with one funnel shift per word (d is a constant of the unrolled loop).
         const int64_t floor_u = 3 * (int64_t)(G < gap_open ? G : gap_open) - P;          // U <= floor_u: DP whatever else holds
-        const uint32_t cap = (uint32_t)((-floor_u - 1) / (int64_t)P);                   // the largest count with -P cnt > floor_u
+        const uint32_t cap = P > 0 ? (uint32_t)((-floor_u - 1) / (int64_t)P) : 0xFFFFFFFEu;   // the largest count with -P cnt > floor_u
         uint32_t cnt_d[QUAL ? 31 : 1];
         #pragma unroll
         for (uint32_t d = 0; d < 31u; ++d)
@@ -794,7 +794,14 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
             if (QUAL) cnt_d[d] = on ? cnt : 0xFFFFFFFFu;
             if (on && cnt <= best_cnt) { best_cnt = cnt; best_d = d; }     // ties: the larger column, as BestSink's `<=`
         }
-        if (best_cnt > cap) { need_dp[job] = 1; return; }           // (includes: no diagonal evaluated)
+        if (best_cnt > cap)                                          // (includes: no diagonal evaluated)
+        {
+            // no diagonal within reach of the three chances: typically a read with an indel.  The gap chance (gap_chance_e2e31_kernel, its own
+            // list pass) evaluates the one-gap alignments of such a job exactly; it needs every diagonal inside the text and plain gap terms
+            const bool gap_chance = !QUAL && P > 0 && N >= M + 30u && gap_ext < 0 && gap_open <= gap_ext && !(b.algo & NVBIO_ALN_NO_GAP_CHANCE);
+            need_dp[job] = gap_chance ? 4 : 1;
+            return;
+        }
         U = -(int64_t)P * (int64_t)best_cnt;
         if (QUAL)
         {
@@ -1056,6 +1063,221 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
     else need_dp[job] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The GAP chance (need_dp = 4: no diagonal of the window has few enough mismatches for the three chances above -- a read with an indel, its
+// two candidate windows, four fifths of what used to reach the DP).  Same setting (SEMI_GLOBAL, match 0, one penalty P, plain gap terms,
+// all 31 diagonals inside the text); with Cg(g) = -(open + (g-1) ext) the cost of a gap of g symbols, an alignment costs the sum of its gaps'
+// Cg plus P per mismatch, and the classes of alignments are ordered by that cost.  EVALUATED exactly: ONE gap of g <= 5 symbols with e <= 2
+// mismatches, by the lead / tail argument of the other chances taken to the third mismatch -- with lead_i(d) / tail_i(d) = the rows before
+// the (i+1)-th / after the (i+1)-th-from-last mismatch of diagonal d, a text gap (prefix on d-g, suffix on d, ending in column d) with <= e
+// mismatches exists iff lead_i(d-g) + tail_{e-i}(d) >= M for some i <= e, a pattern gap (prefix on d, suffix on d-g, ending in d-g) iff
+// lead_i(d) + tail_{e-i}(d-g) + g >= M.  The minimum c* over all of them and the LARGEST end column among the members that reach it are the
+// DP's optimum and BestSink's sink, PROVIDED no other alignment costs <= c*:
+//   * ungapped: every diagonal has more than `cap` mismatches (why the job is here): >= (cap + 1) P;
+//   * one gap with 3 mismatches, or of 6 symbols: Cg(1) + 3 P, Cg(6);  three gaps: 3 Cg(1);  two gaps and a mismatch: 2 Cg(1) + P;
+//     two gaps of (1,3) / (2,2) or more: Cg(1) + Cg(3), 2 Cg(2)          -- c_unk = the least of these; c* < c_unk is required;
+//   * two gaps of (1,1) or (1,2) / (2,1) symbols without a mismatch (costs 2 Cg(1), Cg(1) + Cg(2)): EXISTENCE is tested (over-approximated)
+//     through the middle diagonal b as in the third chance: the prefix on a neighbour a may run to row lo, the suffix on a neighbour c may start
+//     at row hi, a member exists iff lo >= hi or b has no mismatch in rows [lo, hi); one that costs <= c* sends the job to the DP.
+// Anything else -- c* >= c_unk, no member at all, a two-gap member in reach -- is the DP's.  Over-approximation only ever costs a DP.
+// ---------------------------------------------------------------------------------------------
+template <int RBITS>
+__global__ void __launch_bounds__(256)
+gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
+                        int32_t* __restrict__ scores, uint2* __restrict__ sinks, uint8_t* __restrict__ need_dp,
+                        const uint32_t* __restrict__ job_list, const uint32_t* __restrict__ job_count)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= *job_count) return;
+    const uint32_t job = job_list[slot];
+    const uint32_t rid   = b.read_id ? b.read_id[job] : job;
+    const uint32_t first = b.read_offsets[rid];
+    const uint32_t M     = b.read_offsets[rid + 1] - first;
+    const uint32_t fl    = b.flags ? b.flags[job] : 0u;
+    const bool     rev   = (fl & NVBIO_READ_REVERSE) != 0;
+    const bool     comp  = (fl & NVBIO_READ_COMPLEMENT) != 0;
+    const uint32_t tb    = b.win_begin[job];
+    const uint32_t N     = b.win_end[job] - tb;
+    // (flagged by the first pass: 1 <= M <= 161, N >= M + 30, P > 0, open <= ext < 0)
+
+    uint32_t pl[6], ph[6], pn[6], pm[6], ql[7], qh[7];
+    {
+        uint64_t rlo[3], rhi[3], rn[3], tlo[4], thi[4];
+        {
+            ReadWords<RBITS> rw; TextWords13 tw;
+            load_read_words<RBITS>( b.reads, first, M, rw );
+            load_text_words13( b.text, tb, N < 192u ? N : 192u, tw );
+            read_planes192<RBITS>( rw, first, M, rev, comp, rlo, rhi, rn );
+            text_planes208( tw, tb, tlo, thi );
+        }
+        #pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            const int32_t left = (int32_t)M - 64 * k;
+            const uint64_t mask = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+            pl[2*k] = (uint32_t)rlo[k]; pl[2*k+1] = (uint32_t)(rlo[k] >> 32);
+            ph[2*k] = (uint32_t)rhi[k]; ph[2*k+1] = (uint32_t)(rhi[k] >> 32);
+            pm[2*k] = (uint32_t)mask;   pm[2*k+1] = (uint32_t)(mask >> 32);
+            pn[2*k] = (uint32_t)rn[k] & pm[2*k]; pn[2*k+1] = (uint32_t)(rn[k] >> 32) & pm[2*k+1];
+            ql[2*k] = (uint32_t)tlo[k]; ql[2*k+1] = (uint32_t)(tlo[k] >> 32);
+            qh[2*k] = (uint32_t)thi[k]; qh[2*k+1] = (uint32_t)(thi[k] >> 32);
+        }
+        ql[6] = (uint32_t)tlo[3]; qh[6] = (uint32_t)thi[3];
+    }
+
+    // the cost ladder
+    constexpr int GA = 5;
+    const int32_t go = gap_open, ge = gap_ext;
+    int32_t cg[GA + 2];                                          // cg[g] = cost of a gap of g symbols
+    #pragma unroll
+    for (int g = 1; g <= GA + 1; ++g) cg[g] = -(go + (g - 1) * ge);
+    cg[0] = 0;
+    const int64_t floor_u = 3 * (int64_t)(G < gap_open ? G : gap_open) - P;
+    const int32_t cap = (int32_t)((-floor_u - 1) / (int64_t)P);
+    int32_t c_unk = (cap + 1) * P;
+    {
+        const int32_t others[] = { cg[1] + 3 * P, cg[GA + 1], 3 * cg[1], 2 * cg[1] + P, cg[1] + cg[3], 2 * cg[2] };
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) c_unk = others[k] < c_unk ? others[k] : c_unk;
+    }
+    const int32_t cost11 = 2 * cg[1], cost12 = cg[1] + cg[2];
+
+    // mismatch word k (rows 32 k .. 32 k + 31) of diagonal x: the text planes x symbols on (x is wave-uniform: one funnel shift per plane word)
+    auto mmw = [&](const int k, const uint32_t x) -> uint32_t {
+        const uint32_t tl = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], x ), th = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], x );
+        return (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k];
+    };
+    // history of the last GA diagonals (slot k: diagonal d - 1 - k): (lead0, lead1, lead2) and (tail0, tail1, tail2) packed a byte each (<= 161)
+    uint32_t Lp[GA], Tp[GA];
+    #pragma unroll
+    for (int k = 0; k < GA; ++k) { Lp[k] = 0; Tp[k] = 0; }
+    uint32_t hot = 0;                                            // bit k: slot k's diagonal could be half of a one-gap alignment
+    int32_t best_cost = 0x7FFFFFFF; uint32_t best_end = 0;
+    bool ex11 = false, ex12 = false;
+    const int32_t Mi = (int32_t)M;
+    // lead_i(a) + tail_j(c) + g >= M with g <= GA needs one of the two at least (M - GA) / 2: only such diagonals are looked at pair by pair
+    const int32_t hot_thr = (Mi - GA) / 2;
+
+    // no mismatch of diagonal x in rows [lo, hi)?  (lo >= hi: an empty middle segment -- counted as a member.)  f2 / l2: its third mismatch from
+    // either end (M / -1 if it has fewer): nearly always one of them lies inside and no word is looked at
+    auto clean = [&](const uint32_t x, const int32_t bf, const int32_t bl, const int32_t lo, const int32_t hi) -> bool {
+        if (lo >= hi) return true;
+        if ((bf >= lo && bf < hi) || (bl >= lo && bl < hi)) return false;
+        bool any = false;
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            const int32_t a0 = lo - 32 * k > 0 ? lo - 32 * k : 0, a1 = hi - 32 * k < 32 ? hi - 32 * k : 32;
+            if (a0 < a1)
+            {
+                const uint32_t hi_m = (a1 >= 32) ? 0xFFFFFFFFu : ((1u << a1) - 1u);
+                const uint32_t lo_m = (1u << a0) - 1u;
+                any = any || ((mmw( k, x ) & hi_m & ~lo_m) != 0u);
+            }
+        }
+        return !any;
+    };
+
+    for (uint32_t d = 0; d <= 32u; ++d)
+    {
+        const bool have = d < 31u;
+        // the first three and the last three mismatching rows of diagonal d, searched from the two ends only as far as some lane of the wave
+        // still needs (a diagonal that is not the read's own holds three mismatches in its first and in its top word)
+        uint32_t f0 = M, f1 = M, f2 = M, l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu;
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (have && __any( f2 == M && pm[k] != 0u ))
+            {
+                uint32_t w = (f2 == M) ? mmw( k, d ) : 0u;
+                if (f0 == M && w) { f0 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                if (f0 != M && f1 == M && w) { f1 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                if (f1 != M && f2 == M && w) f2 = 32u * k + (uint32_t)__builtin_ctz( w );
+            }
+        #pragma unroll
+        for (int k = 5; k >= 0; --k)
+            if (have && __any( l2 == 0xFFFFFFFFu && pm[k] != 0u ))
+            {
+                uint32_t w = (l2 == 0xFFFFFFFFu) ? mmw( k, d ) : 0u;
+                if (l0 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l0 = 32u * k + t; w &= ~(1u << t); }
+                if (l0 != 0xFFFFFFFFu && l1 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l1 = 32u * k + t; w &= ~(1u << t); }
+                if (l1 != 0xFFFFFFFFu && l2 == 0xFFFFFFFFu && w) l2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
+            }
+        const int32_t L0 = (int32_t)f0, L1 = (int32_t)f1, L2 = (int32_t)f2;          // rows before the 1st / 2nd / 3rd mismatch
+        const int32_t T0 = l0 == 0xFFFFFFFFu ? Mi : Mi - 1 - (int32_t)l0;             // rows after the last / last-but-one / last-but-two
+        const int32_t T1 = l1 == 0xFFFFFFFFu ? Mi : Mi - 1 - (int32_t)l1;
+        const int32_t T2 = l2 == 0xFFFFFFFFu ? Mi : Mi - 1 - (int32_t)l2;
+        const bool hot_d = have && (L2 >= hot_thr || T2 >= hot_thr);
+
+        if (have && __any( hot_d || (hot & 31u) != 0u ))
+        {
+            #pragma unroll
+            for (int g = 1; g <= GA; ++g)
+                if (d >= (uint32_t)g && (hot_d || ((hot >> (g - 1)) & 1u)))
+                {
+                    const int32_t a0 = (int32_t)(Lp[g - 1] & 255u), a1 = (int32_t)((Lp[g - 1] >> 8) & 255u), a2 = (int32_t)(Lp[g - 1] >> 16);
+                    const int32_t t0 = (int32_t)(Tp[g - 1] & 255u), t1 = (int32_t)((Tp[g - 1] >> 8) & 255u), t2 = (int32_t)(Tp[g - 1] >> 16);
+                    // text gap of g: diagonal d - g, then d; ends in column d
+                    if (a2 + T2 >= Mi)
+                    {
+                        int32_t e = 3;
+                        if (a0 + T0 >= Mi) e = 0;
+                        else if (a0 + T1 >= Mi || a1 + T0 >= Mi) e = 1;
+                        else if (a0 + T2 >= Mi || a1 + T1 >= Mi || a2 + T0 >= Mi) e = 2;
+                        if (e < 3)
+                        {
+                            const int32_t c = cg[g] + e * P;
+                            if (c < best_cost || (c == best_cost && d > best_end)) { best_cost = c; best_end = d; }
+                        }
+                    }
+                    // pattern gap of g: diagonal d, then d - g; ends in column d - g
+                    if (L2 + t2 + g >= Mi)
+                    {
+                        int32_t e = 3;
+                        if (L0 + t0 + g >= Mi) e = 0;
+                        else if (L0 + t1 + g >= Mi || L1 + t0 + g >= Mi) e = 1;
+                        else if (L0 + t2 + g >= Mi || L1 + t1 + g >= Mi || L2 + t0 + g >= Mi) e = 2;
+                        if (e < 3)
+                        {
+                            const int32_t c = cg[g] + e * P;
+                            const uint32_t end = d - (uint32_t)g;
+                            if (c < best_cost || (c == best_cost && end > best_end)) { best_cost = c; best_end = end; }
+                        }
+                    }
+                }
+        }
+        // two gaps around the middle diagonal bm = d - 2 (history slot 1): neighbours bm - 2 (slot 3), bm - 1 (slot 2), bm + 1 (slot 0),
+        // bm + 2 (this diagonal)
+        if (d >= 2u)
+        {
+            const uint32_t bm = d - 2u;                            // <= 30
+            const int32_t NEG = -(1 << 20), POS = 1 << 20;
+            int32_t lo1 = NEG, lo2 = NEG, hi1 = POS, hi2 = POS;
+            if (bm >= 1u)       { lo1 = (int32_t)(Lp[2] & 255u);    hi1 = Mi - (int32_t)(Tp[2] & 255u) - 1; }      // a = bm - 1: text gap in; c = bm - 1: pattern gap out
+            if (bm + 1u <= 30u) { const int32_t x = (int32_t)(Lp[0] & 255u) + 1, y = Mi - (int32_t)(Tp[0] & 255u); lo1 = x > lo1 ? x : lo1; hi1 = y < hi1 ? y : hi1; }
+            if (bm >= 2u)       { lo2 = (int32_t)(Lp[3] & 255u);    hi2 = Mi - (int32_t)(Tp[3] & 255u) - 2; }      // a / c = bm - 2
+            if (have)           { const int32_t x = L0 + 2, y = Mi - T0; lo2 = x > lo2 ? x : lo2; hi2 = y < hi2 ? y : hi2; }   // a / c = bm + 2
+            // the middle diagonal's third mismatch from either end (first / last if it has fewer): a row that is NOT clean
+            const int32_t b2 = (int32_t)(Lp[1] >> 16), b1 = (int32_t)((Lp[1] >> 8) & 255u), b0 = (int32_t)(Lp[1] & 255u);
+            const int32_t bf = b2 < Mi ? b2 : (b1 < Mi ? b1 : b0);
+            const int32_t e2 = (int32_t)(Tp[1] >> 16), e1 = (int32_t)((Tp[1] >> 8) & 255u), e0 = (int32_t)(Tp[1] & 255u);
+            const int32_t et = e2 < Mi ? e2 : (e1 < Mi ? e1 : e0);
+            const int32_t bl = et < Mi ? Mi - 1 - et : NEG;
+            if (lo1 > NEG && hi1 < POS) ex11 = ex11 || clean( bm, bf, bl, lo1, hi1 );
+            if (lo1 > NEG && hi2 < POS) ex12 = ex12 || clean( bm, bf, bl, lo1, hi2 );
+            if (lo2 > NEG && hi1 < POS) ex12 = ex12 || clean( bm, bf, bl, lo2, hi1 );
+        }
+        // shift the history
+        #pragma unroll
+        for (int k = GA - 1; k > 0; --k) { Lp[k] = Lp[k - 1]; Tp[k] = Tp[k - 1]; }
+        Lp[0] = (uint32_t)L0 | ((uint32_t)L1 << 8) | ((uint32_t)L2 << 16);
+        Tp[0] = (uint32_t)T0 | ((uint32_t)T1 << 8) | ((uint32_t)T2 << 16);
+        hot = (hot << 1) | (hot_d ? 1u : 0u);
+    }
+    const bool settled = best_cost < c_unk && !(ex11 && cost11 <= best_cost) && !(ex12 && cost12 <= best_cost);
+    if (settled) { scores[job] = -best_cost; sinks[job] = make_uint2( M + best_end, M ); need_dp[job] = 0; }
+    else need_dp[job] = 1;
+}
+
 // host-side conditions of the shortcut: SEMI_GLOBAL, match = 0, one mismatch penalty for every quality,
 // non-positive gap terms
 static bool ungapped_ok(const SchemeDev& sc, const BatchDev& b, int32_t* P, bool* by_quality)
@@ -1204,6 +1426,11 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         const FlagIs is3 = { nullptr, 3 }, is2 = { nullptr, 2 };
         NVB_HIP( hipcub::DevicePartition::If( nullptr, part_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, nowhere, (uint32_t*)nullptr, (int)b.n, is3, is2, s ) );
         if (part_bytes > sel_bytes) sel_bytes = part_bytes;
+        {
+            size_t if_bytes = 0;
+            NVB_HIP( hipcub::DeviceSelect::If( nullptr, if_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, is3, s ) );
+            if (if_bytes > sel_bytes) sel_bytes = if_bytes;
+        }
         if (hipMallocAsync( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1237,6 +1464,17 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
             if (e == hipSuccess && third)
                 hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,2>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
                                     (const uint32_t*)list_t, (const uint32_t*)(count_st + 1) );
+        }
+        if (e == hipSuccess && !by_quality && !(b.algo & NVBIO_ALN_NO_GAP_CHANCE))
+        {
+            // the jobs without a diagonal in reach of those chances (need_dp == 4: reads with an indel, mostly): the gap chance over their list
+            // (the second chance's list and counter have been consumed: reused)
+            const FlagIs f4 = { need_dp, 4 };
+            size_t sb = sel_bytes;
+            e = hipcub::DeviceSelect::If( sel_temp, sb, ids, list_s, count_st, (int)b.n, f4, s );
+            if (e == hipSuccess)
+                hipLaunchKernelGGL( (gap_chance_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                    (const uint32_t*)list_s, (const uint32_t*)count_st );
         }
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)

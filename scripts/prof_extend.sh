@@ -13,7 +13,7 @@ import csv, glob, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 fs = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
 rows = list(csv.DictReader(open(fs[0])))
-keep = [r for r in rows if any(k in r["Name"] for k in ("ungapped", "gotoh", "fm_seed", "DevicePartition", "partition", "select", "candidate", "windows", "mapq", "unpack", "job_", "scan", "Scan"))]
+keep = [r for r in rows if any(k in r["Name"] for k in ("ungapped", "gotoh", "fm_seed", "DevicePartition", "partition", "select", "candidate", "windows", "mapq", "unpack", "job_", "scan", "Scan", "gap_chance"))]
 with open(os.path.join(out, tag + "_kernels.txt"), "w") as f:
     for r in keep:
         line = "%-150s calls %5s avg_ms %9.4f total_ms %9.3f" % (r["Name"][:150], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6)

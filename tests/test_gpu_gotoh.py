@@ -462,3 +462,57 @@ def test_jobs_longer_than_the_declared_bound_are_rejected(amd, orc, typ):
         batch = amd.AlignmentBatch(orc.pack4(reads), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=mrl)
         sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(typ, scheme), batch)
         assert np.array_equal(sc.cpu().numpy(), want_s) and np.array_equal(amd.u32(sk), want_k)
+
+
+def test_gap_chance_on_reads_with_indels(amd, orc):
+    """the gap chance (one-gap alignments of a job without a near-clean diagonal, evaluated exactly): reads with ONE indel of 1-7 symbols
+    anywhere and 0-3 substitutions, reads with TWO indels of 1-2 symbols (the two-gap classes it must rule out or hand to the DP), indels
+    inside homopolymers and short tandem repeats (several placements and end columns tie), reads whose best alignment is worse than anything
+    it evaluates -- several schemes (which classes lie below the cheapest unknown one depends on the numbers), with and without the chance:
+    scores and sinks equal the reference algorithm's"""
+    rng = np.random.default_rng(4242)
+    G = 600000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    runs = rng.integers(200, G - 400, 400)                          # homopolymers and period-2/3 runs sprinkled over the text
+    for p0 in runs:
+        L = int(rng.integers(5, 30)); unit = rng.integers(0, 4, int(rng.integers(1, 4))).astype(np.uint8)
+        text[p0:p0 + L] = np.resize(unit, L)
+    M = 150
+    reads, wbs = [], []
+
+    def mutate(r, k):
+        if k:
+            pos = rng.choice(len(r), k, replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, k)) % 4
+        return r
+
+    def with_indel(src, at, g, ins):
+        return np.concatenate([src[:at], rng.integers(0, 4, g, dtype=np.uint8), src[at:]]) if ins else np.concatenate([src[:at], src[at + g:]])
+
+    for j in range(6000):
+        near_run = j % 3 == 0
+        p0 = int(runs[j % len(runs)] - rng.integers(20, 120)) if near_run else int(rng.integers(100, G - 400))
+        src = text[p0:p0 + M + 16].copy()
+        kind = j % 10
+        if kind < 7:                                                # one indel
+            g = int(rng.integers(1, 8)); at = int(rng.integers(1, M - 8))
+            r = with_indel(src, at, g, rng.random() < 0.5)[:M]
+            r = mutate(r.copy(), int(rng.integers(0, 4)))
+        elif kind < 9:                                              # two indels
+            a1, a2 = sorted(rng.integers(2, M - 6, 2)); g1, g2 = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+            r = with_indel(with_indel(src, int(a2), g2, rng.random() < 0.5), int(a1), g1, rng.random() < 0.5)[:M]
+            r = mutate(r.copy(), int(rng.integers(0, 2)))
+        else:                                                       # many substitutions, no indel
+            r = mutate(src[:M].copy(), int(rng.integers(5, 12)))
+        reads.append(r.astype(np.uint8)); wbs.append(p0 - 15 + int(rng.integers(-6, 7)))
+    R = len(reads)
+    flat = np.concatenate(reads)
+    roffs = (np.arange(R + 1) * M).astype(np.uint32)
+    wb = np.array(wbs, dtype=np.uint32); we = (wb + 31 + M).astype(np.uint32)
+    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 2, 2, -5, -1, -5, -1), (0, 4, 4, -6, -6, -6, -6), (0, 3, 3, -4, -2, -4, -2), (0, 6, 6, -5, -3, -5, -3)):
+        wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we)
+        for algo in (None, amd.ALN_NO_GAP_CHANCE):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M, algo_flags=algo)
+            sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+            bad = np.nonzero((sc.cpu().numpy() != wsc) | (amd.u32(sk) != wsk).any(axis=1))[0]
+            assert len(bad) == 0, (sv, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]], amd.u32(sk)[bad[:5]], wsk[bad[:5]])
+    assert ((wsc < -8) & (wsc > -60)).mean() > 0.5
