@@ -1147,6 +1147,27 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
         const uint32_t tl = __builtin_amdgcn_alignbit( ql[k + 1], ql[k], x ), th = __builtin_amdgcn_alignbit( qh[k + 1], qh[k], x );
         return (((pl[k] ^ tl) | (ph[k] ^ th)) & pm[k]) | pn[k];
     };
+    // the read's LAST 32 rows (rows base .. base + 31; all of them if it has fewer) and the 62 text symbols they can meet, as words of their own:
+    // bit j of (plT, phT, pnT, pmT) = row base + j, bit j of (qlT, qhT) = text symbol base + j
+    const uint32_t base = M >= 32u ? M - 32u : 0u;
+    uint32_t plT, phT, pnT, pmT, qlT[2], qhT[2];
+    {
+        const uint32_t bw = base >> 5, bs = base & 31u;
+        uint32_t a[4] = { 0, 0, 0, 0 }, c[4] = { 0, 0, 0, 0 }, t[3] = { 0, 0, 0 }, u[3] = { 0, 0, 0 };
+        #pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (bw == (uint32_t)k)
+            {
+                a[0] = pl[k]; a[1] = k + 1 < 6 ? pl[k + 1] : 0u; a[2] = ph[k]; a[3] = k + 1 < 6 ? ph[k + 1] : 0u;
+                c[0] = pn[k]; c[1] = k + 1 < 6 ? pn[k + 1] : 0u; c[2] = pm[k]; c[3] = k + 1 < 6 ? pm[k + 1] : 0u;
+                t[0] = ql[k]; t[1] = k + 1 < 7 ? ql[k + 1] : 0u; t[2] = k + 2 < 7 ? ql[k + 2] : 0u;
+                u[0] = qh[k]; u[1] = k + 1 < 7 ? qh[k + 1] : 0u; u[2] = k + 2 < 7 ? qh[k + 2] : 0u;
+            }
+        plT = __builtin_amdgcn_alignbit( a[1], a[0], bs ); phT = __builtin_amdgcn_alignbit( a[3], a[2], bs );
+        pnT = __builtin_amdgcn_alignbit( c[1], c[0], bs ); pmT = __builtin_amdgcn_alignbit( c[3], c[2], bs );
+        qlT[0] = __builtin_amdgcn_alignbit( t[1], t[0], bs ); qlT[1] = __builtin_amdgcn_alignbit( t[2], t[1], bs );
+        qhT[0] = __builtin_amdgcn_alignbit( u[1], u[0], bs ); qhT[1] = __builtin_amdgcn_alignbit( u[2], u[1], bs );
+    }
     // history of the last GA diagonals (slot k: diagonal d - 1 - k): (lead0, lead1, lead2) and (tail0, tail1, tail2) packed a byte each (<= 161)
     uint32_t Lp[GA], Tp[GA];
     #pragma unroll
@@ -1181,27 +1202,44 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
     for (uint32_t d = 0; d <= 32u; ++d)
     {
         const bool have = d < 31u;
-        // the first three and the last three mismatching rows of diagonal d, searched from the two ends only as far as some lane of the wave
-        // still needs (a diagonal that is not the read's own holds three mismatches in its first and in its top word)
+        // the first three and the last three mismatching rows of diagonal d.  A diagonal that is not the read's own (or its partner across the
+        // indel) holds three mismatches in its first 32 and in its last 32 rows: those two words decide, branch-free; only where some lane of
+        // the wave found fewer are the words walked from both ends, as far as some lane still needs
         uint32_t f0 = M, f1 = M, f2 = M, l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu;
-        #pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (have && __any( f2 == M && pm[k] != 0u ))
-            {
-                uint32_t w = (f2 == M) ? mmw( k, d ) : 0u;
-                if (f0 == M && w) { f0 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
-                if (f0 != M && f1 == M && w) { f1 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
-                if (f1 != M && f2 == M && w) f2 = 32u * k + (uint32_t)__builtin_ctz( w );
-            }
-        #pragma unroll
-        for (int k = 5; k >= 0; --k)
-            if (have && __any( l2 == 0xFFFFFFFFu && pm[k] != 0u ))
-            {
-                uint32_t w = (l2 == 0xFFFFFFFFu) ? mmw( k, d ) : 0u;
-                if (l0 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l0 = 32u * k + t; w &= ~(1u << t); }
-                if (l0 != 0xFFFFFFFFu && l1 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l1 = 32u * k + t; w &= ~(1u << t); }
-                if (l1 != 0xFFFFFFFFu && l2 == 0xFFFFFFFFu && w) l2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
-            }
+        if (have)
+        {
+            uint32_t w = mmw( 0, d );
+            if (w) { f0 = (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+            if (w) { f1 = (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+            if (w) f2 = (uint32_t)__builtin_ctz( w );
+            const uint32_t tl = __builtin_amdgcn_alignbit( qlT[1], qlT[0], d ), th = __builtin_amdgcn_alignbit( qhT[1], qhT[0], d );
+            w = (((plT ^ tl) | (phT ^ th)) & pmT) | pnT;          // rows base .. base + 31
+            if (w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l0 = base + t; w &= ~(1u << t); }
+            if (w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l1 = base + t; w &= ~(1u << t); }
+            if (w) l2 = base + 31u - (uint32_t)__builtin_clz( w );
+        }
+        if (have && __any( M > 32u && (f2 == M || l2 == 0xFFFFFFFFu) ))
+        {
+            f0 = f1 = f2 = M; l0 = l1 = l2 = 0xFFFFFFFFu;
+            #pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (__any( f2 == M && pm[k] != 0u ))
+                {
+                    uint32_t w = (f2 == M) ? mmw( k, d ) : 0u;
+                    if (f0 == M && w) { f0 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                    if (f0 != M && f1 == M && w) { f1 = 32u * k + (uint32_t)__builtin_ctz( w ); w &= w - 1u; }
+                    if (f1 != M && f2 == M && w) f2 = 32u * k + (uint32_t)__builtin_ctz( w );
+                }
+            #pragma unroll
+            for (int k = 5; k >= 0; --k)
+                if (__any( l2 == 0xFFFFFFFFu && pm[k] != 0u ))
+                {
+                    uint32_t w = (l2 == 0xFFFFFFFFu) ? mmw( k, d ) : 0u;
+                    if (l0 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l0 = 32u * k + t; w &= ~(1u << t); }
+                    if (l0 != 0xFFFFFFFFu && l1 == 0xFFFFFFFFu && w) { const uint32_t t = 31u - (uint32_t)__builtin_clz( w ); l1 = 32u * k + t; w &= ~(1u << t); }
+                    if (l1 != 0xFFFFFFFFu && l2 == 0xFFFFFFFFu && w) l2 = 32u * k + 31u - (uint32_t)__builtin_clz( w );
+                }
+        }
         const int32_t L0 = (int32_t)f0, L1 = (int32_t)f1, L2 = (int32_t)f2;          // rows before the 1st / 2nd / 3rd mismatch
         const int32_t T0 = l0 == 0xFFFFFFFFu ? Mi : Mi - 1 - (int32_t)l0;             // rows after the last / last-but-one / last-but-two
         const int32_t T1 = l1 == 0xFFFFFFFFu ? Mi : Mi - 1 - (int32_t)l1;
