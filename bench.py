@@ -777,7 +777,7 @@ def main():
                                              "achieved": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9,
                                              "frac": alg_bytes_per_launch / (no_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "extend": {"kernel": ("ungapped_e2e31_kernel<4> (31 diagonals by XOR + popcount on bit planes; settles every candidate whose best diagonal "
-                              "beats any gapped alignment) + banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4> over the rest (two alignments per lane, "
+                              "beats any gapped alignment; second / third chance and the gap chance over dense lists) + banded_gotoh_band31_pk_kernel<SEMI_GLOBAL,4> over the rest (two alignments per lane, "
                               "binary16 packed: exact for these scores, v_pk_maximum3_f16)") if args.mode == "e2e" else
                              "banded_gotoh_band31_pk_kernel<LOCAL,4> (two alignments per lane, int16 packed)",
                    "bound": "valu (packed 16-bit lanes; MFMA not applicable)",

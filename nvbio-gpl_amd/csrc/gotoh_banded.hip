@@ -1099,6 +1099,10 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
     const uint32_t tb    = b.win_begin[job];
     const uint32_t N     = b.win_end[job] - tb;
     // (flagged by the first pass: 1 <= M <= 161, N >= M + 30, P > 0, open <= ext < 0)
+    // need_dp = 2: a third-chance job -- its best diagonal (2 or 3 mismatches) is in scores / sinks; that ungapped class joins the evaluated ones
+    const bool     has_u = need_dp[job] == 2;
+    const int32_t  cu    = has_u ? -scores[job] : 0x7FFFFFFF;
+    const uint32_t cu_end = has_u ? sinks[job].x - M : 0u;
 
     uint32_t pl[6], ph[6], pn[6], pm[6], ql[7], qh[7];
     {
@@ -1134,7 +1138,7 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
     cg[0] = 0;
     const int64_t floor_u = 3 * (int64_t)(G < gap_open ? G : gap_open) - P;
     const int32_t cap = (int32_t)((-floor_u - 1) / (int64_t)P);
-    int32_t c_unk = (cap + 1) * P;
+    int32_t c_unk = has_u ? 0x7FFFFFFF : (cap + 1) * P;         // (every OTHER diagonal of a third-chance job costs at least what its best one does)
     {
         const int32_t others[] = { cg[1] + 3 * P, cg[GA + 1], 3 * cg[1], 2 * cg[1] + P, cg[1] + cg[3], 2 * cg[2] };
         #pragma unroll
@@ -1311,6 +1315,7 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
         Tp[0] = (uint32_t)T0 | ((uint32_t)T1 << 8) | ((uint32_t)T2 << 16);
         hot = (hot << 1) | (hot_d ? 1u : 0u);
     }
+    if (cu < best_cost || (cu == best_cost && cu_end > best_end)) { best_cost = cu; best_end = cu_end; }
     const bool settled = best_cost < c_unk && !(ex11 && cost11 <= best_cost) && !(ex12 && cost12 <= best_cost);
     if (settled) { scores[job] = -best_cost; sinks[job] = make_uint2( M + best_end, M ); need_dp[job] = 0; }
     else need_dp[job] = 1;
@@ -1351,6 +1356,7 @@ static bool packed_ok(const int type, const SchemeDev& sc, const uint32_t max_re
 
 struct IsTwo { __host__ __device__ __forceinline__ uint8_t operator()(const uint8_t v) const { return v == 2u ? 1u : 0u; } };
 struct FlagIs { const uint8_t* flags; uint8_t code; __host__ __device__ __forceinline__ bool operator()(const uint32_t i) const { return flags[i] == code; } };
+struct FlagIn { const uint8_t* flags; uint32_t mask; __host__ __device__ __forceinline__ bool operator()(const uint32_t i) const { return ((mask >> flags[i]) & 1u) != 0u; } };
 
 
 // RAGGED batches: the DP's job list in ascending order of read length, so that the two alignments of a lane -- and the lanes of a wave --
@@ -1461,14 +1467,9 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         // three-way partition of the job ids by flag (3: second chance, 2: third chance), the rest discarded
         size_t part_bytes = 0;
         hipcub::DiscardOutputIterator<uint32_t> nowhere;
-        const FlagIs is3 = { nullptr, 3 }, is2 = { nullptr, 2 };
+        const FlagIs is3 = { nullptr, 3 }; const FlagIn is2 = { nullptr, 0u };
         NVB_HIP( hipcub::DevicePartition::If( nullptr, part_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, nowhere, (uint32_t*)nullptr, (int)b.n, is3, is2, s ) );
         if (part_bytes > sel_bytes) sel_bytes = part_bytes;
-        {
-            size_t if_bytes = 0;
-            NVB_HIP( hipcub::DeviceSelect::If( nullptr, if_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, is3, s ) );
-            if (if_bytes > sel_bytes) sel_bytes = if_bytes;
-        }
         if (hipMallocAsync( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1490,29 +1491,27 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
                                 (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc );
         hipError_t e = hipSuccess;
         {
-            // the jobs a second / third chance can still settle (need_dp == 3 / 2), compacted by one three-way partition, each list through
-            // its own launch: every job ends as 0 or 1.  (With NVBIO_ALN_NO_THIRD_CHANCE the third-chance jobs are simply handed to the
-            // DP: a non-zero flag selects; NVBIO_ALN_NO_SECOND_CHANCE keeps the first pass from flagging any.)
-            const FlagIs f3 = { need_dp, 3 }, f2 = { need_dp, 2 };
+            // the jobs a chance can still settle, compacted by ONE three-way partition, each list through its own launch; every job ends as 0 or 1.
+            //   list 1: need_dp == 3, the second chance.
+            //   list 2: the gap chance's jobs -- need_dp == 4 (no diagonal in reach of the other chances: reads with an indel, mostly) and
+            //           need_dp == 2 (third-chance jobs: the gap chance evaluates what the third chance only rules out, with the job's best diagonal as
+            //           one more class) -- or, without the gap chance (qualities, NVBIO_ALN_NO_GAP_CHANCE), need_dp == 2 for the third chance.
+            // (With NVBIO_ALN_NO_THIRD_CHANCE the third-chance jobs are simply handed to the DP: a non-zero flag selects;
+            // NVBIO_ALN_NO_SECOND_CHANCE keeps the first pass from flagging any.)
+            const bool gapc = !by_quality && !(b.algo & NVBIO_ALN_NO_GAP_CHANCE);
+            const FlagIs f3 = { need_dp, 3 };
+            const FlagIn f2 = { need_dp, gapc ? ((third ? 4u : 0u) | 16u) : 4u };
             size_t pb = sel_bytes;
             e = hipcub::DevicePartition::If( sel_temp, pb, ids, list_s, list_t, nowhere, count_st, (int)b.n, f3, f2, s );
             if (e == hipSuccess)
                 hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,1>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
                                     (const uint32_t*)list_s, (const uint32_t*)count_st );
-            if (e == hipSuccess && third)
+            if (e == hipSuccess && gapc)
+                hipLaunchKernelGGL( (gap_chance_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
+                                    (const uint32_t*)list_t, (const uint32_t*)(count_st + 1) );
+            else if (e == hipSuccess && third)
                 hipLaunchKernelGGL( (ungapped_e2e31_kernel<RB,2>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
                                     (const uint32_t*)list_t, (const uint32_t*)(count_st + 1) );
-        }
-        if (e == hipSuccess && !by_quality && !(b.algo & NVBIO_ALN_NO_GAP_CHANCE))
-        {
-            // the jobs without a diagonal in reach of those chances (need_dp == 4: reads with an indel, mostly): the gap chance over their list
-            // (the second chance's list and counter have been consumed: reused)
-            const FlagIs f4 = { need_dp, 4 };
-            size_t sb = sel_bytes;
-            e = hipcub::DeviceSelect::If( sel_temp, sb, ids, list_s, count_st, (int)b.n, f4, s );
-            if (e == hipSuccess)
-                hipLaunchKernelGGL( (gap_chance_e2e31_kernel<RB>), dim3( (b.n + 255u) / 256u ), dim3( 256 ), 0, s, b, P, G, sc.pat_go, sc.pat_ge, scores, sinks, need_dp,
-                                    (const uint32_t*)list_s, (const uint32_t*)count_st );
         }
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         if (e == hipSuccess)
