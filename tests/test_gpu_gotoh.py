@@ -516,3 +516,52 @@ def test_gap_chance_on_reads_with_indels(amd, orc):
             bad = np.nonzero((sc.cpu().numpy() != wsc) | (amd.u32(sk) != wsk).any(axis=1))[0]
             assert len(bad) == 0, (sv, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]], amd.u32(sk)[bad[:5]], wsk[bad[:5]])
     assert ((wsc < -8) & (wsc > -60)).mean() > 0.5
+
+
+def test_gap_chance_on_ragged_reversed_reads(amd, orc):
+    """the gap chance where nothing is uniform: read lengths 33..161 (and a few shorter than a plane word), reads stored reversed and / or
+    complemented, N symbols, windows shifted and clipped -- one indel of 1-5 symbols or two small ones or many substitutions per read; with the
+    ragged-batch hint and without, with and without the chance"""
+    rng = np.random.default_rng(777)
+    G, R = 500000, 7000
+    text = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = rng.integers(33, 162, R); lens[:60] = rng.integers(8, 33, 60)
+    roffs = np.zeros(R + 1, dtype=np.uint32); roffs[1:] = np.cumsum(lens)
+    starts = rng.integers(60, G - 400, R)
+    flags = rng.integers(0, 4, R).astype(np.uint8)
+    reads = []
+    for k in range(R):
+        L = int(lens[k]); src = text[starts[k]:starts[k] + L + 12].copy()
+        kind = k % 5
+        if kind < 3 and L > 12:
+            g = int(rng.integers(1, 6)); at = int(rng.integers(1, L - 6))
+            r = (np.concatenate([src[:at], rng.integers(0, 4, g, dtype=np.uint8), src[at:]]) if rng.random() < 0.5 else np.concatenate([src[:at], src[at + g:]]))[:L]
+            nm = int(rng.integers(0, 3))
+        elif kind == 3 and L > 20:
+            a1, a2 = sorted(rng.integers(2, L - 6, 2))
+            r = np.concatenate([src[:a1], src[a1 + 1:a2], rng.integers(0, 4, 1, dtype=np.uint8), src[a2:]])[:L]
+            nm = int(rng.integers(0, 2))
+        else:
+            r = src[:L]; nm = int(rng.integers(3, 9))
+        r = r.copy()
+        if nm:
+            pos = rng.choice(L, min(nm, L), replace=False); r[pos] = (r[pos] + 1 + rng.integers(0, 3, len(pos))) % 4
+        if rng.random() < 0.1:
+            r[int(rng.integers(0, L))] = 4
+        # store the read so that the job's flags give back `r` as aligned: reverse / complement are involutions
+        if flags[k] & 2:
+            r = np.where(r < 4, 3 - r, r)
+        if flags[k] & 1:
+            r = r[::-1]
+        reads.append(r.astype(np.uint8))
+    flat = np.concatenate(reads)
+    wb = (starts - 15 + rng.integers(-4, 5, R)).astype(np.uint32); we = (wb + lens + 31).astype(np.uint32)
+    we[::23] -= rng.integers(1, 12, len(we[::23])).astype(np.uint32)           # clipped windows: not the chance's
+    rid = np.arange(R, dtype=np.uint32)
+    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 3, 3, -4, -2, -4, -2)):
+        wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we, read_id=rid, flags=flags)
+        for algo in (None, amd.ALN_RAGGED_READS, amd.ALN_NO_GAP_CHANCE, amd.ALN_RAGGED_READS | amd.ALN_NO_GAP_CHANCE | amd.ALN_NO_F16_DP):
+            batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, flags=flags, max_read_len=161, algo_flags=algo)
+            sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
+            bad = np.nonzero((sc.cpu().numpy() != wsc) | (amd.u32(sk) != wsk).any(axis=1))[0]
+            assert len(bad) == 0, (sv, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]], amd.u32(sk)[bad[:5]], wsk[bad[:5]], lens[bad[:5]], flags[bad[:5]])
