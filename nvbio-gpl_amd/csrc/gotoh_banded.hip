@@ -678,6 +678,19 @@ banded_gotoh_band31_pk_kernel(const BatchDev b, const SchemeDev sc, int32_t* __r
 //   its partners across an indel) are summed exactly, row by row, from the quality bytes; every other diagonal is ruled out by its
 //   count alone.  Everything after that -- which classes of gapped alignments could still reach U* -- is argued with P as the least a
 //   mismatch can cost, which only makes the classes larger (more jobs to the DP, never a wrong answer).
+// the gap chance's cost ladder (gap_chance_e2e31_kernel): the cheapest class of gapped alignments it neither evaluates nor rules out, with P the
+// least a mismatch can cost and gaps of up to GAP_CHANCE_GA symbols evaluated
+constexpr int GAP_CHANCE_GA = 5;
+__device__ __forceinline__ int32_t gap_chance_unknown_cost(const int32_t P, const int32_t go, const int32_t ge)
+{
+    auto cg = [&](const int g) -> int32_t { return -(go + (g - 1) * ge); };
+    int32_t c = cg( 1 ) + 3 * P;                                  // one gap and three mismatches
+    const int32_t others[] = { cg( GAP_CHANCE_GA + 1 ), 3 * cg( 1 ), 2 * cg( 1 ) + P, cg( 1 ) + cg( 3 ), 2 * cg( 2 ) };
+    #pragma unroll
+    for (int k = 0; k < 5; ++k) c = others[k] < c ? others[k] : c;
+    return c;
+}
+
 template <int RBITS, int MODE, bool QUAL = false>
 __global__ void __launch_bounds__(256)
 ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
@@ -798,6 +811,7 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
         {
             // no diagonal within reach of the three chances: typically a read with an indel.  The gap chance (gap_chance_e2e31_kernel, its own
             // list pass) evaluates the one-gap alignments of such a job exactly; it needs every diagonal inside the text and plain gap terms
+            // (not under a quality ramp: see the kernel's header)
             const bool gap_chance = !QUAL && P > 0 && N >= M + 30u && gap_ext < 0 && gap_open <= gap_ext && !(b.algo & NVBIO_ALN_NO_GAP_CHANCE);
             need_dp[job] = gap_chance ? 4 : 1;
             return;
@@ -1081,6 +1095,10 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
 //     at row hi, a member exists iff lo >= hi or b has no mismatch in rows [lo, hi); one that costs <= c* sends the job to the DP.
 // Anything else -- c* >= c_unk, no member at all, a two-gap member in reach -- is the DP's.  Over-approximation only ever costs a DP.
 // ---------------------------------------------------------------------------------------------
+// Not under a quality ramp.  Built and measured (members priced with the penalties their mismatching rows really carry, every split of them between
+// prefix and suffix; parity green): with penalties 2..6 the cheapest class the kernel cannot see -- one gap and three mismatches at the SMALLEST
+// penalty -- costs 14, so a job settles only while its optimum costs 13 or less; the third chance already takes U* >= -11 there, and on the robust
+// batch the pass cost 1.1-1.7 ms for 0.5-1.0 ms of DP saved.  It would take the ladder to five or six mismatches to pay.
 template <int RBITS>
 __global__ void __launch_bounds__(256)
 gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
@@ -1130,7 +1148,7 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
     }
 
     // the cost ladder
-    constexpr int GA = 5;
+    constexpr int GA = GAP_CHANCE_GA;
     const int32_t go = gap_open, ge = gap_ext;
     int32_t cg[GA + 2];                                          // cg[g] = cost of a gap of g symbols
     #pragma unroll
@@ -1138,12 +1156,8 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
     cg[0] = 0;
     const int64_t floor_u = 3 * (int64_t)(G < gap_open ? G : gap_open) - P;
     const int32_t cap = (int32_t)((-floor_u - 1) / (int64_t)P);
-    int32_t c_unk = has_u ? 0x7FFFFFFF : (cap + 1) * P;         // (every OTHER diagonal of a third-chance job costs at least what its best one does)
-    {
-        const int32_t others[] = { cg[1] + 3 * P, cg[GA + 1], 3 * cg[1], 2 * cg[1] + P, cg[1] + cg[3], 2 * cg[2] };
-        #pragma unroll
-        for (int k = 0; k < 6; ++k) c_unk = others[k] < c_unk ? others[k] : c_unk;
-    }
+    int32_t c_unk = gap_chance_unknown_cost( P, go, ge );
+    if (!has_u && (cap + 1) * P < c_unk) c_unk = (cap + 1) * P;  // (every OTHER diagonal of a job that brings its best one costs at least that much)
     const int32_t cost11 = 2 * cg[1], cost12 = cg[1] + cg[2];
 
     // mismatch word k (rows 32 k .. 32 k + 31) of diagonal x: the text planes x symbols on (x is wave-uniform: one funnel shift per plane word)
@@ -1172,6 +1186,7 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
         qlT[0] = __builtin_amdgcn_alignbit( t[1], t[0], bs ); qlT[1] = __builtin_amdgcn_alignbit( t[2], t[1], bs );
         qhT[0] = __builtin_amdgcn_alignbit( u[1], u[0], bs ); qhT[1] = __builtin_amdgcn_alignbit( u[2], u[1], bs );
     }
+    auto pen_of = [&](const int32_t) -> int32_t { return P; };   // what a mismatch costs, whatever its row (one penalty for every quality)
     // history of the last GA diagonals (slot k: diagonal d - 1 - k): (lead0, lead1, lead2) and (tail0, tail1, tail2) packed a byte each (<= 161)
     uint32_t Lp[GA], Tp[GA];
     #pragma unroll
@@ -1258,32 +1273,42 @@ gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, cons
                 {
                     const int32_t a0 = (int32_t)(Lp[g - 1] & 255u), a1 = (int32_t)((Lp[g - 1] >> 8) & 255u), a2 = (int32_t)(Lp[g - 1] >> 16);
                     const int32_t t0 = (int32_t)(Tp[g - 1] & 255u), t1 = (int32_t)((Tp[g - 1] >> 8) & 255u), t2 = (int32_t)(Tp[g - 1] >> 16);
-                    // text gap of g: diagonal d - g, then d; ends in column d
+                    // text gap of g: diagonal d - g (prefix), then d (suffix); ends in column d
                     if (a2 + T2 >= Mi)
                     {
-                        int32_t e = 3;
-                        if (a0 + T0 >= Mi) e = 0;
-                        else if (a0 + T1 >= Mi || a1 + T0 >= Mi) e = 1;
-                        else if (a0 + T2 >= Mi || a1 + T1 >= Mi || a2 + T0 >= Mi) e = 2;
-                        if (e < 3)
-                        {
-                            const int32_t c = cg[g] + e * P;
-                            if (c < best_cost || (c == best_cost && d > best_end)) { best_cost = c; best_end = d; }
-                        }
+                        const int32_t pa[2] = { pen_of( a0 ), pen_of( a1 ) };                     // the prefix diagonal's first / second mismatch
+                        const int32_t pt[2] = { pen_of( Mi - 1 - T0 ), pen_of( Mi - 1 - T1 ) };   // the suffix diagonal's last / last-but-one
+                        const int32_t lead[3] = { a0, a1, a2 }, tail[3] = { T0, T1, T2 };
+                        int32_t c = 0x7FFFFFFF;
+                        #pragma unroll
+                        for (int i = 0; i <= 2; ++i)
+                            #pragma unroll
+                            for (int j = 0; i + j <= 2; ++j)
+                                if (lead[i] + tail[j] >= Mi)
+                                {
+                                    const int32_t x = cg[g] + (i > 0 ? pa[0] : 0) + (i > 1 ? pa[1] : 0) + (j > 0 ? pt[0] : 0) + (j > 1 ? pt[1] : 0);
+                                    c = x < c ? x : c;
+                                }
+                        if (c != 0x7FFFFFFF && (c < best_cost || (c == best_cost && d > best_end))) { best_cost = c; best_end = d; }
                     }
-                    // pattern gap of g: diagonal d, then d - g; ends in column d - g
+                    // pattern gap of g: diagonal d (prefix), then d - g (suffix); ends in column d - g
                     if (L2 + t2 + g >= Mi)
                     {
-                        int32_t e = 3;
-                        if (L0 + t0 + g >= Mi) e = 0;
-                        else if (L0 + t1 + g >= Mi || L1 + t0 + g >= Mi) e = 1;
-                        else if (L0 + t2 + g >= Mi || L1 + t1 + g >= Mi || L2 + t0 + g >= Mi) e = 2;
-                        if (e < 3)
-                        {
-                            const int32_t c = cg[g] + e * P;
-                            const uint32_t end = d - (uint32_t)g;
-                            if (c < best_cost || (c == best_cost && end > best_end)) { best_cost = c; best_end = end; }
-                        }
+                        const int32_t pa[2] = { pen_of( L0 ), pen_of( L1 ) };
+                        const int32_t pt[2] = { pen_of( Mi - 1 - t0 ), pen_of( Mi - 1 - t1 ) };
+                        const int32_t lead[3] = { L0, L1, L2 }, tail[3] = { t0, t1, t2 };
+                        int32_t c = 0x7FFFFFFF;
+                        #pragma unroll
+                        for (int i = 0; i <= 2; ++i)
+                            #pragma unroll
+                            for (int j = 0; i + j <= 2; ++j)
+                                if (lead[i] + tail[j] + g >= Mi)
+                                {
+                                    const int32_t x = cg[g] + (i > 0 ? pa[0] : 0) + (i > 1 ? pa[1] : 0) + (j > 0 ? pt[0] : 0) + (j > 1 ? pt[1] : 0);
+                                    c = x < c ? x : c;
+                                }
+                        const uint32_t end = d - (uint32_t)g;
+                        if (c != 0x7FFFFFFF && (c < best_cost || (c == best_cost && end > best_end))) { best_cost = c; best_end = end; }
                     }
                 }
         }

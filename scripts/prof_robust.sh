@@ -4,7 +4,7 @@ TAG=${1:-r03c}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/${TAG}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-sweep --no-plain-ab --no-traceback > $R/gpurun_out/prof/${TAG}.json 2> $R/gpurun_out/prof/${TAG}.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/${TAG}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-sweep --no-plain-ab --no-traceback --no-cpp-host --no-nvbowtie-mode > $R/gpurun_out/prof/${TAG}.json 2> $R/gpurun_out/prof/${TAG}.err
 rc=$?
 [ $rc -ne 0 ] && { tail -5 $R/gpurun_out/prof/${TAG}.err; exit $rc; }
 python3 - $(find $R/gpurun_out/prof/${TAG}_stats -name "*kernel_trace.csv" | head -1) $R/gpurun_out/prof/${TAG}_robust_kernels.txt $R/gpurun_out/prof/${TAG}_headline_kernels.txt <<'PY'

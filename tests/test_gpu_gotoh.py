@@ -336,7 +336,7 @@ def _with_qualities(amd, orc, rng, flat, roffs, text, wb, we, M, schemes=((0, 2,
         for sv in schemes:
             wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we,
                                                      read_id=rid, flags=fl, quals=quals)
-            for algo in (None, amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_NO_QUALITY_SHORTCUT):
+            for algo in (None, amd.ALN_NO_UNGAPPED_SCORE, amd.ALN_NO_QUALITY_SHORTCUT, amd.ALN_NO_GAP_CHANCE):
                 batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, quals=quals, max_read_len=M, algo_flags=algo)
                 sc, sk = amd.batch_banded_alignment_score(31, amd.make_gotoh_aligner(oracle.SEMI_GLOBAL, _scheme(amd, sv)), batch)
                 bad = np.nonzero(sc.cpu().numpy() != wsc)[0]
@@ -516,6 +516,8 @@ def test_gap_chance_on_reads_with_indels(amd, orc):
             bad = np.nonzero((sc.cpu().numpy() != wsc) | (amd.u32(sk) != wsk).any(axis=1))[0]
             assert len(bad) == 0, (sv, algo, bad[:5], sc.cpu().numpy()[bad[:5]], wsc[bad[:5]], amd.u32(sk)[bad[:5]], wsk[bad[:5]])
     assert ((wsc < -8) & (wsc > -60)).mean() > 0.5
+    # ... and under quality ramps: members are priced with the penalties of the rows that really mismatch, every split of them between prefix and suffix
+    _with_qualities(amd, orc, rng, flat, roffs, text, wb, we, M, schemes=((0, 2, 6, -8, -3, -8, -3), (0, 1, 3, -5, -1, -5, -1), (0, 3, 10, -9, -2, -9, -2), (0, 4, 5, -6, -3, -6, -3)))
 
 
 def test_gap_chance_on_ragged_reversed_reads(amd, orc):
