@@ -58,6 +58,7 @@ seed_hits_select_kernel(const uint32_t* __restrict__ active_in, const uint32_t n
                         uint2* __restrict__ deques, uint32_t* __restrict__ sizes, uint32_t* __restrict__ active_out, uint32_t* __restrict__ hit_read_id,
                         uint32_t* __restrict__ hit_loc, uint32_t* __restrict__ hit_seed, unsigned int* __restrict__ counts)
 {
+    __shared__ uint32_t s_cnt[4], s_base[2];
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_active; base += gridDim.x * blockDim.x)
     {
@@ -92,18 +93,24 @@ seed_hits_select_kernel(const uint32_t* __restrict__ active_in, const uint32_t n
                 }
             }
         }
+        // slots: ONE returning atomic per workgroup (every wave adding to the same counter serialises in L2: ~10 ns each, 3 ms per 10 M reads)
         const uint64_t m = __ballot( take );
-        if (m)
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll( m );
+        __syncthreads();
+        if (threadIdx.x == 0)
         {
-            uint32_t slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd( &counts[0], (unsigned int)__popcll( m ) );
-            slot0 = (uint32_t)__shfl( (int)slot0, 0 );
-            if (take)
-            {
-                const uint32_t slot = slot0 + (uint32_t)__popcll( m & ((1ull << lane) - 1ull) );
-                active_out[slot] = read | (top_flag << 31); hit_read_id[slot] = read; hit_loc[slot] = row; hit_seed[slot] = seed;
-            }
+            const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base[0] = tot ? atomicAdd( &counts[0], (unsigned int)tot ) : 0u;
         }
+        __syncthreads();
+        if (take)
+        {
+            uint32_t slot = s_base[0] + (uint32_t)__popcll( m & ((1ull << lane) - 1ull) );
+            for (uint32_t w = 0; w < wave; ++w) slot += s_cnt[w];
+            active_out[slot] = read | (top_flag << 31); hit_read_id[slot] = read; hit_loc[slot] = row; hit_seed[slot] = seed;
+        }
+        __syncthreads();
     }
 }
 
@@ -178,6 +185,7 @@ seed_hits_select_multi_kernel(const uint32_t* __restrict__ active_in, const uint
                               uint32_t* __restrict__ hits_first, uint32_t* __restrict__ hits_count, uint32_t* __restrict__ hit_read_id,
                               uint32_t* __restrict__ hit_loc, uint32_t* __restrict__ hit_seed, unsigned int* __restrict__ counts)
 {
+    __shared__ uint32_t s_cnt[4], s_hits[4], s_base[2];
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_active; base += gridDim.x * blockDim.x)
     {
@@ -201,12 +209,20 @@ seed_hits_select_multi_kernel(const uint32_t* __restrict__ active_in, const uint
         #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t a = (uint32_t)__shfl_up( (int)incl, d ); if (lane >= (uint32_t)d) incl += a; }
         const uint32_t wave_hits = (uint32_t)__shfl( (int)incl, 63 );
-        uint32_t slot0 = 0, hit0 = 0;
-        if (m)
+        // one returning atomic per workgroup and counter (every wave adding to the same two counters serialises in L2)
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane == 0) { s_cnt[wave] = (uint32_t)__popcll( m ); s_hits[wave] = wave_hits; }
+        __syncthreads();
+        if (threadIdx.x == 0)
         {
-            if (lane == 0) { slot0 = atomicAdd( &counts[0], (unsigned int)__popcll( m ) ); hit0 = atomicAdd( &counts[1], wave_hits ); }
-            slot0 = (uint32_t)__shfl( (int)slot0, 0 ); hit0 = (uint32_t)__shfl( (int)hit0, 0 );
+            const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], toth = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
+            s_base[0] = tot ? atomicAdd( &counts[0], (unsigned int)tot ) : 0u;
+            s_base[1] = toth ? atomicAdd( &counts[1], (unsigned int)toth ) : 0u;
         }
+        __syncthreads();
+        uint32_t slot0 = s_base[0], hit0 = s_base[1];
+        for (uint32_t w = 0; w < wave; ++w) { slot0 += s_cnt[w]; hit0 += s_hits[w]; }
+        __syncthreads();
         if (want)
         {
             const uint32_t slot = slot0 + (uint32_t)__popcll( m & ((1ull << lane) - 1ull) );
