@@ -508,7 +508,8 @@ def test_gap_chance_on_reads_with_indels(amd, orc):
     flat = np.concatenate(reads)
     roffs = (np.arange(R + 1) * M).astype(np.uint32)
     wb = np.array(wbs, dtype=np.uint32); we = (wb + 31 + M).astype(np.uint32)
-    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 2, 2, -5, -1, -5, -1), (0, 4, 4, -6, -6, -6, -6), (0, 3, 3, -4, -2, -4, -2), (0, 6, 6, -5, -3, -5, -3)):
+    for sv in ((0, 6, 6, -8, -3, -8, -3), (0, 2, 2, -5, -1, -5, -1), (0, 4, 4, -6, -6, -6, -6), (0, 3, 3, -4, -2, -4, -2), (0, 6, 6, -5, -3, -5, -3),
+               (0, 9, 9, -4, -2, -4, -2), (0, 1, 1, -7, -1, -7, -1), (0, 5, 5, -2, -2, -2, -2)):
         wsc, wsk = orc.banded_gotoh_packed_batch(31, oracle.SEMI_GLOBAL, oracle.Scheme(*sv), orc.pack4(flat), roffs, orc.pack2(text), wb, we)
         for algo in (None, amd.ALN_NO_GAP_CHANCE):
             batch = amd.AlignmentBatch(orc.pack4(flat), 4, roffs, orc.pack2(text), 2, wb, we, max_read_len=M, algo_flags=algo)
