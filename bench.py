@@ -419,6 +419,9 @@ def main():
     ap.add_argument("--max-seed-hits", type=int, default=0, help="extend at most this many SA rows of a seed's range (0: all; needed with --repeat-family)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank maps --reads reads per step; strong: --reads reads per step in all, split over the ranks")
+    ap.add_argument("--side-priority", type=int, default=0, help="priority of the seed pass's side stream (-1 = high)")
+    ap.add_argument("--overlap-seed-pass", action="store_true", help="the next batch's seed pass on a side stream BESIDE this batch's extension: 5.62 instead of 5.76 ms per step, "
+                    "but each kernel then runs slower than alone (the seed pass 3.3 instead of 2.3 ms) and the roofline of the launch would be that of a shared GPU: off by default")
     ap.add_argument("--no-step-pipelining", action="store_true",
                     help="do not enqueue the next step's seed pass ahead of this step's extension (the host then waits for the seed pass's counts with the GPU idle)")
     ap.add_argument("--no-defer-heavy", action="store_true", help="the searches the canonical table cannot answer run inside the seed pass instead of as a dense launch behind it")
@@ -534,12 +537,20 @@ def main():
     # GPU extends batch i and the GPU never waits for the host.  K steps still are K seed passes and K extensions inside the timed region.
     can_pipe = (not args.no_step_pipelining and params.direct and fmi.supports_direct() and params.fused_seed_pass and bool(fmi.canonical))
 
+    side = torch.cuda.Stream(device=device, priority=args.side_priority) if (can_pipe and args.overlap_seed_pass) else None
+
     def run_steps(k, timers=None):
+        # the seed pass of batch i+1 on a side stream beside the extension of batch i; a slot's buffers are rewritten only behind the extension that read them
         out = None
-        pre = pipeline.seed_pass_begin(fmi, batch, params, 0, timers) if (can_pipe and k) else None
+        done = [None, None]
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(device))
+        pre = pipeline.seed_pass_begin(fmi, batch, params, 0, timers, stream=side) if (can_pipe and k) else None
         for i in range(k):
-            nxt = pipeline.seed_pass_begin(fmi, batch, params, (i + 1) & 1, timers) if (can_pipe and i + 1 < k) else None
+            nxt = pipeline.seed_pass_begin(fmi, batch, params, (i + 1) & 1, timers, stream=side, after=done[(i + 1) & 1]) if (can_pipe and i + 1 < k) else None
             out = step(timers, pre)
+            if side is not None:
+                done[i & 1] = torch.cuda.Event(); done[i & 1].record()
             pre = nxt
         return out
 
@@ -735,7 +746,7 @@ def main():
                                  if args.mode == "e2e" else "local Gotoh, match 2, mismatch -2 (no qualities), gaps -8/-3, min score 10 ln L"), "kmer_table": args.kmer, "canonical_table": use_both, "wide_entries": bool(use_both and not args.no_wide_table), "sa_int": args.sa_int, "match_direct": use_direct, "fused_seed_pass": use_fused, "sa_isa_verify": bool(args.sa_int == 1 and args.verify),
                    "index_bytes_per_gpu": fmi.device_bytes(), "index_bytes_per_reference_base": fmi.device_bytes() / float(n),
                    "parallelism": "read-shard x%d" % world, "reads_per_step_all_ranks": world * R,
-                   "steps_pipelined": bool(can_pipe), "defer_heavy_searches": bool(params.defer_heavy),
+                   "steps_pipelined": bool(can_pipe), "seed_pass_beside_extension": bool(can_pipe and args.overlap_seed_pass), "defer_heavy_searches": bool(params.defer_heavy),
                    "traceback_in_step": bool(args.with_traceback), "repeat_family_copies": args.repeat_family,
                    "max_seed_hits": params.max_seed_hits},
         "left_out_of_the_step": {"note": "the timed step re-runs one HBM-resident batch: no H2D/D2H, no index build"

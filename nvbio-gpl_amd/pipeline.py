@@ -120,13 +120,21 @@ def _batch_geometry(torch, fmi, reads, params):
     return dict(S_int=S_int, spr=spr, ragged=ragged, intervals=intervals, min_scores=min_scores, qs=qs, read_off=read_off)
 
 
-def seed_pass_begin(fmi, reads, params, slot=0, timers=None):
+def seed_pass_begin(fmi, reads, params, slot=0, timers=None, stream=None, after=None):
     """Enqueue the two-strand seed pass of a batch and the copy of its counts to pinned host memory; returns the handle
     seed_and_extend( ..., pre = handle ) continues from.  A caller that streams batches enqueues batch i+1's seed pass BEFORE batch i's
     extension: the host then reads i+1's counts while the GPU extends batch i, and the one host synchronisation of a step -- the sizes
     of the extension's launches -- never leaves the GPU idle (bench.py does this).  slot: which of the handle's buffer sets to use
-    (two consecutive batches need different ones)."""
+    (two consecutive batches need different ones).
+    stream: a side stream to enqueue the pass on, so that it runs BESIDE the previous batch's extension (the seed pass waits for HBM lines, the
+    extension for the VALU: the two share a CU well); after: an event of the caller's stream behind the last kernel that read this slot's
+    buffers (the extension of two batches ago) -- the pass waits for it on the device."""
     import torch
+    if stream is not None:
+        if after is not None:
+            stream.wait_event(after)
+        with torch.cuda.stream(stream):
+            return seed_pass_begin(fmi, reads, params, slot, timers)
     geo = _batch_geometry(torch, fmi, reads, params)
     bufs = getattr(fmi, "_seed_bufs2", None)
     if bufs is None:
