@@ -420,6 +420,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank maps --reads reads per step; strong: --reads reads per step in all, split over the ranks")
     ap.add_argument("--side-priority", type=int, default=0, help="priority of the seed pass's side stream (-1 = high)")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the (extra) measurement of the step with the seed pass beside the extension")
+    ap.add_argument("--overlap-grid-blocks", type=int, default=448, help="workgroups of the seed pass in that measurement (a multiple of 64)")
+    ap.add_argument("--seed-grid-blocks", type=int, default=0, help="workgroups of the seed-pass launch (a multiple of 64; 0 = the library's 16384): with "
+                    "--overlap-seed-pass a small grid leaves SIMD room for the extension's kernels")
     ap.add_argument("--overlap-seed-pass", action="store_true", help="the next batch's seed pass on a side stream BESIDE this batch's extension: 5.62 instead of 5.76 ms per step, "
                     "but each kernel then runs slower than alone (the seed pass 3.3 instead of 2.3 ms) and the roofline of the launch would be that of a shared GPU: off by default")
     ap.add_argument("--no-step-pipelining", action="store_true",
@@ -510,6 +514,7 @@ def main():
     if args.algo_flags:
         params.algo_flags = (params.algo_flags or 0) | args.algo_flags
     params.fused_seed_pass = not args.no_fused_seeds
+    params.seed_grid_blocks = args.seed_grid_blocks
     params.defer_heavy = not args.no_defer_heavy
     params.mapq = not args.no_mapq               # score_reduce's second-best alignment + BowtieMapq2, inside the timed step
     sv = params.scheme.c
@@ -910,6 +915,40 @@ def main():
             result["strong_scaling_sweep_1gpu"] = sweep
         except Exception as e:
             result["strong_scaling_sweep_1gpu"] = {"error": repr(e)}
+
+    # ---- the same K steps with batch i+1's seed pass on a side stream BESIDE batch i's extension, the seed pass held to a grid of a few hundred workgroups
+    #      (2 waves per SIMD: the extension's VALU-bound kernels find room next to it).  The step is faster, but neither kernel then owns the GPU: the
+    #      seed launch takes twice as long as alone, which is why the headline and its roofline stay with the one-stream schedule ----
+    if rank == 0 and world == 1 and can_pipe and not args.no_overlap_leg and not args.overlap_seed_pass:
+        try:
+            ov_side = torch.cuda.Stream(device=device)
+            old_blocks = params.seed_grid_blocks
+            params.seed_grid_blocks = args.overlap_grid_blocks
+
+            def ov_steps(k, tm=None):
+                out = None; done = [None, None]
+                ov_side.wait_stream(torch.cuda.current_stream(device))
+                pre = pipeline.seed_pass_begin(fmi, batch, params, 0, tm, stream=ov_side) if k else None
+                for i in range(k):
+                    nxt = pipeline.seed_pass_begin(fmi, batch, params, (i + 1) & 1, tm, stream=ov_side, after=done[(i + 1) & 1]) if i + 1 < k else None
+                    out = pipeline.seed_and_extend(fmi, genome, n, batch, params, tm, pre=pre)
+                    done[i & 1] = torch.cuda.Event(); done[i & 1].record()
+                    pre = nxt
+                return out
+            ov_steps(max(2, args.warmup))
+            otm = {}
+            torch.cuda.synchronize(); o0 = time.perf_counter()
+            Ko = max(args.steps, 12)                                  # (the first batch's seed pass has nothing to run beside: a longer run shows the steady state)
+            obs, obp, obrc, onc = ov_steps(Ko, otm)
+            torch.cuda.synchronize(); odt = (time.perf_counter() - o0) / Ko
+            params.seed_grid_blocks = old_blocks
+            result["overlapped_step"] = {"ms_per_step": odt * 1e3, "reads_per_s": R / odt, "steps": Ko, "seed_pass_grid_blocks": args.overlap_grid_blocks,
+                                         "kernel_ms_while_sharing_the_gpu": {k: float(np.mean(event_ms(v))) for k, v in otm.items() if k in ("match_both", "extend")},
+                                         "results_equal": bool(torch.equal(obs, bs) and torch.equal(obp, bp) and torch.equal(obrc, brc)),
+                                         "note": "seed pass of batch i+1 on a side stream beside the extension of batch i (pipeline.seed_pass_begin( stream =, after = )); "
+                                                 "not the headline: every kernel's duration is then that of a shared GPU"}
+        except Exception as e:
+            result["overlapped_step"] = {"error": repr(e)}
 
     # ---- BASELINE configs 2, 4, 5 at kernel / composition level on the same index (untimed extras; rank 0, one GPU) ----
     if rank == 0 and world == 1 and not args.no_configs:

@@ -147,7 +147,8 @@ def seed_pass_begin(fmi, reads, params, slot=0, timers=None, stream=None, after=
         a.record()
     # seeds that end on 2..4 rows (short repeats) leave all their keys at once: on unique-ish genomes the residual lists stay
     # empty and the scan + locate path with its host round trips is not entered at all
-    fmi.match_seed_diagonals_both(geo["qs"], reads.read_len, b, inline_hits=min(4, params.max_seed_hits or 4), defer_heavy=params.defer_heavy)
+    fmi.match_seed_diagonals_both(geo["qs"], reads.read_len, b, inline_hits=min(4, params.max_seed_hits or 4), defer_heavy=params.defer_heavy,
+                                  grid_blocks=int(getattr(params, "seed_grid_blocks", 0) or 0))
     if ev_t is not None:
         ev_t.record()
     if "host" not in b:

@@ -68,6 +68,9 @@ def test_bench_json_contract(extra):
     assert [e["reads"] for e in sw] == [5000, 10000, 20000, 40000] and all(e["ms_per_step"] > 0 for e in sw)
     # the robust-input step (repeat family + per-base qualities + ragged reads) over the canonical table, checked against the plain operators
     if canon:
+        ov = d["overlapped_step"]
+        assert "error" not in ov, ov
+        assert ov["ms_per_step"] > 0 and ov["results_equal"] is True
         ch = d["cpp_host"]
         assert "error" not in ch, ch
         assert ch["ms_per_step"] > 0 and ch["results_equal_python_step"] is True
