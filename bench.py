@@ -1016,6 +1016,10 @@ def main():
                 raw = np.fromfile(outp, dtype=np.uint8)
                 cs_ = raw[:4 * R].view(np.int32); cp_ = raw[4 * R:12 * R].view(np.int64); cr_ = raw[12 * R:13 * R]
                 cj["results_equal_python_step"] = bool(np.array_equal(cs_, hbs) and np.array_equal(cp_, hbp) and np.array_equal(cr_, hbrc))
+                if not cj["results_equal_python_step"]:
+                    diff = np.nonzero((cs_ != hbs) | (cp_ != hbp) | (cr_ != hbrc))[0]
+                    cj["reads_that_differ"] = int(len(diff))
+                    cj["first_differences"] = [[int(r), int(cs_[r]), int(hbs[r]), int(cp_[r]), int(hbp[r]), int(cr_[r]), int(hbrc[r])] for r in diff[:8]]
                 cj["note"] = ("the timed step's composition without second best / MAPQ, host side in C++ (hipDeviceSynchronize at both ends of every step, "
                               "no step pipelining); same reads, same reference, its own index build")
                 result["cpp_host"] = cj

@@ -30,6 +30,15 @@ const char* get_error();
 #define NVB_REQUIRE(cond, msg)                                                                     \
     do { if (!(cond)) { nvbio_amd::set_error("invalid argument: %s", msg); return NVBIO_ERR_INVALID; } } while (0)
 
+// Scratch with stream-ordered semantics WITHOUT the runtime's stream-ordered pool: a block handed out by scratch_alloc may be used by work enqueued on
+// `s` after the call; scratch_free gives it back at once, for the next call on the SAME stream (whose work runs behind everything that used the block).
+// Blocks are plain hipMalloc allocations cached per (device, stream).  Why not hipMallocAsync / hipFreeAsync: on ROCm 7.2 a block RE-used from the
+// default pool did not hold what a kernel had just written into it -- the flags of the banded scorer's first pass read back as zeros in the second
+// call of a process (seen with hipMemcpy right behind the kernel; with hipMalloc / hipFree in its place: never), and once in a few fresh-box runs the
+// gap chance read zeros there in production (61,818 reads of 10 M scored -20 instead of -18).  core.hip.
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s);
+void       scratch_free(void* p, hipStream_t s);
+
 // select the device and fail loudly if it is not a gfx950: there is no CPU fallback
 nvbio_status use_device(int device);
 

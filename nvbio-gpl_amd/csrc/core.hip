@@ -1,5 +1,7 @@
 // core.hip -- status/error plumbing and device selection of the C ABI.
 #include "common.h"
+#include <mutex>
+#include <vector>
 
 namespace nvbio_amd {
 
@@ -13,6 +15,70 @@ void set_error(const char* fmt, ...)
     va_end( ap );
 }
 const char* get_error() { return g_error; }
+
+// ---- scratch blocks cached per (device, stream): see common.h ----
+namespace {
+struct ScratchBlock { void* p; size_t cap; bool busy; int device; hipStream_t stream; };
+std::mutex                 g_scratch_mutex;
+std::vector<ScratchBlock>  g_scratch;
+const size_t SCRATCH_KEEP_PER_STREAM = 64ull << 30;             // idle blocks beyond this are released (after the stream has drained)
+}
+
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
+{
+    *p = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice( &dev );
+    if (e != hipSuccess) return e;
+    if (bytes == 0) bytes = 256;
+    const size_t want = (bytes + ((2u << 20) - 1u)) & ~(size_t)((2u << 20) - 1u);
+    std::lock_guard<std::mutex> lock( g_scratch_mutex );
+    // best fit among this stream's idle blocks (not more than 4x the request: a boundary-column block is not spent on a counter)
+    int best = -1;
+    for (size_t i = 0; i < g_scratch.size(); ++i)
+    {
+        const ScratchBlock& b = g_scratch[i];
+        if (!b.busy && b.device == dev && b.stream == s && b.cap >= want && b.cap <= 4u * want + (64u << 20) && (best < 0 || b.cap < g_scratch[best].cap)) best = (int)i;
+    }
+    if (best >= 0) { g_scratch[best].busy = true; *p = g_scratch[best].p; return hipSuccess; }
+    void* q = nullptr;
+    e = hipMalloc( &q, want );
+    if (e != hipSuccess)
+    {
+        // out of memory: give this stream's idle blocks back (its work may still use them: drain it first) and try once more
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize( s );
+        for (size_t i = 0; i < g_scratch.size(); )
+        {
+            if (!g_scratch[i].busy && g_scratch[i].device == dev) { (void)hipFree( g_scratch[i].p ); g_scratch.erase( g_scratch.begin() + i ); }
+            else ++i;
+        }
+        e = hipMalloc( &q, want );
+        if (e != hipSuccess) return e;
+    }
+    g_scratch.push_back( ScratchBlock{ q, want, true, dev, s } );
+    *p = q;
+    return hipSuccess;
+}
+
+void scratch_free(void* p, hipStream_t s)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock( g_scratch_mutex );
+    size_t idle = 0; int dev = -1;
+    for (ScratchBlock& b : g_scratch)
+        if (b.p == p) { b.busy = false; dev = b.device; }
+    for (const ScratchBlock& b : g_scratch) if (!b.busy && b.device == dev && b.stream == s) idle += b.cap;
+    if (idle > SCRATCH_KEEP_PER_STREAM)
+    {
+        (void)hipStreamSynchronize( s );                          // work behind which the idle blocks were given back may still read them
+        for (size_t i = 0; i < g_scratch.size(); )
+        {
+            if (!g_scratch[i].busy && g_scratch[i].device == dev && g_scratch[i].stream == s) { (void)hipFree( g_scratch[i].p ); g_scratch.erase( g_scratch.begin() + i ); }
+            else ++i;
+        }
+    }
+}
 
 nvbio_status use_device(int device)
 {
@@ -43,21 +109,7 @@ nvbio_status use_device(int device)
         set_error( "hipSetDevice(%d) failed", device );
         return NVBIO_ERR_HIP;
     }
-    // Scratch (boundary columns, direction vectors, scan temporaries) comes from the device's stream-ordered
-    // pool.  By default the pool hands freed blocks back to the driver at every synchronisation, which makes
-    // each call pay for mapping gigabytes again (measured: 1.4 s per 16 GiB); let it keep up to 48 GiB (a paired-end
-    // step holds a scoring column, a banded and a full-matrix direction scratch at once).
-    static bool pool_ready[64] = { false };
-    if (device < 64 && !pool_ready[device])
-    {
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool( &pool, device ) == hipSuccess)
-        {
-            uint64_t keep = 48ull << 30;
-            (void)hipMemPoolSetAttribute( pool, hipMemPoolAttrReleaseThreshold, &keep );
-        }
-        pool_ready[device] = true;
-    }
+    // (scratch -- boundary columns, direction vectors, scan temporaries -- comes from scratch_alloc above, not from the runtime's stream-ordered pool)
     return NVBIO_OK;
 }
 

@@ -1519,9 +1519,9 @@ nvbio_status nvbio_fm_filter_scan(nvbio_fm_index_t index, const nvbio_uint2* ran
     size_t temp_bytes = 0;
     NVB_HIP( hipcub::DeviceScan::InclusiveSum( nullptr, temp_bytes, sizes, slots_dev, (int)n_queries, s ) );
     void* temp = nullptr;
-    if (hipMallocAsync( &temp, temp_bytes ? temp_bytes : 16, s ) != hipSuccess) { set_error( "filter_scan: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (scratch_alloc( &temp, temp_bytes ? temp_bytes : 16, s ) != hipSuccess) { set_error( "filter_scan: out of device memory" ); return NVBIO_ERR_NOMEM; }
     const hipError_t e = hipcub::DeviceScan::InclusiveSum( temp, temp_bytes, sizes, slots_dev, (int)n_queries, s );
-    (void)hipFreeAsync( temp, s );
+    scratch_free( temp, s );
     if (e != hipSuccess) { set_error( "filter_scan: scan failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     NVB_HIP( hipMemcpyAsync( n_hits, slots_dev + (n_queries - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s ) );
     NVB_HIP( hipStreamSynchronize( s ) );
@@ -1606,7 +1606,7 @@ nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_stri
     DeviceGuard g( idx->device ); if (!g.ok) return NVBIO_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     uint32_t* overflow = nullptr;
-    NVB_HIP( hipMallocAsync( (void**)&overflow, sizeof(uint32_t), s ) );
+    NVB_HIP( scratch_alloc( (void**)&overflow, sizeof(uint32_t), s ) );
     NVB_HIP( hipMemsetAsync( overflow, 0, sizeof(uint32_t), s ) );
     const DevIndex f = idx->dev();
     const dim3 grid( grid_for( q.n, 128 ) ), block( 128 );
@@ -1623,7 +1623,7 @@ nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_stri
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync( &h_over, overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s );
     if (e == hipSuccess) e = hipStreamSynchronize( s );
-    (void)hipFreeAsync( overflow, s );
+    scratch_free( overflow, s );
     if (e != hipSuccess) { set_error( "hamming_backtrack failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     if (h_over) { set_error( "hamming_backtrack: the 128-entry stack of the reference's benchmark overflowed for %u branches", h_over ); return NVBIO_ERR_UNSUPPORTED; }
     return NVBIO_OK;
@@ -1689,7 +1689,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
     bool own_temp = false;
     if (temp == nullptr)
     {
-        if (hipMallocAsync( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
+        if (scratch_alloc( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
         own_temp = true;
     }
     else NVB_REQUIRE( temp_bytes >= L.total, "temp_bytes too small (nvbio_fm_match_seed_diagonals_temp_bytes)" );
@@ -1731,7 +1731,7 @@ nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_s
                             (const uint32_t*)tile_offsets, L.tl.n_tiles, L.slots, keys_dev, (unsigned int*)counts_dev );
         e = hipGetLastError();
     }
-    if (own_temp) (void)hipFreeAsync( temp, s );
+    if (own_temp) scratch_free( temp, s );
     if (e != hipSuccess) { set_error( "seed pass failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }
@@ -1813,7 +1813,7 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
     bool own_temp = false;
     if (temp == nullptr)
     {
-        if (hipMallocAsync( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
+        if (scratch_alloc( (void**)&temp, L.total, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "seed pass: out of device memory for %llu bytes of scratch", (unsigned long long)L.total ); return NVBIO_ERR_NOMEM; }
         own_temp = true;
     }
     else NVB_REQUIRE( temp_bytes >= L.total, "temp_bytes too small (nvbio_fm_match_seed_diagonals_both_temp_bytes)" );
@@ -1875,7 +1875,7 @@ nvbio_status nvbio_fm_match_seed_diagonals_both(nvbio_fm_index_t index, const nv
             e = hipGetLastError();
         }
     }
-    if (own_temp) (void)hipFreeAsync( temp, s );
+    if (own_temp) scratch_free( temp, s );
     if (e != hipSuccess) { set_error( "seed pass failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }
@@ -1966,7 +1966,7 @@ nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uin
     size_t sort_bytes = 0;
     NVB_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 32, s ) );
     uint8_t* aux = nullptr;
-    if (hipMallocAsync( (void**)&aux, ids_bytes + rng_bytes + sort_bytes + 256u, s ) != hipSuccess)
+    if (scratch_alloc( (void**)&aux, ids_bytes + rng_bytes + sort_bytes + 256u, s ) != hipSuccess)
     {
         (void)hipGetLastError();
         set_error( "residual diagonals: out of device memory" );
@@ -1983,7 +1983,7 @@ nvbio_status nvbio_fm_residual_diagonals(nvbio_fm_index_t index, const nvbio_uin
                             keys_dev, (unsigned int*)n_keys_dev );
         e = hipGetLastError();
     }
-    (void)hipFreeAsync( aux, s );
+    scratch_free( aux, s );
     if (e != hipSuccess) { set_error( "residual diagonals failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }

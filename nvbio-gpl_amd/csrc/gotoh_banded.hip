@@ -1419,7 +1419,7 @@ static nvbio_status sort_jobs_by_length(const BatchDev& b, const uint32_t* job_l
     NVB_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, sort_bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                                  (int)b.n, 0, bits, s ) );
     uint8_t* aux = nullptr;
-    if (hipMallocAsync( (void**)&aux, 2u * kb + 2u * lb + 256u + sort_bytes, s ) != hipSuccess)
+    if (scratch_alloc( (void**)&aux, 2u * kb + 2u * lb + 256u + sort_bytes, s ) != hipSuccess)
     {
         (void)hipGetLastError();
         set_error( "banded score: out of device memory for the length-sorted job list" );
@@ -1431,7 +1431,7 @@ static nvbio_status sort_jobs_by_length(const BatchDev& b, const uint32_t* job_l
     void* tmp = aux + 2u * kb + 2u * lb + 256u;
     hipLaunchKernelGGL( job_length_keys_kernel, dim3( (b.n + 255u) / 256u < 65536u ? (b.n + 255u) / 256u : 65536u ), dim3( 256 ), 0, s, b, job_list, job_count, k_in, l_all, c_all );
     const hipError_t e = hipcub::DeviceRadixSort::SortPairs( tmp, sort_bytes, (const uint16_t*)k_in, k_out, job_list ? job_list : (const uint32_t*)l_all, l_out, (int)b.n, 0, bits, s );
-    if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "job sort failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+    if (e != hipSuccess) { scratch_free( aux, s ); set_error( "job sort failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     *list_out = l_out; *count_out = job_list ? job_count : c_all; *aux_out = aux;
     return NVBIO_OK;
 }
@@ -1495,7 +1495,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         const FlagIs is3 = { nullptr, 3 }; const FlagIn is2 = { nullptr, 0u };
         NVB_HIP( hipcub::DevicePartition::If( nullptr, part_bytes, ids, (uint32_t*)nullptr, (uint32_t*)nullptr, nowhere, (uint32_t*)nullptr, (int)b.n, is3, is2, s ) );
         if (part_bytes > sel_bytes) sel_bytes = part_bytes;
-        if (hipMallocAsync( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (scratch_alloc( &aux, flags_bytes + 3u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
             set_error( "banded score: out of device memory for the job list" );
@@ -1545,12 +1545,12 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
             if (TYPE == NVBIO_SEMI_GLOBAL && sc.match == 0 && (b.algo & NVBIO_ALN_RAGGED_READS) && !(b.algo & NVBIO_ALN_NO_LENGTH_SORT))
             {
                 const nvbio_status st = sort_jobs_by_length( b, job_list, job_count, &jl, &jc, &aux2, s );
-                if (st != NVBIO_OK) { (void)hipFreeAsync( aux, s ); return st; }
+                if (st != NVBIO_OK) { scratch_free( aux, s ); return st; }
             }
             launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, jl, jc, s );
-            if (aux2) (void)hipFreeAsync( aux2, s );
+            if (aux2) scratch_free( aux2, s );
         }
-        (void)hipFreeAsync( aux, s );
+        scratch_free( aux, s );
         if (e != hipSuccess) { set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
         NVB_HIP( hipGetLastError() );
         return NVBIO_OK;
@@ -1560,7 +1560,7 @@ static nvbio_status launch_pk(const BatchDev& b, const SchemeDev& sc, int32_t* s
         const uint32_t* jl = nullptr; const uint32_t* jc = nullptr; void* aux2 = nullptr;
         NVB_CHECK( sort_jobs_by_length( b, nullptr, nullptr, &jl, &jc, &aux2, s ) );
         launch_pk_kernel<TYPE,RB>( b, sc, pairs, scores, sinks, jl, jc, s );
-        (void)hipFreeAsync( aux2, s );
+        scratch_free( aux2, s );
         NVB_HIP( hipGetLastError() );
         return NVBIO_OK;
     }

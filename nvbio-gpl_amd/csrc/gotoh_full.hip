@@ -1352,7 +1352,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         // (the narrow route: one more flag array, its job list, the band windows; see narrow_jobs_kernel)
         const bool narrow = shortcut && !text_blocking && !(b.algo & (NVBIO_ALN_NO_NARROW_SCORE | NVBIO_ALN_NO_PACKED_DP)) && max_pattern_len <= 161u &&
                             banded31_packed_ok( sc, max_pattern_len ) && sc.pat_ge < 0;
-        if (hipMallocAsync( &aux, 4u * flags_bytes + 5u * list_bytes + 512u + sel_bytes, s ) != hipSuccess)
+        if (scratch_alloc( &aux, 4u * flags_bytes + 5u * list_bytes + 512u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
             set_error( "full Gotoh: out of device memory for the job lists" );
@@ -1386,7 +1386,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
                 uint32_t* list_s = list_n; uint32_t* count_s = count_n + 1;                    // (the narrow route's list is built after this)
                 hipcub::TransformInputIterator<uint8_t, FlagIs3, const uint8_t*> is3( need_dp, FlagIs3() );
                 const hipError_t e3 = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is3, list_s, count_s, (int)b.n, s );
-                if (e3 != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e3 ) ); return NVBIO_ERR_HIP; }
+                if (e3 != hipSuccess) { scratch_free( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e3 ) ); return NVBIO_ERR_HIP; }
                 if (batch->read_bits == 4) hipLaunchKernelGGL( (ungapped_full_e2e_kernel<4,1>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
                                                                (const uint32_t*)list_s, (const uint32_t*)count_s );
                 else                       hipLaunchKernelGGL( (ungapped_full_e2e_kernel<2,1>), grid, block, 0, s, b, P, G, sc.pat_go, sc.pat_ge, second_chance, min_scores_dev, text_blocking != 0, scores_dev, (uint2*)sinks_dev, need_dp, narrow,
@@ -1419,7 +1419,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
             list_a = nullptr; count_a = nullptr;
             e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
         }
-        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        if (e != hipSuccess) { scratch_free( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
     // boundary columns: caller scratch if given, else stream-ordered scratch; jobs are processed in
@@ -1432,7 +1432,7 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         cap_jobs = temp_bytes / (rows * sizeof(uint32_t));
         if (!(cap_jobs >= 64 || cap_jobs >= b.n))
         {
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "invalid argument: temp_bytes too small (see nvbio_full_gotoh_temp_bytes)" );
             return NVBIO_ERR_INVALID;
         }
@@ -1443,10 +1443,10 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
         const uint64_t budget = 8ull << 30;                      // at most 8 GiB of scratch per launch
         if (cap_jobs * rows * sizeof(uint32_t) > budget) cap_jobs = budget / (rows * sizeof(uint32_t));
         if (cap_jobs < 64) cap_jobs = 64;
-        if (hipMallocAsync( &owned, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
+        if (scratch_alloc( &owned, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
         {
             (void)hipGetLastError();
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
         }
@@ -1489,8 +1489,8 @@ static nvbio_status full_score(int device, int type, int text_blocking, const Sc
             launch_type<true> ( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s, job_list, job_count ) :
             launch_type<false>( type, b, sc, batch->read_bits, batch->text_bits, (uint32_t)begin, jobs, min_scores_dev, column, scores_dev, (uint2*)sinks_dev, s, job_list, job_count );
     }
-    if (owned) (void)hipFreeAsync( owned, s );
-    if (aux)   (void)hipFreeAsync( aux, s );
+    if (owned) scratch_free( owned, s );
+    if (aux)   scratch_free( aux, s );
     return st;
 }
 
@@ -1544,7 +1544,7 @@ extern "C" nvbio_status nvbio_full_gotoh_score_best2(int device, nvbio_alignment
     if (cap_jobs * rows * sizeof(uint32_t) > budget) cap_jobs = budget / (rows * sizeof(uint32_t));
     if (cap_jobs < 64) cap_jobs = 64;
     void* column = nullptr;
-    if (hipMallocAsync( &column, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
+    if (scratch_alloc( &column, cap_jobs * rows * sizeof(uint32_t), s ) != hipSuccess)
     {
         (void)hipGetLastError();
         set_error( "full Gotoh: out of device memory for %llu boundary columns", (unsigned long long)cap_jobs );
@@ -1559,7 +1559,7 @@ extern "C" nvbio_status nvbio_full_gotoh_score_best2(int device, nvbio_alignment
         st = type == NVBIO_GLOBAL ? NVB_B2( NVBIO_GLOBAL ) : type == NVBIO_LOCAL ? NVB_B2( NVBIO_LOCAL ) : NVB_B2( NVBIO_SEMI_GLOBAL );
 #undef NVB_B2
     }
-    (void)hipFreeAsync( column, s );
+    scratch_free( column, s );
     return st;
 }
 

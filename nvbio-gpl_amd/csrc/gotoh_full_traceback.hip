@@ -572,7 +572,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, 2u * flags_bytes + 4u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (scratch_alloc( &aux, 2u * flags_bytes + 4u * list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
             set_error( "full traceback: out of device memory for the job list" );
@@ -606,7 +606,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
             e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, band_route, band_list, band_count, (int)b.n, s );
         }
         if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, need_dp, job_list, job_count, (int)b.n, s );
-        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        if (e != hipSuccess) { scratch_free( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
     // ---- 4. the DP with direction vectors + walk, over the job list (or every job) ----
@@ -617,7 +617,7 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         cap_jobs = (temp_bytes / per_job) & ~63ull;                  // whole waves of 64 jobs
         if (cap_jobs < 64)
         {
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "invalid argument: temp_bytes too small (see nvbio_full_gotoh_traceback_temp_bytes)" );
             return NVBIO_ERR_INVALID;
         }
@@ -629,10 +629,10 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
         const uint64_t budget = 8ull << 30;
         if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
         cap_jobs = (cap_jobs + 63u) & ~63ull;
-        if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
+        if (scratch_alloc( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
             (void)hipGetLastError();
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "full traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
         }
@@ -667,8 +667,8 @@ static nvbio_status full_traceback_impl(int device, nvbio_alignment_type type, c
 #undef NVB_TB
         if (hipGetLastError() != hipSuccess) { set_error( "full traceback launch failed" ); st = NVBIO_ERR_HIP; }
     }
-    if (owned) (void)hipFreeAsync( owned, s );
-    if (aux)   (void)hipFreeAsync( aux, s );
+    if (owned) scratch_free( owned, s );
+    if (aux)   scratch_free( aux, s );
     return st;
 }
 

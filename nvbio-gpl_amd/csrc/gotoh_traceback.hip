@@ -592,7 +592,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, sel_bytes, ids, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)b.n, s ) );
         const uint64_t flags_bytes = ((uint64_t)b.n + 255u) & ~255ull;
         const uint64_t list_bytes  = ((uint64_t)b.n * 4u + 255u) & ~255ull;
-        if (hipMallocAsync( &aux, 2u * (flags_bytes + list_bytes + 256u) + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
+        if (scratch_alloc( &aux, 2u * (flags_bytes + list_bytes + 256u) + list_bytes + 256u + sel_bytes, s ) != hipSuccess)
         {
             (void)hipGetLastError();
             set_error( "banded traceback: out of device memory for the job list" );
@@ -619,7 +619,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         default: NVB_BAND(31); break;
         }
 #undef NVB_BAND
-        if (st1 != NVBIO_OK) { (void)hipFreeAsync( aux, s ); return st1; }
+        if (st1 != NVBIO_OK) { scratch_free( aux, s ); return st1; }
         // ---- 3. the jobs that do need the DP, compacted (their number stays on the device) ----
         hipcub::TransformInputIterator<uint8_t, IsCode<1>, const uint8_t*> is_full( need_dp, IsCode<1>() );
         hipcub::TransformInputIterator<uint8_t, IsCode<2>, const uint8_t*> is_narrow( need_dp, IsCode<2>() );
@@ -627,7 +627,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         if (e == hipSuccess && narrow) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_narrow, job_list2, job_count2, (int)b.n, s );
         hipcub::TransformInputIterator<uint8_t, IsCode<3>, const uint8_t*> is_narrow7( need_dp, IsCode<3>() );
         if (e == hipSuccess && narrow) e = hipcub::DeviceSelect::Flagged( sel_temp, sel_bytes, ids, is_narrow7, job_list3, job_count3, (int)b.n, s );
-        if (e != hipSuccess) { (void)hipFreeAsync( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
+        if (e != hipSuccess) { scratch_free( aux, s ); set_error( "DeviceSelect failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     }
 
     // ---- 4. the DP with direction vectors + walk back, over the job list (or every job) ----
@@ -640,7 +640,7 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         cap_jobs = temp_bytes / per_job;
         if (!(cap_jobs >= 64 || cap_jobs >= b.n))
         {
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "invalid argument: temp_bytes too small (see nvbio_banded_gotoh_traceback_temp_bytes)" );
             return NVBIO_ERR_INVALID;
         }
@@ -654,10 +654,10 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
         const uint64_t budget = 16ull << 30;                     // at most 16 GiB of scratch per launch
         if (cap_jobs * per_job > budget) cap_jobs = budget / per_job;
         if (cap_jobs < 64) cap_jobs = 64;
-        if (hipMallocAsync( &owned, cap_jobs * per_job, s ) != hipSuccess)
+        if (scratch_alloc( &owned, cap_jobs * per_job, s ) != hipSuccess)
         {
             (void)hipGetLastError();
-            if (aux) (void)hipFreeAsync( aux, s );
+            if (aux) scratch_free( aux, s );
             set_error( "banded traceback: out of device memory for %llu direction matrices", (unsigned long long)cap_jobs );
             return NVBIO_ERR_NOMEM;
         }
@@ -696,8 +696,8 @@ static nvbio_status banded_traceback_impl(int device, uint32_t band, nvbio_align
                                  (uint2*)sources_dev, (uint2*)sinks_dev, cigars_dev, cigar_stride, cigar_lens_dev, s, band_off );
         }
     }
-    if (owned) (void)hipFreeAsync( owned, s );
-    if (aux)   (void)hipFreeAsync( aux, s );
+    if (owned) scratch_free( owned, s );
+    if (aux)   scratch_free( aux, s );
     return st;
 }
 

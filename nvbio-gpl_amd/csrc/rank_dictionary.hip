@@ -129,9 +129,9 @@ nvbio_status nvbio_rank_dictionary_build(int device, const nvbio_rank_dictionary
     uint32_t* cnt = nullptr; uint64_t* sums = nullptr; void* temp = nullptr; size_t temp_bytes = 0;
     hipcub::TransformInputIterator<uint64_t, U32toU64, const uint32_t*> in0( (const uint32_t*)nullptr, U32toU64() );
     hipError_t e = hipcub::DeviceScan::ExclusiveSum( nullptr, temp_bytes, in0, (uint64_t*)nullptr, (int)nb, s );
-    if (e == hipSuccess) e = hipMallocAsync( (void**)&cnt, 4ull * nb * sizeof(uint32_t), s );
-    if (e == hipSuccess) e = hipMallocAsync( (void**)&sums, 4ull * nb * sizeof(uint64_t), s );
-    if (e == hipSuccess) e = hipMallocAsync( &temp, temp_bytes ? temp_bytes : 16, s );
+    if (e == hipSuccess) e = scratch_alloc( (void**)&cnt, 4ull * nb * sizeof(uint32_t), s );
+    if (e == hipSuccess) e = scratch_alloc( (void**)&sums, 4ull * nb * sizeof(uint64_t), s );
+    if (e == hipSuccess) e = scratch_alloc( &temp, temp_bytes ? temp_bytes : 16, s );
     if (e == hipSuccess)
     {
         if (dict->word_bits == 32) hipLaunchKernelGGL( block_symbol_counts_kernel<uint32_t>, dim3( grid_for( nb ) ), dim3(256), 0, s, (const uint32_t*)dict->text_dev, dict->length, dict->K, nb, cnt );
@@ -157,9 +157,9 @@ nvbio_status nvbio_rank_dictionary_build(int device, const nvbio_rank_dictionary
         if (e == hipSuccess) e = hipMemcpyAsync( &last_cnt[c], cnt + c * nb + nb - 1u, sizeof(uint32_t), hipMemcpyDeviceToHost, s );
     }
     if (e == hipSuccess) e = hipStreamSynchronize( s );
-    if (cnt)  (void)hipFreeAsync( cnt, s );
-    if (sums) (void)hipFreeAsync( sums, s );
-    if (temp) (void)hipFreeAsync( temp, s );
+    if (cnt)  scratch_free( cnt, s );
+    if (sums) scratch_free( sums, s );
+    if (temp) scratch_free( temp, s );
     if (e != hipSuccess) { (void)hipGetLastError(); set_error( "rank_dictionary_build failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     for (uint32_t c = 0; c < 4u; ++c) counts[c] = last_sum[c] + last_cnt[c];
     return NVBIO_OK;

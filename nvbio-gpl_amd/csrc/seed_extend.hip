@@ -683,7 +683,7 @@ extern "C" nvbio_status nvbio_sort_unique_keys(int device, uint64_t* keys_dev, u
     uint8_t* temp = (uint8_t*)temp_dev; bool own = false;
     if (!temp)
     {
-        if (hipMallocAsync( (void**)&temp, need, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "sort_unique_keys: out of device memory" ); return NVBIO_ERR_NOMEM; }
+        if (scratch_alloc( (void**)&temp, need, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "sort_unique_keys: out of device memory" ); return NVBIO_ERR_NOMEM; }
         own = true;
     }
     else NVB_REQUIRE( temp_bytes >= need, "temp_bytes too small (nvbio_sort_unique_keys_temp_bytes)" );
@@ -693,7 +693,7 @@ extern "C" nvbio_status nvbio_sort_unique_keys(int device, uint64_t* keys_dev, u
     size_t    work_bytes = (size_t)(need - 512u - n * sizeof(uint64_t));
     hipError_t e = hipcub::DeviceRadixSort::SortKeys( work, work_bytes, (const uint64_t*)keys_dev, sorted, (int)n, 0, 64, s );
     if (e == hipSuccess) e = hipcub::DeviceSelect::Unique( work, work_bytes, (const uint64_t*)sorted, keys_dev, n_out_dev, (int)n, s );
-    if (own) (void)hipFreeAsync( temp, s );
+    if (own) scratch_free( temp, s );
     if (e != hipSuccess) { set_error( "sort_unique_keys failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }

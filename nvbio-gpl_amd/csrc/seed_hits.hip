@@ -468,10 +468,10 @@ nvbio_status nvbio_read_queue_filter(int device, const uint32_t* queue_dev, uint
     hipcub::CountingInputIterator<uint32_t> ids( 0u );
     if (queue_dev) NVB_HIP( hipcub::DeviceSelect::If( nullptr, bytes, queue_dev, queue_out_dev, count_dev, (int)n, pred, s ) );
     else           NVB_HIP( hipcub::DeviceSelect::If( nullptr, bytes, ids, queue_out_dev, count_dev, (int)n, pred, s ) );
-    if (hipMallocAsync( &tmp, bytes ? bytes : 16, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "read_queue_filter: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (scratch_alloc( &tmp, bytes ? bytes : 16, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "read_queue_filter: out of device memory" ); return NVBIO_ERR_NOMEM; }
     const hipError_t e = queue_dev ? hipcub::DeviceSelect::If( tmp, bytes, queue_dev, queue_out_dev, count_dev, (int)n, pred, s )
                                    : hipcub::DeviceSelect::If( tmp, bytes, ids, queue_out_dev, count_dev, (int)n, pred, s );
-    (void)hipFreeAsync( tmp, s );
+    scratch_free( tmp, s );
     if (e != hipSuccess) { set_error( "read_queue_filter failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }
@@ -488,9 +488,9 @@ nvbio_status nvbio_select_flagged_indices(int device, const uint8_t* flags_dev, 
     size_t bytes = 0; void* tmp = nullptr;
     hipcub::CountingInputIterator<uint32_t> ids( 0u );
     NVB_HIP( hipcub::DeviceSelect::Flagged( nullptr, bytes, ids, flags_dev, queue_out_dev, count_dev, (int)n, s ) );
-    if (hipMallocAsync( &tmp, bytes ? bytes : 16, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "select_flagged_indices: out of device memory" ); return NVBIO_ERR_NOMEM; }
+    if (scratch_alloc( &tmp, bytes ? bytes : 16, s ) != hipSuccess) { (void)hipGetLastError(); set_error( "select_flagged_indices: out of device memory" ); return NVBIO_ERR_NOMEM; }
     const hipError_t e = hipcub::DeviceSelect::Flagged( tmp, bytes, ids, flags_dev, queue_out_dev, count_dev, (int)n, s );
-    (void)hipFreeAsync( tmp, s );
+    scratch_free( tmp, s );
     if (e != hipSuccess) { set_error( "select_flagged_indices failed: %s", hipGetErrorString( e ) ); return NVBIO_ERR_HIP; }
     return NVBIO_OK;
 }

@@ -38,7 +38,7 @@ struct Rng { uint64_t s; uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 
 int main(int argc, char** argv)
 {
     const char *genome_path = nullptr, *reads_path = nullptr, *out_path = nullptr;
-    uint64_t genome_len = 0; uint32_t n_reads = 0, read_len = 150, steps = 3, kmer = 17; bool synthetic = false, canonical = true;
+    uint64_t genome_len = 0; uint32_t n_reads = 0, read_len = 150, steps = 3, kmer = 17, algo_flags = 0; bool synthetic = false, canonical = true, poison = false;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -53,6 +53,8 @@ int main(int argc, char** argv)
         else if (a == "--kmer")       kmer = (uint32_t)atoi( val() );
         else if (a == "--synthetic")  synthetic = true;
         else if (a == "--no-canonical") canonical = false;
+        else if (a == "--poison")     poison = true;                                // overwrite the score / sink arrays before every scoring call (no result may come from the step before)
+        else if (a == "--algo-flags") algo_flags = (uint32_t)atoi( val() );       // nvbio_alignment_batch::algo_flags of the extension (NVBIO_ALN_*: A/B runs)
         else { fprintf( stderr, "unknown argument %s\n", a.c_str() ); return 2; }
     }
     if (!genome_len || !n_reads || (!synthetic && !(genome_path && reads_path))) { fprintf( stderr, "usage: see the head of fmmap_amd.cpp\n" ); return 2; }
@@ -175,7 +177,12 @@ int main(int argc, char** argv)
                 check( nvbio_diagonals_to_windows( 0, keys.data(), n, BAND, M, N, rid.data(), flags.data(), wb.data(), we.data(), 0 ) );
                 nvbio_alignment_batch b; memset( &b, 0, sizeof(b) );
                 b.reads_dev = d_reads.data(); b.read_bits = 4; b.read_offsets_dev = offs.data(); b.read_id_dev = rid.data(); b.flags_dev = flags.data();
-                b.text_dev = d_genome.data(); b.text_bits = 2; b.win_begin_dev = wb.data(); b.win_end_dev = we.data(); b.n = (uint32_t)n; b.max_read_len = M;
+                b.text_dev = d_genome.data(); b.text_bits = 2; b.win_begin_dev = wb.data(); b.win_end_dev = we.data(); b.n = (uint32_t)n; b.max_read_len = M; b.algo_flags = algo_flags;
+                if (poison)
+                {
+                    check_hip( hipMemsetAsync( scores.data(), 0x5A, (size_t)n * sizeof(int32_t), 0 ), "hipMemsetAsync" );
+                    check_hip( hipMemsetAsync( sinks.data(), 0x5A, (size_t)n * sizeof(nvbio_uint2), 0 ), "hipMemsetAsync" );
+                }
                 check( nvbio_banded_gotoh_score( 0, BAND, NVBIO_SEMI_GLOBAL, &fs, &b, scores.data(), sinks.data(), 0 ) );
                 check( nvbio_best_candidate_reduce( 0, keys.data(), scores.data(), sinks.data(), wb.data(), n, best.data(), 0 ) );
             }
