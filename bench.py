@@ -964,7 +964,7 @@ def main():
         try:
             stored4 = pack4(reads_sym.flip(1).reshape(-1))                       # nvBowtie stores reads reversed (io::REVERSE)
             sb = pipeline.ReadBatch(stored4, R, M)
-            pipeline.nvbowtie_best_approx_host(fmi, genome, n, pipeline.ReadBatch(stored4[:(min(R, 100000) * M + 7) // 8 + 4], min(R, 100000), M), params)   # warm
+            pipeline.nvbowtie_best_approx_host(fmi, genome, n, sb, params)       # warm, at full size: the library's scratch blocks are cached per stream by size
             torch.cuda.synchronize(); t0 = time.perf_counter()
             nb = pipeline.nvbowtie_best_approx_host(fmi, genome, n, sb, params)
             torch.cuda.synchronize(); ndt = time.perf_counter() - t0
@@ -999,6 +999,7 @@ def main():
             fmi.close()
             del fmi
             torch.cuda.empty_cache()
+            amd.release_scratch()                                   # the library keeps its scratch blocks per stream: the second index needs the room
         except Exception as e:
             result["robust"] = {"error": repr(e)}
         if cpp_inputs is not None:

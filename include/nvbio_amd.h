@@ -17,6 +17,9 @@
  *     default stream) and is asynchronous; nvbio_amd_stream_synchronize() (or the caller's
  *     own hipStreamSynchronize) waits for it.  Calls on one handle from several host
  *     threads are safe as long as each thread uses its own stream and output buffers.
+ *   - scratch a call needs beyond the caller's buffers (job lists, boundary columns, scan temporaries) comes from device blocks the
+ *     library allocates with hipMalloc and KEEPS, per (device, stream), for the next call on that stream: after the first calls at a
+ *     given size no call allocates.  nvbio_amd_release_scratch() gives the idle blocks back (it synchronises their streams).
  *   - results are bit-identical to the reference's CPU path: SA ranges, SA rows and text
  *     positions as uint32, scores as int32, sinks as (text, pattern) uint32 pairs.
  */
@@ -47,6 +50,8 @@ const char* nvbio_amd_last_error(void);
 nvbio_status nvbio_amd_device_count(int* count);
 nvbio_status nvbio_amd_device_arch(int device, char* name, uint32_t name_len);
 nvbio_status nvbio_amd_stream_synchronize(int device, void* stream);
+/* hipFree every scratch block that no call is using (see "Conventions"); each behind a synchronisation of the stream it served */
+nvbio_status nvbio_amd_release_scratch(void);
 
 /* -------------------------------------------------------------------------------------------
  * pair of uint32, layout-compatible with the reference's uint2 (SA ranges, hits, sinks)

@@ -123,6 +123,11 @@ def lib():
     return _lib
 
 
+def release_scratch():
+    """nvbio_amd_release_scratch: give the library's idle scratch blocks back to the driver (it keeps them per stream between calls)"""
+    _check(lib().nvbio_amd_release_scratch())
+
+
 def _check(status):
     if status != 0:
         raise NvbioError(status, lib().nvbio_amd_last_error().decode())

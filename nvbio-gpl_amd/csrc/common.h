@@ -38,6 +38,7 @@ const char* get_error();
 // gap chance read zeros there in production (61,818 reads of 10 M scored -20 instead of -18).  core.hip.
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s);
 void       scratch_free(void* p, hipStream_t s);
+void       scratch_release_idle();                        // hipFree every idle block (each behind a synchronisation of its stream)
 
 // select the device and fail loudly if it is not a gfx950: there is no CPU fallback
 nvbio_status use_device(int device);

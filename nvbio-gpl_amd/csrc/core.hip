@@ -33,12 +33,12 @@ hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
     if (bytes == 0) bytes = 256;
     const size_t want = (bytes + ((2u << 20) - 1u)) & ~(size_t)((2u << 20) - 1u);
     std::lock_guard<std::mutex> lock( g_scratch_mutex );
-    // best fit among this stream's idle blocks (not more than 4x the request: a boundary-column block is not spent on a counter)
+    // best fit among this stream's idle blocks (any larger block will do: a loop whose requests shrink from pass to pass must not allocate in every pass)
     int best = -1;
     for (size_t i = 0; i < g_scratch.size(); ++i)
     {
         const ScratchBlock& b = g_scratch[i];
-        if (!b.busy && b.device == dev && b.stream == s && b.cap >= want && b.cap <= 4u * want + (64u << 20) && (best < 0 || b.cap < g_scratch[best].cap)) best = (int)i;
+        if (!b.busy && b.device == dev && b.stream == s && b.cap >= want && (best < 0 || b.cap < g_scratch[best].cap)) best = (int)i;
     }
     if (best >= 0) { g_scratch[best].busy = true; *p = g_scratch[best].p; return hipSuccess; }
     void* q = nullptr;
@@ -59,6 +59,24 @@ hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
     g_scratch.push_back( ScratchBlock{ q, want, true, dev, s } );
     *p = q;
     return hipSuccess;
+}
+
+void scratch_release_idle()
+{
+    std::lock_guard<std::mutex> lock( g_scratch_mutex );
+    int prev = -1; (void)hipGetDevice( &prev );
+    for (size_t i = 0; i < g_scratch.size(); )
+    {
+        if (!g_scratch[i].busy)
+        {
+            (void)hipSetDevice( g_scratch[i].device );
+            (void)hipStreamSynchronize( g_scratch[i].stream );   // work behind which the block was given back may still use it
+            (void)hipFree( g_scratch[i].p );
+            g_scratch.erase( g_scratch.begin() + i );
+        }
+        else ++i;
+    }
+    if (prev >= 0) (void)hipSetDevice( prev );
 }
 
 void scratch_free(void* p, hipStream_t s)
@@ -120,6 +138,7 @@ using namespace nvbio_amd;
 extern "C" {
 
 int         nvbio_amd_version(void)    { return NVBIO_AMD_VERSION; }
+nvbio_status nvbio_amd_release_scratch(void) { scratch_release_idle(); return NVBIO_OK; }
 const char* nvbio_amd_last_error(void) { return get_error(); }
 
 nvbio_status nvbio_amd_device_count(int* count)
