@@ -21,7 +21,7 @@ namespace {
 struct ScratchBlock { void* p; size_t cap; bool busy; int device; hipStream_t stream; };
 std::mutex                 g_scratch_mutex;
 std::vector<ScratchBlock>  g_scratch;
-const size_t SCRATCH_KEEP_PER_STREAM = 64ull << 30;             // idle blocks beyond this are released (after the stream has drained)
+const size_t SCRATCH_KEEP_PER_STREAM = 32ull << 30;             // idle blocks beyond this are released (after the stream has drained)
 }
 
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
