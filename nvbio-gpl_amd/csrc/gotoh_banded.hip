@@ -1087,7 +1087,9 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
 // mismatches exists iff lead_i(d-g) + tail_{e-i}(d) >= M for some i <= e, a pattern gap (prefix on d, suffix on d-g, ending in d-g) iff
 // lead_i(d) + tail_{e-i}(d-g) + g >= M.  The minimum c* over all of them and the LARGEST end column among the members that reach it are the
 // DP's optimum and BestSink's sink, PROVIDED no other alignment costs <= c*:
-//   * ungapped: every diagonal has more than `cap` mismatches (why the job is here): >= (cap + 1) P;
+//   * ungapped: every diagonal has more than `cap` mismatches (why a need_dp = 4 job is here): >= (cap + 1) P.  A THIRD-CHANCE job (need_dp = 2)
+//     brings its best diagonal instead (2 or 3 mismatches, U* and column stashed by the first pass): that class joins the evaluated ones with its
+//     exact cost -P U* and its column, every other diagonal costs at least as much, and the term drops out of the bound;
 //   * one gap with 3 mismatches, or of 6 symbols: Cg(1) + 3 P, Cg(6);  three gaps: 3 Cg(1);  two gaps and a mismatch: 2 Cg(1) + P;
 //     two gaps of (1,3) / (2,2) or more: Cg(1) + Cg(3), 2 Cg(2)          -- c_unk = the least of these; c* < c_unk is required;
 //   * two gaps of (1,1) or (1,2) / (2,1) symbols without a mismatch (costs 2 Cg(1), Cg(1) + Cg(2)): EXISTENCE is tested (over-approximated)
