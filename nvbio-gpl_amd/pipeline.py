@@ -807,3 +807,70 @@ def nvbowtie_best_approx_paired_host(fmi, genome2, genome_len, stored_mates1, st
         raise RuntimeError(_host_lib().nvbio_host_last_error().decode())
     return dict(best_a=best_a, best_o=best_o, n_extensions=int(st.n_extensions), n_opposite=int(st.n_opposite), passes=int(st.passes),
                 multi_passes=int(st.multi_passes))
+
+
+def nvbowtie_paired_traceback(genome2, genome_len, stored_mates1, stored_mates2, params, loop, nvb=None, cigar_stride=32):
+    """The traceback stage behind nvBowtie's paired loop (Aligner::best_approx: banded_traceback_best for the anchor mate, traceback_best for the
+    opposite mate, traceback_inl.h:191-275): for every pair the loop found (best_a[:, 0] paired), the anchor mate is traced back through the banded
+    traceback in the window BestAnchorScoreStream scored it in, the opposite mate through the full-matrix traceback from its window's begin to the
+    column its alignment ends in -- scores and sinks are the loop's, so neither scoring pass is repeated.
+    loop: the dict of nvbowtie_best_approx_paired_host.  -> dict( paired [R] bool; per mate m = 1, 2: begin{m} (text position where the alignment
+    starts, -1 unpaired), rc{m}, score{m}, cigars{m} [R, cigar_stride] (io::Cigar runs, backtracking order), cigar_lens{m} )."""
+    import torch
+    from . import BatchedAlignmentTraceback, BatchedBandedAlignmentTraceback
+    nvb = nvb or NvBowtieParams()
+    dev = loop["best_a"].device
+    R = stored_mates1.n
+    mates = (stored_mates1, stored_mates2)
+    a1 = loop["best_a"][:, 0].to(torch.int64); o1 = loop["best_o"][:, 0].to(torch.int64)
+    paired = (((a1[:, 3] >> 2) & 1) == 1) & (a1[:, 1] != -1)
+    out = {"paired": paired}
+    for m in (1, 2):
+        out["begin%d" % m] = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        out["rc%d" % m] = torch.zeros((R,), dtype=torch.uint8, device=dev)
+        out["score%d" % m] = torch.zeros((R,), dtype=torch.int32, device=dev)
+        out["cigars%d" % m] = torch.zeros((R, cigar_stride), dtype=torch.int16, device=dev)
+        out["cigar_lens%d" % m] = torch.zeros((R,), dtype=torch.int32, device=dev)
+    aligner = GotohAligner(params.aln_type, params.scheme)
+
+    def i32(t):
+        return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32)
+
+    def flags_of(rc):                                                  # reads stored reversed: forward = READ_REVERSE, reverse-complemented = READ_COMPLEMENT
+        return torch.where(rc.bool(), torch.full_like(rc, READ_COMPLEMENT), torch.full_like(rc, READ_REVERSE)).to(torch.uint8)
+
+    for am in (0, 1):                                                  # pairs whose anchor is mate am + 1
+        ids = torch.nonzero(paired & (((a1[:, 3] >> 1) & 1) == am)).view(-1)
+        if ids.numel() == 0:
+            continue
+        a, o = mates[am], mates[1 - am]
+        rid32 = ids.to(torch.int32)
+        # anchor: the band window of pe_anchor_flatten around hit.loc; sink.x = hit.sink - window begin
+        g = a1[ids, 1] & 0xFFFFFFFF
+        a_rc = (a1[ids, 3] & 1).to(torch.uint8)
+        wb = torch.where(g > nvb.band // 2, g - nvb.band // 2, torch.zeros_like(g))
+        we = torch.clamp(wb + nvb.band + a.read_len, max=genome_len)
+        sx = g + (a1[ids, 2] & 0xFFFFFFFF) - wb
+        a_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * a.read_len
+        batch = AlignmentBatch(a.reads4, 4, a_off, genome2, 2, i32(wb), i32(we), quals=a.quals, read_id=rid32, flags=flags_of(a_rc), device=dev, max_read_len=a.read_len)
+        sinks = torch.stack([i32(sx), torch.full_like(i32(sx), a.read_len)], dim=1).contiguous()
+        _, src, _, cig, ln = BatchedBandedAlignmentTraceback(nvb.band, aligner).enact(batch, cigar_stride=cigar_stride, scores=a1[ids, 0].to(torch.int32).contiguous(), sinks=sinks)
+        k = am + 1
+        out["begin%d" % k][ids] = wb + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        out["rc%d" % k][ids] = a_rc; out["score%d" % k][ids] = a1[ids, 0].to(torch.int32)
+        out["cigars%d" % k][ids] = cig; out["cigar_lens%d" % k][ids] = ln
+        # opposite mate: from its window's begin (alignment.pos) to the column it ends in (pos + sink)
+        ob = o1[ids, 1] & 0xFFFFFFFF
+        osx = o1[ids, 2] & 0xFFFFFFFF
+        o_rc = (o1[ids, 3] & 1).to(torch.uint8)
+        o_off = torch.arange(R + 1, device=dev, dtype=torch.int32) * o.read_len
+        batch = AlignmentBatch(o.reads4, 4, o_off, genome2, 2, i32(ob), i32(ob + osx), quals=o.quals, read_id=rid32, flags=flags_of(o_rc), device=dev, max_read_len=o.read_len)
+        sinks = torch.stack([i32(osx), torch.full_like(i32(osx), o.read_len)], dim=1).contiguous()
+        max_text = int(osx.max().item()) if ids.numel() else 1
+        _, src, _, cig, ln = BatchedAlignmentTraceback(aligner).enact(batch, o.read_len, max(max_text, 1), cigar_stride=cigar_stride,
+                                                                     scores=o1[ids, 0].to(torch.int32).contiguous(), sinks=sinks)
+        k = 2 - am
+        out["begin%d" % k][ids] = ob + (src[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        out["rc%d" % k][ids] = o_rc; out["score%d" % k][ids] = o1[ids, 0].to(torch.int32)
+        out["cigars%d" % k][ids] = cig; out["cigar_lens%d" % k][ids] = ln
+    return out

@@ -192,6 +192,37 @@ def test_paired_best_approx_loop_equals_the_oracle(amd, orc, mode):
         if not ff:                                                                 # the per-mate fallback holds mate 1 of the pairs that are none
             assert (a[72:100, 0, 1] != -1).mean() > 0.9 and not paired[72:100].any()
     assert n_paired > 0
+    # the traceback stage behind the loop: the anchor mate through the banded traceback in its band window, the opposite mate through the full-matrix
+    # traceback from its window's begin to the column it ends in; CIGARs and alignment begins equal the oracle's tracebacks of the same strings
+    tb = pipeline.nvbowtie_paired_traceback(g_dev, G, rb[0], rb[1], params, got, pipeline.NvBowtieParams(**kw), cigar_stride=32)
+    ba = got["best_a"].cpu().numpy().astype(np.int64); bo = got["best_o"].cpu().numpy().astype(np.int64)
+    is_pair = tb["paired"].cpu().numpy()
+    assert np.array_equal(is_pair, (((ba[:, 0, 3] >> 2) & 1) == 1) & (ba[:, 0, 1] != -1))
+    mates = (m1, m2)
+
+    def oriented(read, rc):
+        return (np.where(read[::-1] < 4, 3 - read[::-1], read[::-1]) if rc else read).astype(np.uint8)
+    checked = 0
+    for r in np.nonzero(is_pair)[0][::3]:
+        am = int((ba[r, 0, 3] >> 1) & 1); a_rc = int(ba[r, 0, 3] & 1); o_rc = int(bo[r, 0, 3] & 1)
+        Ma = mates[am].shape[1]
+        gpos = int(ba[r, 0, 1] & 0xFFFFFFFF)
+        wb = gpos - 15 if gpos > 15 else 0; we = min(wb + 31 + Ma, G)
+        ok, sc_, src_, snk_, cig_, _ = orc.banded_gotoh_traceback(31, oracle.SEMI_GLOBAL, osc, oriented(mates[am][r], a_rc), text[wb:we])
+        k = am + 1
+        assert sc_ == ba[r, 0, 0] and int(tb["score%d" % k][r]) == sc_, (mode, r, "anchor score")
+        assert int(tb["begin%d" % k][r]) == wb + src_[0] and int(tb["rc%d" % k][r]) == a_rc, (mode, r, "anchor begin")
+        n = int(tb["cigar_lens%d" % k][r])
+        assert n == len(cig_) and np.array_equal(tb["cigars%d" % k][r, :n].cpu().numpy().view(np.uint16), cig_), (mode, r, "anchor cigar")
+        ob = int(bo[r, 0, 1] & 0xFFFFFFFF); osx = int(bo[r, 0, 2] & 0xFFFFFFFF)
+        ok, sc_, src_, snk_, cig_ = orc.full_gotoh_traceback(oracle.SEMI_GLOBAL, osc, oriented(mates[1 - am][r], o_rc), text[ob:ob + osx])
+        k = 2 - am
+        assert sc_ == bo[r, 0, 0], (mode, r, "opposite score")
+        assert int(tb["begin%d" % k][r]) == ob + src_[0] and int(tb["rc%d" % k][r]) == o_rc, (mode, r, "opposite begin")
+        n = int(tb["cigar_lens%d" % k][r])
+        assert n == len(cig_) and np.array_equal(tb["cigars%d" % k][r, :n].cpu().numpy().view(np.uint16), cig_), (mode, r, "opposite cigar")
+        checked += 1
+    assert checked > 20
     fmi.close()
 
 
