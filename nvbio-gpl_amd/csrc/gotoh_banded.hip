@@ -1100,7 +1100,8 @@ ungapped_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const 
 // Not under a quality ramp.  Built and measured (members priced with the penalties their mismatching rows really carry, every split of them between
 // prefix and suffix; parity green): with penalties 2..6 the cheapest class the kernel cannot see -- one gap and three mismatches at the SMALLEST
 // penalty -- costs 14, so a job settles only while its optimum costs 13 or less; the third chance already takes U* >= -11 there, and on the robust
-// batch the pass cost 1.1-1.7 ms for 0.5-1.0 ms of DP saved.  It would take the ladder to five or six mismatches to pay.
+// batch the pass cost 1.1-1.7 ms for 0.5-1.0 ms of DP saved.  With the ladder taken to four priced mismatches per member (bound 18: two gaps and a
+// mismatch; also built, also green) the DP went 3.9 -> 2.7 ms and the pass cost 2.1: a job costs the pass half a DP and only half of them settle.
 template <int RBITS>
 __global__ void __launch_bounds__(256)
 gap_chance_e2e31_kernel(const BatchDev b, const int32_t P, const int32_t G, const int32_t gap_open, const int32_t gap_ext,
