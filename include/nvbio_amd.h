@@ -320,7 +320,7 @@ nvbio_status nvbio_fm_hamming_backtrack(nvbio_fm_index_t index, const nvbio_stri
  * records, SA word, text words): the unit in which the pass's memory traffic is accounted (a slower kernel instantiation,
  * for measurement harnesses).
  * temp_dev / temp_bytes: optional caller scratch (nvbio_fm_match_seed_diagonals_temp_bytes); if NULL the library allocates and
- * frees stream-ordered scratch itself. */
+ * frees scratch itself (blocks kept per stream: see "Conventions"). */
 nvbio_status nvbio_fm_match_seed_diagonals_temp_bytes(const nvbio_string_set* seeds, uint64_t* bytes);
 nvbio_status nvbio_fm_match_seed_diagonals(nvbio_fm_index_t index, const nvbio_string_set* seeds, uint32_t flags, uint32_t read_len,
                                            uint32_t strand, uint64_t* keys_dev, nvbio_uint2* residual_ranges_dev, uint32_t* residual_ids_dev,
@@ -857,7 +857,7 @@ nvbio_status nvbio_banded_gotoh_score_staged(int device, uint32_t band, nvbio_al
  * DP (the reference's tie rule makes their traceback all substitutions); the others run the DP once, writing
  * their direction vectors to scratch.  Results do not depend on which route a job takes.
  * temp_dev / temp_bytes: optional caller scratch (nvbio_banded_gotoh_traceback_temp_bytes); if NULL the library
- * allocates stream-ordered scratch and processes the batch in as many launches as 16 GiB allow. */
+ * allocates scratch (kept per stream) and processes the batch in as many launches as 16 GiB allow. */
 enum { NVBIO_TRACEBACK_SINKS_GIVEN = 1 };
 nvbio_status nvbio_banded_gotoh_traceback_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t band, uint64_t* bytes);
 nvbio_status nvbio_banded_gotoh_traceback(int device, uint32_t band, nvbio_alignment_type type,
@@ -927,7 +927,7 @@ nvbio_status nvbio_finish_alignment(int device, const nvbio_alignment_batch* bat
  * batched_inl.h:39-77).  text_blocking != 0 selects TextBlockingTag (sw-benchmark), 0 the default
  * PatternBlockingTag; min_scores_dev (optional) enables the reference's stripe early exit.
  * temp_dev / temp_bytes: optional caller scratch (see nvbio_full_gotoh_temp_bytes); if NULL the
- * library allocates and frees stream-ordered scratch itself. */
+ * library allocates and frees scratch itself (blocks kept per stream: see "Conventions"). */
 nvbio_status nvbio_full_gotoh_temp_bytes(const nvbio_alignment_batch* batch_host_sizes, uint32_t max_pattern_len,
                                          uint32_t max_text_len, int text_blocking, uint64_t* bytes);
 nvbio_status nvbio_full_gotoh_score(int device, nvbio_alignment_type type, int text_blocking,

@@ -144,8 +144,8 @@ _SCRATCH = {}
 def _scratch(device, nbytes, cap=8 << 30):
     """one persistent scratch tensor per device for the DP kernels' boundary columns / direction vectors (at most `cap`
     bytes; the library processes a batch in as many launches as the scratch allows).  Handing the library caller scratch
-    keeps multi-GiB stream-ordered allocations out of every call: their cost depends on the state of the HIP memory pool
-    (observed: an occasional 0.7 s stall in a paired-end step).  All users are ordered on the current stream."""
+    keeps multi-GiB allocations out of the call (the library would otherwise take a block of its own scratch cache for them and
+    keep it).  All users are ordered on the current stream."""
     torch = _torch()
     nbytes = int(min(max(nbytes, 1 << 20), cap))
     key = str(device)

@@ -419,7 +419,7 @@ def traceback_best_all(genome2, genome_len, reads, params, best_keys, best_wb, c
     batch = AlignmentBatch(reads.reads4, 4, read_off, genome2, 2, wb, we, quals=reads.quals, flags=flags, device=dev, max_read_len=M)
     known = dict(scores=scores, sinks=sinks) if params.aln_type != LOCAL else {}
     op = BatchedBandedAlignmentTraceback(params.band, GotohAligner(params.aln_type, params.scheme))
-    # the direction vectors of the gapped alignments (a minority) go to the persistent scratch: a multi-GiB stream-ordered allocation
+    # the direction vectors of the gapped alignments (a minority) go to the persistent scratch: a multi-GiB allocation
     # per call stalls the step for 0.1-0.2 s whenever the HIP pool has handed the memory back (measured)
     from . import _scratch
     temp = _scratch(dev, op.min_temp_storage(batch) // 4, cap=6 << 30)
@@ -584,7 +584,7 @@ def paired_end(fmi, genome2, genome_len, mates1, mates2, params, pe=None, timers
         batch = AlignmentBatch(a.reads4, 4, a_off, genome2, 2, i32(wb), i32(we), quals=a.quals, read_id=rid32,
                                flags=(a_rc.to(torch.uint8) * (READ_REVERSE | READ_COMPLEMENT)).to(torch.uint8), device=dev,
                                max_read_len=a.read_len)
-        # (direction vectors to the persistent scratch: a multi-GiB stream-ordered allocation inside the call stalls for ~0.1 s
+        # (direction vectors to the persistent scratch: a multi-GiB allocation inside the call stalls for ~0.1 s
         # whenever the HIP pool has handed the memory back)
         from . import _scratch
         tb_op = BatchedBandedAlignmentTraceback(params.band, aligner)
